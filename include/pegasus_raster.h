@@ -1,0 +1,145 @@
+/*
+ * pegasus_raster.h -- C ABI of libpegasus_raster.so, the MI355X (gfx950) Gaussian-splatting
+ * rasterizer that replaces PEGASUS's CUDA extension `diff_gaussian_rasterization._C`.
+ *
+ * What each entry point replaces.  The reference binds its rasterizer through a PyTorch C++
+ * extension that lives in an absent, un-pinned submodule
+ * (/root/reference/.gitmodules:1-3 ; installed by /root/reference/setup.sh:19), so the
+ * citations are to the reference's CALL SITES of that extension's Python surface:
+ *
+ *   pgr_forward            <- _C.rasterize_gaussians(...) behind GaussianRasterizer.forward;
+ *                             reached from render(): /root/reference/src/gs/render.py:16,57,86,118,
+ *                             /root/reference/pegasus.py:271
+ *   pgr_mark_visible       <- _C.mark_visible behind GaussianRasterizer.markVisible
+ *   pgr_color_masks        <- the colour-distance masks /root/reference/src/gs/render.py:60-63,89-93
+ *   pgr_quantize_frame     <- (img*255).astype(uint8), (depth*1000).astype(uint16):
+ *                             /root/reference/pegasus.py:347,355
+ *
+ * Conventions
+ *   - Every pointer in PgrScene / PgrCamera / PgrOutputs is a DEVICE address of a contiguous
+ *     array (fp32 / int32) in the layouts PEGASUS's GaussianModel getters produce
+ *     (/root/reference/src/gs/gaussian_model.py:105-128).  The caller (torch) owns all memory.
+ *   - The library never allocates or frees device memory and never touches the default stream:
+ *     all work is enqueued on `stream` (a hipStream_t passed as void*).
+ *   - Re-entrant, no global state.  One call = one stream = one workspace.
+ *   - Return value: 0 = enqueued; negative = PgrStatus.  pgr_status_string() names a code.
+ */
+#ifndef PEGASUS_RASTER_H
+#define PEGASUS_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGR_ABI_VERSION 1
+#define PGR_TILE_SIZE 16
+
+typedef enum PgrStatus {
+    PGR_OK = 0,
+    PGR_ERR_INVALID_ARGUMENT = -1,   /* NULL / inconsistent pointers, bad sizes, bad sh_degree */
+    PGR_ERR_WORKSPACE_TOO_SMALL = -2,/* workspace_bytes < pgr_workspace_bytes(...) */
+    PGR_ERR_INSTANCE_OVERFLOW = -3,  /* sum(tiles_touched) > max_instances; *num_instances holds the need */
+    PGR_ERR_LAUNCH_FAILURE = -4,     /* a HIP call failed; see pgr_last_hip_error */
+    PGR_ERR_NO_DEVICE = -5
+} PgrStatus;
+
+/* One merged point cloud (environment first, then objects), activated values. */
+typedef struct PgrScene {
+    int32_t n;                   /* Gaussians */
+    const float *means3d;        /* [n,3]  get_xyz */
+    const float *opacities;      /* [n]    get_opacity (sigmoid applied) */
+    const float *scales;         /* [n,3]  get_scaling (exp applied)      -- or NULL with cov3d_precomp */
+    const float *rotations;      /* [n,4]  get_rotation (w,x,y,z), unit   -- or NULL with cov3d_precomp */
+    const float *cov3d_precomp;  /* [n,6]  (xx,xy,xz,yy,yz,zz)            -- or NULL */
+    const float *shs;            /* [n,sh_stride,3] get_features          -- or NULL with colors_precomp */
+    const float *colors_precomp; /* [n,3]                                 -- or NULL */
+    int32_t sh_degree;           /* active degree 0..3 */
+    int32_t sh_stride;           /* coefficients stored per Gaussian, >= (sh_degree+1)^2 */
+    float scale_modifier;
+} PgrScene;
+
+/* The fields of GaussianRasterizationSettings that describe one view.  Scalars are host values;
+ * the four small tensors stay on the device exactly as PEGASUS's Camera holds them. */
+typedef struct PgrCamera {
+    int32_t image_width, image_height;
+    float tanfovx, tanfovy;
+    const float *viewmatrix;     /* device [16], world_view_transform (transposed storage) */
+    const float *projmatrix;     /* device [16], full_proj_transform  (transposed storage) */
+    const float *campos;         /* device [3] */
+    const float *bg;             /* device [3] */
+} PgrCamera;
+
+typedef struct PgrOutputs {
+    float *color;                /* [3,H,W]  required */
+    float *depth;                /* [1,H,W]  required: sum_i T_i alpha_i z_i (no bg, not normalised) */
+    int32_t *radii;              /* [n]      required */
+    float *final_T;              /* [H,W]    optional (NULL) */
+    uint32_t *n_contrib;         /* [H,W]    optional (NULL) */
+} PgrOutputs;
+
+/* Device pointers into a workspace, for stage-level parity tests and for backward. */
+typedef struct PgrWorkspaceView {
+    const float *xy;             /* [n,2] */
+    const float *depth;          /* [n]   */
+    const float *conic_opacity;  /* [n,4] */
+    const float *rgb;            /* [n,4] (r,g,b,unused) */
+    const uint32_t *tiles_touched; /* [n] */
+    const uint32_t *offsets;     /* [n] inclusive scan */
+    const uint64_t *keys_sorted; /* [num_instances] (tile << 32) | depth bits */
+    const uint32_t *gauss_sorted;/* [num_instances] */
+    const uint32_t *ranges;      /* [tiles,2] */
+    const uint32_t *num_instances; /* [1] device counter */
+} PgrWorkspaceView;
+
+int32_t pgr_abi_version(void);
+const char *pgr_version(void);
+const char *pgr_status_string(int32_t status);
+/* Text of the last HIP error seen by THIS thread inside the library (thread-local, read-only use). */
+const char *pgr_last_hip_error(void);
+
+/* Bytes of workspace needed to render one view of `n` Gaussians at width x height with room for
+ * `max_instances` (Gaussian,tile) pairs. */
+size_t pgr_workspace_bytes(int32_t n, int32_t width, int32_t height, int64_t max_instances);
+
+/* Render one view.  `num_instances` (host, optional) receives sum(tiles_touched).  The call
+ * synchronises `stream` once, after the offset scan, exactly where the reference reads
+ * num_rendered back, so that an overflow is reported instead of rendered. */
+int32_t pgr_forward(const PgrScene *scene, const PgrCamera *camera, const PgrOutputs *out,
+                    void *workspace, size_t workspace_bytes, int64_t max_instances,
+                    int64_t *num_instances, void *stream);
+
+/* Profiling twin of pgr_forward (bench / rocprof only): records HIP events on `stream` at the stage
+ * boundaries, synchronises, and writes the elapsed milliseconds of each stage to stage_ms[PGR_NUM_STAGES]
+ * in the order of PgrStage. */
+#define PGR_NUM_STAGES 6
+typedef enum PgrStage {
+    PGR_STAGE_PREPROCESS = 0, PGR_STAGE_SCAN = 1, PGR_STAGE_EMIT = 2, PGR_STAGE_SORT = 3,
+    PGR_STAGE_RANGES = 4, PGR_STAGE_COMPOSITE = 5
+} PgrStage;
+int32_t pgr_forward_profiled(const PgrScene *scene, const PgrCamera *camera, const PgrOutputs *out,
+                             void *workspace, size_t workspace_bytes, int64_t max_instances,
+                             int64_t *num_instances, void *stream, float *stage_ms);
+
+/* Fill `view` with device pointers into a workspace laid out for (n,width,height,max_instances). */
+int32_t pgr_workspace_view(void *workspace, size_t workspace_bytes, int32_t n, int32_t width, int32_t height,
+                           int64_t max_instances, PgrWorkspaceView *view);
+
+/* present[i] = 1 iff Gaussian i passes the near-plane test of `viewmatrix` (device [16]). */
+int32_t pgr_mark_visible(int32_t n, const float *means3d, const float *viewmatrix, uint8_t *present,
+                         void *stream);
+
+/* masks[k,y,x] = || img[:,y,x] - colors[k,:] ||_2 <= threshold   (uint8 0/1), img is CHW fp32. */
+int32_t pgr_color_masks(const float *img_chw, int32_t width, int32_t height, const float *colors_k3,
+                        int32_t k, float threshold, uint8_t *masks_khw, void *stream);
+
+/* rgb_hwc = uint8(img*255) (wraps, no clamp), depth_mm = uint16(depth*1000). Either pair may be NULL. */
+int32_t pgr_quantize_frame(const float *img_chw, const float *depth_hw, int32_t width, int32_t height,
+                           uint8_t *rgb_hwc, uint16_t *depth_mm_hw, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEGASUS_RASTER_H */

@@ -1,0 +1,107 @@
+"""ctypes binding of libpegasus_raster.so (include/pegasus_raster.h).
+
+There is NO fallback: if the library is missing or fails to load, every rasterizer entry point
+raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libpegasus_raster.so"
+
+PGR_OK = 0
+PGR_ERR_INVALID_ARGUMENT = -1
+PGR_ERR_WORKSPACE_TOO_SMALL = -2
+PGR_ERR_INSTANCE_OVERFLOW = -3
+PGR_ERR_LAUNCH_FAILURE = -4
+PGR_NUM_STAGES = 6
+STAGE_NAMES = ("preprocess", "scan", "emit", "sort", "ranges", "composite")
+
+
+class PgrScene(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32),
+        ("means3d", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
+        ("cov3d_precomp", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+        ("sh_degree", C.c_int32), ("sh_stride", C.c_int32), ("scale_modifier", C.c_float),
+    ]
+
+
+class PgrCamera(C.Structure):
+    _fields_ = [
+        ("image_width", C.c_int32), ("image_height", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+        ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("bg", C.c_void_p),
+    ]
+
+
+class PgrOutputs(C.Structure):
+    _fields_ = [("color", C.c_void_p), ("depth", C.c_void_p), ("radii", C.c_void_p), ("final_T", C.c_void_p),
+                ("n_contrib", C.c_void_p)]
+
+
+class PgrWorkspaceView(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("xy", "depth", "conic_opacity", "rgb", "tiles_touched", "offsets",
+                                          "keys_sorted", "gauss_sorted", "ranges", "num_instances")]
+
+
+# every symbol include/pegasus_raster.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "pgr_abi_version": (C.c_int32, []),
+    "pgr_version": (C.c_char_p, []),
+    "pgr_status_string": (C.c_char_p, [C.c_int32]),
+    "pgr_last_hip_error": (C.c_char_p, []),
+    "pgr_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
+    "pgr_forward": (C.c_int32, [C.POINTER(PgrScene), C.POINTER(PgrCamera), C.POINTER(PgrOutputs), C.c_void_p,
+                                C.c_size_t, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
+    "pgr_forward_profiled": (C.c_int32, [C.POINTER(PgrScene), C.POINTER(PgrCamera), C.POINTER(PgrOutputs),
+                                         C.c_void_p, C.c_size_t, C.c_int64, C.POINTER(C.c_int64), C.c_void_p,
+                                         C.POINTER(C.c_float)]),
+    "pgr_workspace_view": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                                       C.POINTER(PgrWorkspaceView)]),
+    "pgr_mark_visible": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pgr_color_masks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
+                                    C.c_void_p, C.c_void_p]),
+    "pgr_quantize_frame": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
+}
+
+_lib = None
+
+
+class RasterizerLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads the HIP library (once).  Raises RasterizerLibraryError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RasterizerLibraryError(
+                f"{LIB_PATH} is missing: build it with `python -m pegasus_amd.build` "
+                "(there is no CPU fallback for the rasterizer)")
+        try:
+            handle = C.CDLL(str(LIB_PATH))
+        except OSError as e:
+            raise RasterizerLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.pgr_abi_version() != 1:
+            raise RasterizerLibraryError("libpegasus_raster.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str = "pegasus_raster"):
+    if status == PGR_OK:
+        return
+    L = lib()
+    msg = f"{what}: {L.pgr_status_string(status).decode()} ({status})"
+    if status == PGR_ERR_LAUNCH_FAILURE:
+        msg += f" [{L.pgr_last_hip_error().decode()}]"
+    if status == PGR_ERR_INVALID_ARGUMENT:
+        raise ValueError(msg)
+    raise RuntimeError(msg)

@@ -1,0 +1,45 @@
+"""Builds pegasus_amd/csrc/libpegasus_raster.so for gfx950 with hipcc (in-tree; the .so is git-ignored
+but travels to the GPU box with the working-tree snapshot)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB = CSRC / "libpegasus_raster.so"
+ARCH = "gfx950"
+# -ffp-contract=off: every fused multiply-add in the kernels is an explicit fmaf(), which is what
+# makes the integer stages bit-exact against the oracle (DESIGN.md "Arithmetic contract").
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", f"--offload-arch={ARCH}"]
+
+
+def sources():
+    return sorted(CSRC.glob("*.hip")), sorted(CSRC.glob("*.h")) + [CSRC.parents[1] / "include" / "pegasus_raster.h"]
+
+
+def needs_build() -> bool:
+    if not LIB.exists():
+        return True
+    srcs, hdrs = sources()
+    newest = max(p.stat().st_mtime for p in srcs + hdrs)
+    return LIB.stat().st_mtime < newest
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    if not force and not needs_build():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    srcs, _ = sources()
+    tmp = LIB.with_suffix(f".tmp{os.getpid()}.so")
+    cmd = [hipcc, *FLAGS, "-o", str(tmp), *map(str, srcs)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=str(CSRC))
+    os.replace(tmp, LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

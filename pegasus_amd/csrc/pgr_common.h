@@ -1,0 +1,46 @@
+// pgr_common.h -- shared device/host definitions for libpegasus_raster (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pegasus_raster.h"
+
+namespace pgr {
+
+constexpr int TILE = PGR_TILE_SIZE;          // 16x16 pixel tiles (part of the contract: radii/tiles_touched)
+constexpr int WAVE = 64;                     // gfx950 wavefront
+constexpr float NEAR_Z = 0.2f;
+constexpr float LOWPASS = 0.3f;
+constexpr float ALPHA_MAX = 0.99f;
+constexpr float ALPHA_MIN = 1.0f / 255.0f;
+constexpr float T_EPS = 0.0001f;
+
+// Per-view constants, resident in HBM so that no host round trip is needed to read the
+// caller's device-side camera tensors.  256 B, read through the scalar cache.
+struct alignas(16) CameraDev {
+    float view[16];
+    float proj[16];
+    float campos[3];
+    float tanfovx;
+    float bg[3];
+    float tanfovy;
+    float focal_x, focal_y;
+    int32_t width, height;
+    int32_t grid_x, grid_y;
+    int32_t pad[2];
+    float pad2[16];
+};
+static_assert(sizeof(CameraDev) == 256, "CameraDev must be 256 B");
+
+// Workspace carve-up (all offsets multiples of 256 B).
+struct Layout {
+    size_t cam, counters, xy, depth, conic_opacity, rgb, tiles_touched, offsets, block_sums,
+        keys_unsorted, vals_unsorted, keys_sorted, vals_sorted, ranges, sort_temp, total;
+    size_t sort_temp_bytes;
+    int32_t tiles;
+    int32_t n_blocks;
+};
+
+constexpr int PRE_BLOCK = 256;               // Gaussians per preprocess workgroup
+
+}  // namespace pgr

@@ -1,0 +1,280 @@
+// preprocess.hip.h -- per-Gaussian projection, EWA covariance, SH colour, tile rectangle.
+//
+// Replaces the per-Gaussian stage of the reference's missing CUDA extension (SURVEY.md
+// section 8a row a5; call sites /root/reference/src/gs/render.py:16, /root/reference/pegasus.py:271).
+// Arithmetic contract: identical operation order to oracle/pgr_oracle.c (fp32, explicit fmaf,
+// translation unit compiled with -ffp-contract=off) => every output of this kernel is bit-exact
+// against the oracle.
+//
+// HBM-bound: reads 12 B (xyz) for every Gaussian, +28 B (scale, rotation) for the ones in front of
+// the near plane, +196 B (opacity, 48 SH floats) for the ones whose tile rectangle is non-empty;
+// writes 4+4 B (radius, tiles_touched) for every Gaussian and 44 B for survivors.
+#pragma once
+#include "pgr_common.h"
+
+namespace pgr {
+
+__device__ __forceinline__ float dot3_chain(float a0, float b0, float a1, float b1, float a2, float b2) {
+    return fmaf(a2, b2, fmaf(a1, b1, a0 * b0));
+}
+
+__device__ __forceinline__ int clamp_trunc(float f, int hi) {
+    if (!(f > 0.0f)) return 0;
+    if (f >= (float)hi) return hi;
+    return (int)f;
+}
+
+struct TileRect { int minx, miny, maxx, maxy; };
+
+__device__ __forceinline__ TileRect tile_rect(float px, float py, int radius, int grid_x, int grid_y) {
+    const float rf = (float)radius;
+    TileRect r;
+    r.minx = clamp_trunc((px - rf) / (float)TILE, grid_x);
+    r.miny = clamp_trunc((py - rf) / (float)TILE, grid_y);
+    r.maxx = clamp_trunc((px + rf + (float)(TILE - 1)) / (float)TILE, grid_x);
+    r.maxy = clamp_trunc((py + rf + (float)(TILE - 1)) / (float)TILE, grid_y);
+    return r;
+}
+
+__device__ __forceinline__ void cov3d_from_scale_rot(float s0, float s1, float s2, float mod, float4 q, float cov[6]) {
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    float R[3][3];
+    R[0][0] = 1.0f - 2.0f * (y * y + z * z);
+    R[0][1] = 2.0f * (x * y - r * z);
+    R[0][2] = 2.0f * (x * z + r * y);
+    R[1][0] = 2.0f * (x * y + r * z);
+    R[1][1] = 1.0f - 2.0f * (x * x + z * z);
+    R[1][2] = 2.0f * (y * z - r * x);
+    R[2][0] = 2.0f * (x * z - r * y);
+    R[2][1] = 2.0f * (y * z + r * x);
+    R[2][2] = 1.0f - 2.0f * (x * x + y * y);
+    const float sx = mod * s0, sy = mod * s1, sz = mod * s2;
+    float M[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        M[i][0] = R[i][0] * sx;
+        M[i][1] = R[i][1] * sy;
+        M[i][2] = R[i][2] * sz;
+    }
+    cov[0] = dot3_chain(M[0][0], M[0][0], M[0][1], M[0][1], M[0][2], M[0][2]);
+    cov[1] = dot3_chain(M[0][0], M[1][0], M[0][1], M[1][1], M[0][2], M[1][2]);
+    cov[2] = dot3_chain(M[0][0], M[2][0], M[0][1], M[2][1], M[0][2], M[2][2]);
+    cov[3] = dot3_chain(M[1][0], M[1][0], M[1][1], M[1][1], M[1][2], M[1][2]);
+    cov[4] = dot3_chain(M[1][0], M[2][0], M[1][1], M[2][1], M[1][2], M[2][2]);
+    cov[5] = dot3_chain(M[2][0], M[2][0], M[2][1], M[2][1], M[2][2], M[2][2]);
+}
+
+template <int DEG>
+__device__ __forceinline__ void sh_basis(float x, float y, float z, float b[16]) {
+    constexpr float C0 = 0.28209479177387814f;
+    constexpr float C1 = 0.4886025119029199f;
+    constexpr float C2_0 = 1.0925484305920792f, C2_1 = -1.0925484305920792f, C2_2 = 0.31539156525252005f,
+                    C2_3 = -1.0925484305920792f, C2_4 = 0.5462742152960396f;
+    constexpr float C3_0 = -0.5900435899266435f, C3_1 = 2.890611442640554f, C3_2 = -0.4570457994644658f,
+                    C3_3 = 0.3731763325901154f, C3_4 = -0.4570457994644658f, C3_5 = 1.445305721320277f,
+                    C3_6 = -0.5900435899266435f;
+    b[0] = C0;
+    if constexpr (DEG > 0) {
+        b[1] = -(C1 * y);
+        b[2] = C1 * z;
+        b[3] = -(C1 * x);
+    }
+    if constexpr (DEG > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z;
+        const float xy = x * y, yz = y * z, xz = x * z;
+        b[4] = C2_0 * xy;
+        b[5] = C2_1 * yz;
+        b[6] = C2_2 * (2.0f * zz - xx - yy);
+        b[7] = C2_3 * xz;
+        b[8] = C2_4 * (xx - yy);
+        if constexpr (DEG > 2) {
+            b[9] = C3_0 * y * (3.0f * xx - yy);
+            b[10] = C3_1 * xy * z;
+            b[11] = C3_2 * y * (4.0f * zz - xx - yy);
+            b[12] = C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+            b[13] = C3_4 * x * (4.0f * zz - xx - yy);
+            b[14] = C3_5 * z * (xx - yy);
+            b[15] = C3_6 * x * (xx - 3.0f * yy);
+        }
+    }
+}
+
+// SH -> RGB for one Gaussian, coefficients read straight from HBM (12 B per coefficient).
+template <int DEG>
+__device__ __forceinline__ float3 sh_to_rgb(const float* __restrict__ sh, float dx, float dy, float dz) {
+    float b[16];
+    sh_basis<DEG>(dx, dy, dz, b);
+    constexpr int NC = (DEG + 1) * (DEG + 1);
+    float acc[3];
+    // coefficient-major, RGB-minor: 3*NC contiguous floats; 16-B aligned when the stride is 16
+    acc[0] = b[0] * sh[0];
+    acc[1] = b[0] * sh[1];
+    acc[2] = b[0] * sh[2];
+#pragma unroll
+    for (int k = 1; k < NC; ++k) {
+        acc[0] = fmaf(b[k], sh[3 * k + 0], acc[0]);
+        acc[1] = fmaf(b[k], sh[3 * k + 1], acc[1]);
+        acc[2] = fmaf(b[k], sh[3 * k + 2], acc[2]);
+    }
+    return make_float3(fmaxf(acc[0] + 0.5f, 0.0f), fmaxf(acc[1] + 0.5f, 0.0f), fmaxf(acc[2] + 0.5f, 0.0f));
+}
+
+struct PreOut {
+    float2* xy;
+    float* depth;
+    float4* conic_opacity;
+    float4* rgb;             // (r,g,b,depth)
+    uint32_t* tiles_touched;
+    int32_t* radii;
+    uint32_t* block_sums;    // [gridDim.x] sum of tiles_touched per workgroup
+};
+
+__global__ __launch_bounds__(PRE_BLOCK) void preprocess_kernel(PgrScene sc, const CameraDev* __restrict__ camp,
+                                                               PreOut o) {
+    const CameraDev& cam = *camp;
+    const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    uint32_t touched = 0;
+    int radius = 0;
+
+    if (i < sc.n) {
+        const float px = sc.means3d[3 * i + 0], py = sc.means3d[3 * i + 1], pz = sc.means3d[3 * i + 2];
+        const float* vm = cam.view;
+        const float* pm = cam.proj;
+        float tx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
+        float ty = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
+        const float tz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
+        if (tz > NEAR_Z) {
+            const float hx = pm[0] * px + pm[4] * py + pm[8] * pz + pm[12];
+            const float hy = pm[1] * px + pm[5] * py + pm[9] * pz + pm[13];
+            const float hw = pm[3] * px + pm[7] * py + pm[11] * pz + pm[15];
+            const float p_w = 1.0f / (hw + 0.0000001f);
+            const float ndc_x = hx * p_w, ndc_y = hy * p_w;
+
+            float cov[6];
+            if (sc.cov3d_precomp) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) cov[k] = sc.cov3d_precomp[6 * (size_t)i + k];
+            } else {
+                const float4 q = reinterpret_cast<const float4*>(sc.rotations)[i];
+                cov3d_from_scale_rot(sc.scales[3 * i + 0], sc.scales[3 * i + 1], sc.scales[3 * i + 2],
+                                     sc.scale_modifier, q, cov);
+            }
+
+            const float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
+            const float txtz = tx / tz, tytz = ty / tz;
+            tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+            ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+            const float j00 = cam.focal_x / tz;
+            const float j02 = -(cam.focal_x * tx) / (tz * tz);
+            const float j11 = cam.focal_y / tz;
+            const float j12 = -(cam.focal_y * ty) / (tz * tz);
+            float T0[3], T1[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                T0[c] = fmaf(j02, vm[4 * c + 2], j00 * vm[4 * c + 0]);
+                T1[c] = fmaf(j12, vm[4 * c + 2], j11 * vm[4 * c + 1]);
+            }
+            const float S[3][3] = {{cov[0], cov[1], cov[2]}, {cov[1], cov[3], cov[4]}, {cov[2], cov[4], cov[5]}};
+            float U0[3], U1[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                U0[c] = dot3_chain(T0[0], S[0][c], T0[1], S[1][c], T0[2], S[2][c]);
+                U1[c] = dot3_chain(T1[0], S[0][c], T1[1], S[1][c], T1[2], S[2][c]);
+            }
+            const float c_xx = dot3_chain(U0[0], T0[0], U0[1], T0[1], U0[2], T0[2]) + LOWPASS;
+            const float c_xy = dot3_chain(U0[0], T1[0], U0[1], T1[1], U0[2], T1[2]);
+            const float c_yy = dot3_chain(U1[0], T1[0], U1[1], T1[1], U1[2], T1[2]) + LOWPASS;
+
+            const float det = c_xx * c_yy - c_xy * c_xy;
+            if (det != 0.0f) {
+                const float det_inv = 1.0f / det;
+                const float con_x = c_yy * det_inv, con_y = -c_xy * det_inv, con_z = c_xx * det_inv;
+                const float mid = 0.5f * (c_xx + c_yy);
+                const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float lambda1 = mid + disc, lambda2 = mid - disc;
+                const float rad_f = ceilf(3.0f * sqrtf(fmaxf(lambda1, lambda2)));
+                const int rad = rad_f >= 2147483520.0f ? 2147483520 : (int)rad_f;
+                const float pix_x = ((ndc_x + 1.0f) * (float)cam.width - 1.0f) * 0.5f;
+                const float pix_y = ((ndc_y + 1.0f) * (float)cam.height - 1.0f) * 0.5f;
+                const TileRect r = tile_rect(pix_x, pix_y, rad, cam.grid_x, cam.grid_y);
+                const int w = r.maxx - r.minx, h = r.maxy - r.miny;
+                if (w > 0 && h > 0) {
+                    float3 rgb;
+                    if (sc.colors_precomp) {
+                        rgb = make_float3(sc.colors_precomp[3 * (size_t)i], sc.colors_precomp[3 * (size_t)i + 1],
+                                          sc.colors_precomp[3 * (size_t)i + 2]);
+                    } else {
+                        float dx = px - cam.campos[0], dy = py - cam.campos[1], dz = pz - cam.campos[2];
+                        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                        dx = dx / len; dy = dy / len; dz = dz / len;
+                        const float* sh = sc.shs + (size_t)i * sc.sh_stride * 3;
+                        switch (sc.sh_degree) {
+                            case 0: rgb = sh_to_rgb<0>(sh, dx, dy, dz); break;
+                            case 1: rgb = sh_to_rgb<1>(sh, dx, dy, dz); break;
+                            case 2: rgb = sh_to_rgb<2>(sh, dx, dy, dz); break;
+                            default: rgb = sh_to_rgb<3>(sh, dx, dy, dz); break;
+                        }
+                    }
+                    radius = rad;
+                    touched = (uint32_t)(w * h);
+                    o.xy[i] = make_float2(pix_x, pix_y);
+                    o.depth[i] = tz;
+                    o.conic_opacity[i] = make_float4(con_x, con_y, con_z, sc.opacities[i]);
+                    o.rgb[i] = make_float4(rgb.x, rgb.y, rgb.z, tz);
+                }
+            }
+        }
+        o.radii[i] = radius;
+        o.tiles_touched[i] = touched;
+    }
+
+    // workgroup sum of tiles_touched -> block_sums (feeds the offset scan without re-reading HBM)
+    uint32_t s = touched;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, WAVE);
+    __shared__ uint32_t wave_sums[PRE_BLOCK / WAVE];
+    if ((threadIdx.x & (WAVE - 1)) == 0) wave_sums[threadIdx.x / WAVE] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < PRE_BLOCK / WAVE; ++w) t += wave_sums[w];
+        o.block_sums[blockIdx.x] = t;
+    }
+}
+
+// packs the caller's four device-side camera tensors + host scalars into one CameraDev
+__global__ void pack_camera_kernel(const float* __restrict__ view, const float* __restrict__ proj,
+                                   const float* __restrict__ campos, const float* __restrict__ bg, float tanfovx,
+                                   float tanfovy, int width, int height, CameraDev* out) {
+    const int t = threadIdx.x;
+    if (t < 16) {
+        out->view[t] = view[t];
+        out->proj[t] = proj[t];
+    }
+    if (t < 3) {
+        out->campos[t] = campos[t];
+        out->bg[t] = bg[t];
+    }
+    if (t == 0) {
+        out->tanfovx = tanfovx;
+        out->tanfovy = tanfovy;
+        out->focal_x = (float)width / (2.0f * tanfovx);
+        out->focal_y = (float)height / (2.0f * tanfovy);
+        out->width = width;
+        out->height = height;
+        out->grid_x = (width + TILE - 1) / TILE;
+        out->grid_y = (height + TILE - 1) / TILE;
+    }
+}
+
+__global__ void mark_visible_kernel(int n, const float* __restrict__ means3d, const float* __restrict__ vm,
+                                    uint8_t* __restrict__ present) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float px = means3d[3 * i], py = means3d[3 * i + 1], pz = means3d[3 * i + 2];
+    const float tz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
+    present[i] = tz > NEAR_Z ? 1 : 0;
+}
+
+}  // namespace pgr

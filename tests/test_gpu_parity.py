@@ -1,0 +1,163 @@
+"""GPU parity: the HIP path (through the drop-in surface and the C ABI) against the CPU oracle on the
+same seeded inputs.  Integer/index stages bit-exact; images within BASELINE.json's 1e-4."""
+import math
+
+import numpy as np
+import pytest
+
+from pegasus_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_both(oracle, cloud, view, gpu_device, sh_degree=3, bg=(0.0, 0.0, 0.0), **kw):
+    from helpers import gpu_forward
+    act = cloud.activated()
+    o = oracle.forward(**act, sh_degree=sh_degree, **view.raster_kwargs(bg), num_threads=8,
+                       scale_modifier=kw.get("scale_modifier", 1.0))
+    g = gpu_forward(act, view, sh_degree=sh_degree, bg=bg, device=str(gpu_device), **kw)
+    return g, o
+
+
+def _check_all(g, o):
+    from helpers import assert_images_match, assert_preprocess_bit_exact
+    assert_preprocess_bit_exact(g, o)
+    assert g["num_instances"] == o["num_instances"]
+    np.testing.assert_array_equal(g["offsets"], np.cumsum(o["tiles_touched"], dtype=np.uint32))
+    np.testing.assert_array_equal(g["keys_sorted"], o["keys_sorted"])
+    np.testing.assert_array_equal(g["gauss_sorted"], o["gauss_sorted"])
+    np.testing.assert_array_equal(g["ranges"], o["ranges"])
+    assert_images_match(g, o)
+
+
+def test_c1_cube_256(oracle, gpu_device):
+    cloud, views = scenes.scene_c1()
+    g, o = _run_both(oracle, cloud, views[0], gpu_device)
+    _check_all(g, o)
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_degrees_and_background(oracle, gpu_device, deg):
+    cloud, views = scenes.scene_c1(seed=10 + deg, n=3000)
+    g, o = _run_both(oracle, cloud, views[0], gpu_device, sh_degree=deg, bg=(0.25, 0.5, 1.0))
+    _check_all(g, o)
+
+
+def test_c2_object_800(oracle, gpu_device):
+    cloud, views = scenes.scene_c2(n=150_000, n_views=3)
+    for v in views:
+        g, o = _run_both(oracle, cloud, v, gpu_device)
+        _check_all(g, o)
+
+
+def test_c3_merged_scene_scaled(oracle, gpu_device):
+    cloud, views = scenes.scene_c3(scale=0.1, n_views=2)
+    for v in views:
+        g, o = _run_both(oracle, cloud, v, gpu_device)
+        _check_all(g, o)
+
+
+def test_ragged_image_size(oracle, gpu_device):
+    """Width/height not multiples of 16 (PEGASUS default is 640x480; also an odd size)."""
+    cloud, _ = scenes.scene_c1(seed=5, n=5000)
+    fov = math.radians(50)
+    from pegasus_amd import graphics as G
+    R, t = G.look_at_opencv((0.3, -0.2, -3.0), (0, 0, 0), up=(0, -1, 0))
+    for (w, h) in ((640, 480), (333, 211)):
+        v = scenes.make_view(R, t, w, h, fovx=fov, fovy=fov * h / w)
+        g, o = _run_both(oracle, cloud, v, gpu_device)
+        _check_all(g, o)
+
+
+def test_scale_modifier(oracle, gpu_device):
+    cloud, views = scenes.scene_c1(seed=6, n=2000)
+    g, o = _run_both(oracle, cloud, views[0], gpu_device, scale_modifier=1.7)
+    _check_all(g, o)
+
+
+def test_all_culled_gives_background(oracle, gpu_device):
+    """Every Gaussian behind the near plane: image = bg, depth 0, radii 0."""
+    cloud, views = scenes.scene_c1(seed=7, n=500)
+    cloud.xyz[:, 2] -= 10.0   # camera sits at z=-3 looking +z
+    g, o = _run_both(oracle, cloud, views[0], gpu_device, bg=(0.1, 0.2, 0.3))
+    assert (g["radii"] == 0).all() and g["num_instances"] == 0
+    np.testing.assert_array_equal(g["color"], o["color"])
+    assert np.allclose(g["color"][1], 0.2) and (g["out_depth"] == 0).all()
+
+
+def test_empty_scene_stays_zero(gpu_device):
+    import torch
+    from pegasus_amd import diff_gaussian_rasterization as dgr
+    dev = gpu_device
+    s = dgr.GaussianRasterizationSettings(64, 64, 0.5, 0.5, torch.ones(3, device=dev), 1.0,
+                                          torch.eye(4, device=dev), torch.eye(4, device=dev), 0,
+                                          torch.zeros(3, device=dev), False, False)
+    color, radii, depth = dgr.GaussianRasterizer(s)(
+        torch.zeros((0, 3), device=dev), None, torch.zeros((0, 1), device=dev),
+        shs=torch.zeros((0, 16, 3), device=dev), scales=torch.zeros((0, 3), device=dev),
+        rotations=torch.zeros((0, 4), device=dev))
+    assert color.shape == (3, 64, 64) and depth.shape == (1, 64, 64) and radii.shape == (0,)
+    assert float(color.abs().max()) == 0.0 and float(depth.abs().max()) == 0.0
+
+
+def test_precomputed_colour_and_cov(oracle, gpu_device):
+    from helpers import gpu_forward, assert_images_match
+    cloud, views = scenes.scene_c1(seed=8, n=4000)
+    act = cloud.activated()
+    v = views[0]
+    base = oracle.forward(**act, sh_degree=3, **v.raster_kwargs(), stage="preprocess")
+    colors = np.random.default_rng(0).uniform(0, 1, size=(cloud.n, 3)).astype(np.float32)
+    kw = dict(means3d=act["means3d"], opacities=act["opacities"], cov3d_precomp=base["cov3d"],
+              colors_precomp=colors)
+    o = oracle.forward(**kw, **v.raster_kwargs(), num_threads=4)
+    g = gpu_forward(act, v, colors_precomp=colors, cov3d_precomp=base["cov3d"], device=str(gpu_device))
+    np.testing.assert_array_equal(g["radii"], o["radii"])
+    np.testing.assert_array_equal(g["gauss_sorted"], o["gauss_sorted"])
+    assert_images_match(g, o)
+
+
+def test_mark_visible(oracle, gpu_device):
+    import torch
+    from pegasus_amd import diff_gaussian_rasterization as dgr
+    cloud, views = scenes.scene_c1(seed=9, n=4096 + 17)
+    cloud.xyz[::3, 2] -= 3.5
+    v = views[0]
+    dev = gpu_device
+    s = dgr.GaussianRasterizationSettings(v.height, v.width, v.tanfovx, v.tanfovy, torch.zeros(3, device=dev), 1.0,
+                                          torch.from_numpy(v.world_view_transform).to(dev),
+                                          torch.from_numpy(v.full_proj_transform).to(dev), 3,
+                                          torch.from_numpy(v.camera_center).to(dev), False, False)
+    vis = dgr.GaussianRasterizer(s).markVisible(torch.from_numpy(cloud.xyz).to(dev)).cpu().numpy()
+    np.testing.assert_array_equal(vis, oracle.mark_visible(cloud.xyz, v.world_view_transform))
+    assert 0 < vis.sum() < vis.size
+
+
+def test_masks_and_quantisation(oracle, gpu_device):
+    import ctypes as C
+    import torch
+    from pegasus_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    H, W, K = 120, 200, 5
+    colors = rng.uniform(0, 1, size=(K, 3)).astype(np.float32)
+    img = rng.uniform(0, 1.3, size=(3, H, W)).astype(np.float32)
+    for k in range(K):   # paint patches near each colour, some just inside / outside the 0.1 ball
+        img[:, 10 * k:10 * k + 8, :50] = colors[k][:, None, None] + rng.normal(0, 0.05, size=(3, 8, 50))
+    depth = rng.uniform(0, 70, size=(H, W)).astype(np.float32)
+    dev = gpu_device
+    timg, tdepth, tcol = (torch.from_numpy(a).to(dev) for a in (img, depth, colors))
+    masks = torch.zeros((K, H, W), dtype=torch.uint8, device=dev)
+    rgb8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+    mm = torch.zeros((H, W), dtype=torch.int16, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(L.pgr_color_masks(P(timg), W, H, P(tcol), K, 0.1, P(masks), st))
+    _lib.check(L.pgr_quantize_frame(P(timg), P(tdepth), W, H, P(rgb8), P(mm), st))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(masks.cpu().numpy(), oracle.color_masks(img, colors, 0.1))
+    o_rgb, o_mm = oracle.quantize(img, depth)
+    np.testing.assert_array_equal(rgb8.cpu().numpy(), o_rgb)
+    np.testing.assert_array_equal(mm.cpu().numpy().view(np.uint16), o_mm)
+    # and against numpy's own casts, which is what the reference executes (pegasus.py:347,355)
+    np.testing.assert_array_equal(o_rgb, (img.transpose(1, 2, 0) * 255).astype(np.uint8))
+    np.testing.assert_array_equal(o_mm, (depth * 1000).astype(np.uint16))
