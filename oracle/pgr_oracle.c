@@ -305,6 +305,12 @@ static void composite_tile(const PgrOracleIn *in, PgrOracleOut *out, const float
             float T = 1.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f, D = 0.0f;
             uint32_t last = 0;
             uint8_t amb = 0;
+            /* Ambiguity tracking.  exp() is the one operation that is not bit-identical between this
+             * oracle (glibc expf) and the GPU (v_exp_f32 of power*log2e): the relative difference of alpha is
+             * bounded by ALPHA_RELERR.  T inherits a relative error that grows by alpha*err/(1-alpha) per
+             * blend; a pixel is flagged when a threshold comparison lies inside those bounds. */
+            const float ALPHA_RELERR = 1.0e-6f;
+            float T_relerr = 0.0f;
             for (uint32_t j = 0; j < cnt; ++j) {
                 const Splat *s = &scratch[j];
                 const float dx = s->x - pxf, dy = s->y - pyf;
@@ -315,10 +321,11 @@ static void composite_tile(const PgrOracleIn *in, PgrOracleOut *out, const float
                 const float e = expf(power);
                 const float araw = s->op * e;
                 const float alpha = fminf(PGR_ALPHA_MAX, araw);
-                if (fabsf(araw - PGR_ALPHA_MIN) <= 4e-6f * PGR_ALPHA_MIN) amb = 1;
+                if (fabsf(araw - PGR_ALPHA_MIN) <= ALPHA_RELERR * PGR_ALPHA_MIN) amb = 1;
                 if (alpha < PGR_ALPHA_MIN) continue;
                 const float test_T = fmaf(-alpha, T, T);
-                if (fabsf(test_T - PGR_T_EPS) <= 2e-4f * PGR_T_EPS) amb = 1;
+                const float step_err = araw < PGR_ALPHA_MAX ? alpha * ALPHA_RELERR / (1.0f - alpha) : 0.0f;
+                if (fabsf(test_T - PGR_T_EPS) <= (T_relerr + step_err + 2.0e-7f) * PGR_T_EPS) amb = 1;
                 if (test_T < PGR_T_EPS) break; /* this entry is NOT blended */
                 const float w = alpha * T;
                 Cr = fmaf(s->r, w, Cr);
@@ -326,6 +333,7 @@ static void composite_tile(const PgrOracleIn *in, PgrOracleOut *out, const float
                 Cb = fmaf(s->b, w, Cb);
                 D = fmaf(s->depth, w, D);
                 T = test_T;
+                T_relerr += step_err + 1.0e-7f;
                 last = j + 1;
             }
             const size_t pix = (size_t)py * W + px, P = (size_t)W * H;
