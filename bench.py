@@ -34,14 +34,15 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c5"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink Gaussian counts (debug only; INVALID as a result)")
     ap.add_argument("--views", type=int, default=64, help="distinct cameras cycled through")
+    ap.add_argument("--batch", type=int, default=16, help="views per step (one pgr_forward_batch call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
-    ap.add_argument("--profile-steps", type=int, default=8, help="steps measured per-stage with HIP events")
+    ap.add_argument("--profile-steps", type=int, default=2, help="steps measured per-stage with HIP events")
     return ap.parse_args()
 
 
@@ -94,29 +95,32 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from pegasus_amd import _lib
-    from pegasus_amd import diff_gaussian_rasterization as dgr
-    L = _lib.lib()
+    from pegasus_amd import _lib, rasterizer
+    _lib.lib()
 
     # every rank builds the same scene (replicated: 472 MB at 2 M Gaussians) and takes views rank::world
-    n_views_total = max(args.views * world, world)
+    B = max(1, args.batch)
+    n_views_total = max(args.views, B) * world
     cloud, views, label = build_workload(args.workload, args.scale, n_views_total)
     my_views = views[rank::world] or views
     act = cloud.activated()
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     means, opac, scales, rots, shs = (t(act[k]) for k in ("means3d", "opacities", "scales", "rotations", "shs"))
     bg = torch.zeros(3, device=dev)
-    settings = []
-    for v in my_views:
-        settings.append(dgr.GaussianRasterizationSettings(
-            v.height, v.width, v.tanfovx, v.tanfovy, bg, 1.0, t(v.world_view_transform), t(v.full_proj_transform),
-            3, t(v.camera_center), False, False))
+    specs = [rasterizer.ViewSpec(v.height, v.width, v.tanfovx, v.tanfovy, bg, t(v.world_view_transform),
+                                 t(v.full_proj_transform), t(v.camera_center)) for v in my_views]
     W, H = my_views[0].width, my_views[0].height
     P = W * H
+    # frame buffers of one batch, allocated once (the product writes frames in place)
+    frames = [dict(color=torch.empty((3, H, W), device=dev), depth=torch.empty((1, H, W), device=dev), radii=None)
+              for _ in range(B)]
 
-    def step(i, want_aux=False):
-        s = settings[i % len(settings)]
-        return dgr.rasterize_gaussians(means, None, shs, None, opac, scales, rots, None, s, want_aux=want_aux)
+    def batch_views(i):
+        return [specs[(i * B + k) % len(specs)] for k in range(B)]
+
+    def step(i, **kw):
+        return rasterizer.forward_views(means, opac, batch_views(i), shs=shs, scales=scales, rotations=rots,
+                                        sh_degree=3, want_radii=False, outputs=frames, **kw)
 
     for i in range(args.warmup):
         step(i)
@@ -126,7 +130,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = step(i)
+        step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -137,35 +141,27 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
-    # ---- per-view statistics and per-stage HIP-event timing (outside the timed region) ----
+    # ---- per-view statistics and per-stage HIP-event timing of whole batches (outside the timed region) ----
     stage_ms = np.zeros((0, _lib.PGR_NUM_STAGES))
     stats = []
     if rank == 0:
         rows = []
-        for i in range(max(1, min(args.profile_steps, len(settings)))):
-            s = settings[i]
-            color = torch.empty((3, H, W), device=dev)
-            depth = torch.empty((1, H, W), device=dev)
-            radii = torch.empty((cloud.n,), dtype=torch.int32, device=dev)
-            ncontrib = torch.empty((H, W), dtype=torch.int32, device=dev)
-            scene = _lib.PgrScene(n=cloud.n, means3d=means.data_ptr(), opacities=opac.data_ptr(),
-                                  scales=scales.data_ptr(), rotations=rots.data_ptr(), cov3d_precomp=None,
-                                  shs=shs.data_ptr(), colors_precomp=None, sh_degree=3, sh_stride=16,
-                                  scale_modifier=1.0)
-            cam = _lib.PgrCamera(W, H, float(s.tanfovx), float(s.tanfovy), s.viewmatrix.data_ptr(),
-                                 s.projmatrix.data_ptr(), s.campos.data_ptr(), s.bg.data_ptr())
-            outs = _lib.PgrOutputs(color.data_ptr(), depth.data_ptr(), radii.data_ptr(), None, ncontrib.data_ptr())
-            info = dgr.last_forward_info()
-            ws = info["workspace"]
-            ms = (C.c_float * _lib.PGR_NUM_STAGES)()
-            need = C.c_int64(0)
-            _lib.check(L.pgr_forward_profiled(C.byref(scene), C.byref(cam), C.byref(outs), C.c_void_p(ws.data_ptr()),
-                                              ws.numel(), info["used_max_instances"], C.byref(need),
-                                              C.c_void_p(torch.cuda.current_stream().cuda_stream), ms),
-                       "pgr_forward_profiled")
-            rows.append(list(ms))
-            V = int((radii > 0).sum().item())
-            stats.append(dict(N=cloud.n, V=V, I=int(need.value), evals=int(ncontrib.sum(dtype=torch.int64).item())))
+        for i in range(max(1, args.profile_steps)):
+            ms = []
+            res = rasterizer.forward_views(means, opac, batch_views(i), shs=shs, scales=scales, rotations=rots,
+                                           sh_degree=3, want_radii=True, want_aux=True, stage_ms=ms)
+            rows.append(ms)
+            info = rasterizer.last_forward_info()
+            for k, r in enumerate(res):
+                stats.append(dict(V=int((r["radii"] > 0).sum().item()), I=info["num_instances"][k],
+                                  evals=int(r["n_contrib"].sum(dtype=torch.int64).item())))
+            del res
+        # aux outputs change the compositor's epilogue only; re-time the plain variant for the stage table
+        rows = []
+        for i in range(max(1, args.profile_steps)):
+            ms = []
+            step(i, stage_ms=ms)
+            rows.append(ms)
         stage_ms = np.asarray(rows)
 
     if rank != 0:
@@ -173,26 +169,29 @@ def main():
             dist.destroy_process_group()
         return
 
-    total_views = args.steps * world
+    total_views = args.steps * B * world
     value = total_views / elapsed
     N = cloud.n
     V = float(np.mean([s["V"] for s in stats]))
     I = float(np.mean([s["I"] for s in stats]))
     evals = float(np.mean([s["evals"] for s in stats]))
     B_view, per_stage_bytes = algorithmic_bytes(N, V, I, P)
-    mean_ms = stage_ms.mean(axis=0)
+    mean_ms = stage_ms.mean(axis=0)          # per batch of B views
     dom = int(np.argmax(mean_ms))
     dom_name = _lib.STAGE_NAMES[dom]
-    dom_bytes = per_stage_bytes[dom_name]
-    achieved = dom_bytes / (mean_ms[dom] * 1e-3) / 1e9 if mean_ms[dom] > 0 else 0.0
+    launches = 1 if dom_name == "composite" else B      # the compositor covers the whole batch in one launch
+    dom_bytes = per_stage_bytes[dom_name] * B / launches
+    dom_ms = float(mean_ms[dom]) / launches
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     roofline = {
         "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-        "kernel_ms": round(float(mean_ms[dom]), 4), "algorithmic_bytes_per_launch": int(dom_bytes),
-        "stage_ms": {k: round(float(m), 4) for k, m in zip(_lib.STAGE_NAMES, mean_ms)},
-        "whole_path": {"bytes_per_view": int(B_view), "achieved": round(B_view * value / 1e9, 2),
-                       "frac": round(B_view * value / 1e9 / HBM_PEAK_GBS, 5)},
-        "composite_evals_per_s": round(evals / (mean_ms[5] * 1e-3), 1) if mean_ms[5] > 0 else None,
+        "kernel_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes),
+        "launches_per_step": launches,
+        "stage_ms_per_view": {k: round(float(m) / B, 4) for k, m in zip(_lib.STAGE_NAMES, mean_ms)},
+        "whole_path": {"bytes_per_view": int(B_view), "achieved": round(B_view * value / world / 1e9, 2),
+                       "frac": round(B_view * value / world / 1e9 / HBM_PEAK_GBS, 5)},
+        "composite_evals_per_s": round(evals * B / (mean_ms[5] * 1e-3), 1) if mean_ms[5] > 0 else None,
         "N": N, "V": round(V), "I": round(I), "P": P,
     }
 
@@ -217,7 +216,7 @@ def main():
         "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": label, "gaussians": N, "width": W, "height": H, "views_per_step": 1,
+        "config": {"workload": label, "gaussians": N, "width": W, "height": H, "views_per_step": B,
                    "distinct_views": len(my_views), "outputs": "color[3,H,W] f32 + depth[1,H,W] f32 + radii",
                    "parallelism": f"view-shard x{world}"},
         "roofline": roofline,

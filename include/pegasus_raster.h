@@ -103,6 +103,9 @@ const char *pgr_last_hip_error(void);
 /* Bytes of workspace needed to render one view of `n` Gaussians at width x height with room for
  * `max_instances` (Gaussian,tile) pairs. */
 size_t pgr_workspace_bytes(int32_t n, int32_t width, int32_t height, int64_t max_instances);
+/* Same for a batch of `n_views` views in flight at once (pgr_forward_batch). */
+size_t pgr_batch_workspace_bytes(int32_t n, int32_t width, int32_t height, int64_t max_instances_per_view,
+                                 int32_t n_views);
 
 /* Render one view.  `num_instances` (host, optional) receives sum(tiles_touched).  The call
  * synchronises `stream` once, after the offset scan, exactly where the reference reads
@@ -111,21 +114,33 @@ int32_t pgr_forward(const PgrScene *scene, const PgrCamera *camera, const PgrOut
                     void *workspace, size_t workspace_bytes, int64_t max_instances,
                     int64_t *num_instances, void *stream);
 
-/* Profiling twin of pgr_forward (bench / rocprof only): records HIP events on `stream` at the stage
- * boundaries, synchronises, and writes the elapsed milliseconds of each stage to stage_ms[PGR_NUM_STAGES]
- * in the order of PgrStage. */
+/* Render `n_views` views of ONE scene (the per-frame loop of /root/reference/pegasus.py:254-325 calls
+ * render() once per camera over the same merged cloud; this is that loop as one call).  `cameras` and
+ * `outs` are HOST arrays of n_views entries; all views share the image size; outs[v].radii may be NULL.
+ * The batch is what fills an MI355X: the compositing of every (view, tile) list is one launch, ordered
+ * longest list first, so no view waits on its own slowest tile.  One stream synchronisation per batch
+ * (instance counts), `num_instances` (host, optional) receives n_views counts. */
+int32_t pgr_forward_batch(const PgrScene *scene, int32_t n_views, const PgrCamera *cameras,
+                          const PgrOutputs *outs, void *workspace, size_t workspace_bytes,
+                          int64_t max_instances_per_view, int64_t *num_instances, void *stream);
+
+/* Profiling twin of pgr_forward_batch (bench / rocprof only): records HIP events on `stream` at the
+ * stage boundaries (each stage runs for all views before the next starts), synchronises, and writes the
+ * elapsed milliseconds of each stage for the whole batch to stage_ms[PGR_NUM_STAGES] in PgrStage order. */
 #define PGR_NUM_STAGES 6
 typedef enum PgrStage {
     PGR_STAGE_PREPROCESS = 0, PGR_STAGE_SCAN = 1, PGR_STAGE_EMIT = 2, PGR_STAGE_SORT = 3,
     PGR_STAGE_RANGES = 4, PGR_STAGE_COMPOSITE = 5
 } PgrStage;
-int32_t pgr_forward_profiled(const PgrScene *scene, const PgrCamera *camera, const PgrOutputs *out,
-                             void *workspace, size_t workspace_bytes, int64_t max_instances,
-                             int64_t *num_instances, void *stream, float *stage_ms);
+int32_t pgr_forward_batch_profiled(const PgrScene *scene, int32_t n_views, const PgrCamera *cameras,
+                                   const PgrOutputs *outs, void *workspace, size_t workspace_bytes,
+                                   int64_t max_instances_per_view, int64_t *num_instances, void *stream,
+                                   float *stage_ms);
 
-/* Fill `view` with device pointers into a workspace laid out for (n,width,height,max_instances). */
+/* Fill `view` with device pointers into view `view_index` of a workspace laid out for
+ * (n,width,height,max_instances,n_views). */
 int32_t pgr_workspace_view(void *workspace, size_t workspace_bytes, int32_t n, int32_t width, int32_t height,
-                           int64_t max_instances, PgrWorkspaceView *view);
+                           int64_t max_instances, int32_t n_views, int32_t view_index, PgrWorkspaceView *view);
 
 /* present[i] = 1 iff Gaussian i passes the near-plane test of `viewmatrix` (device [16]). */
 int32_t pgr_mark_visible(int32_t n, const float *means3d, const float *viewmatrix, uint8_t *present,

@@ -54,11 +54,14 @@ SYMBOLS = {
     "pgr_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
     "pgr_forward": (C.c_int32, [C.POINTER(PgrScene), C.POINTER(PgrCamera), C.POINTER(PgrOutputs), C.c_void_p,
                                 C.c_size_t, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
-    "pgr_forward_profiled": (C.c_int32, [C.POINTER(PgrScene), C.POINTER(PgrCamera), C.POINTER(PgrOutputs),
-                                         C.c_void_p, C.c_size_t, C.c_int64, C.POINTER(C.c_int64), C.c_void_p,
-                                         C.POINTER(C.c_float)]),
+    "pgr_batch_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32]),
+    "pgr_forward_batch": (C.c_int32, [C.POINTER(PgrScene), C.c_int32, C.POINTER(PgrCamera), C.POINTER(PgrOutputs),
+                                      C.c_void_p, C.c_size_t, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
+    "pgr_forward_batch_profiled": (C.c_int32, [C.POINTER(PgrScene), C.c_int32, C.POINTER(PgrCamera),
+                                               C.POINTER(PgrOutputs), C.c_void_p, C.c_size_t, C.c_int64,
+                                               C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_float)]),
     "pgr_workspace_view": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
-                                       C.POINTER(PgrWorkspaceView)]),
+                                       C.c_int32, C.c_int32, C.POINTER(PgrWorkspaceView)]),
     "pgr_mark_visible": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgr_color_masks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
                                     C.c_void_p, C.c_void_p]),

@@ -19,6 +19,19 @@ struct CompOut {
     uint32_t* n_contrib; // optional
 };
 
+// One entry per view of a batch, resident in HBM; read through the scalar cache (wave-uniform).
+struct alignas(16) ViewEntry {
+    const CameraDev* cam;
+    const uint2* ranges;
+    const uint32_t* gauss_sorted;
+    const float2* xy;
+    const float4* conic_opacity;
+    const float4* rgbd;
+    CompOut out;
+    uint64_t pad[2];
+};
+static_assert(sizeof(ViewEntry) == 96, "ViewEntry layout");
+
 __global__ __launch_bounds__(COMP_THREADS) void composite_kernel(const CameraDev* __restrict__ camp,
                                                                  const uint2* __restrict__ ranges,
                                                                  const uint32_t* __restrict__ gauss_sorted,
@@ -95,6 +108,196 @@ __global__ __launch_bounds__(COMP_THREADS) void composite_kernel(const CameraDev
         if (o.final_T) o.final_T[pix] = T;
         if (o.n_contrib) o.n_contrib[pix] = last;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// composite_wave_kernel: ONE WAVE per half tile (16 x 8 pixels), two pixels per lane.
+//
+// gfx950 mapping: the two pixels of a lane (same x, rows r and r+4) are evaluated with packed
+// fp32 math (v_pk_mul/fma/add_f32: two IEEE fp32 results per issue slot), every threshold is a lane
+// mask instead of a branch, and non-blended lanes run the blend with alpha = 0 (exact no-op:
+// fma(c, 0, C) == C, fma(-0, T, T) == T), so the per-pixel operation order and results are those of the
+// oracle.  The workgroup is a single wave: no cross-wave barrier, early-out per half tile.  The list is
+// consumed in batches of 64: lane j gathers entry j's 40 B (xy, conic+opacity, rgb+depth) into registers
+// one batch AHEAD, parks it in LDS, and every lane then broadcast-reads the batch.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int HALF_ROWS = 8;     // rows per half tile
+constexpr int WAVE_BATCH = 64;   // list entries staged per round
+
+template <bool AUX>
+__global__ __launch_bounds__(WAVE) void composite_wave_kernel(const ViewEntry* __restrict__ views,
+                                                              uint32_t items_per_view,
+                                                              const uint32_t* __restrict__ work_order) {
+    uint32_t item = work_order ? work_order[blockIdx.x] : blockIdx.x;
+    const uint32_t view = item / items_per_view;
+    item -= view * items_per_view;
+    const ViewEntry& ve = views[view];
+    const CameraDev& cam = *ve.cam;
+    const uint2* __restrict__ ranges = ve.ranges;
+    const uint32_t* __restrict__ gauss_sorted = ve.gauss_sorted;
+    const float2* __restrict__ xy = ve.xy;
+    const float4* __restrict__ conic_opacity = ve.conic_opacity;
+    const float4* __restrict__ rgbd = ve.rgbd;
+    const CompOut o = ve.out;
+    const int W = cam.width, H = cam.height;
+    const int tile = (int)(item >> 1), half = (int)(item & 1);
+    const int tile_x = tile % cam.grid_x, tile_y = tile / cam.grid_x;
+    const int lane = threadIdx.x;
+    const int px = tile_x * TILE + (lane & (TILE - 1));
+    const int py0 = tile_y * TILE + half * HALF_ROWS + (lane >> 4);
+    const int py1 = py0 + 4;
+    const bool in0 = px < W && py0 < H, in1 = px < W && py1 < H;
+    const float pxf = (float)px;
+    const f32x2 pyf = {(float)py0, (float)py1};
+
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+
+    __shared__ float4 s_a[2][WAVE_BATCH];  // x, y, hx, ny
+    __shared__ float4 s_b[2][WAVE_BATCH];  // hz, opacity, r, g
+    __shared__ float2 s_c[2][WAVE_BATCH];  // b, depth
+
+    f32x2 T = {1.0f, 1.0f}, Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f}, D = {0.f, 0.f};
+    uint32_t last0 = 0, last1 = 0;
+    bool done0 = !in0, done1 = !in1;
+
+    // register-staged prefetch of the first batch
+    float2 p = make_float2(0.f, 0.f);
+    float4 co = make_float4(0.f, 0.f, 0.f, 0.f), cd = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < n) {
+        const uint32_t g = gauss_sorted[range.x + lane];
+        p = xy[g];
+        co = conic_opacity[g];
+        cd = rgbd[g];
+    }
+
+    int buf = 0;
+    for (int base = 0; base < n; base += WAVE_BATCH, buf ^= 1) {
+        // park the prefetched batch (entries past the end are null splats: opacity 0 -> never valid)
+        s_a[buf][lane] = make_float4(p.x, p.y, -0.5f * co.x, -co.y);
+        s_b[buf][lane] = make_float4(-0.5f * co.z, co.w, cd.x, cd.y);
+        s_c[buf][lane] = make_float2(cd.z, cd.w);
+        __syncthreads();
+        // issue the gather of the NEXT batch now; it lands while this batch is composited
+        p = make_float2(0.f, 0.f);
+        co = make_float4(0.f, 0.f, 0.f, 0.f);
+        cd = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (base + WAVE_BATCH + lane < n) {
+            const uint32_t g = gauss_sorted[range.x + base + WAVE_BATCH + lane];
+            p = xy[g];
+            co = conic_opacity[g];
+            cd = rgbd[g];
+        }
+        const int cnt = min(WAVE_BATCH, n - base);
+        for (int j0 = 0; j0 < cnt; j0 += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                const float4 a = s_a[buf][j];
+                const float4 b = s_b[buf][j];
+                const float2 c = s_c[buf][j];
+                const float dx = a.x - pxf;
+                const f32x2 dxv = {dx, dx};
+                const f32x2 dy = (f32x2){a.y, a.y} - pyf;
+                const f32x2 t1 = (f32x2){a.w, a.w} * dy;
+                const f32x2 t2 = __builtin_elementwise_fma((f32x2){a.z, a.z}, dxv, t1);
+                const f32x2 t4 = ((f32x2){b.x, b.x} * dy) * dy;
+                const f32x2 power = __builtin_elementwise_fma(dxv, t2, t4);
+                const f32x2 p2 = power * (f32x2){1.4426950408889634f, 1.4426950408889634f};
+                const f32x2 e = {__builtin_amdgcn_exp2f(p2.x), __builtin_amdgcn_exp2f(p2.y)};
+                const f32x2 araw = (f32x2){b.y, b.y} * e;
+                const f32x2 alpha = {fminf(ALPHA_MAX, araw.x), fminf(ALPHA_MAX, araw.y)};
+                const f32x2 test_T = __builtin_elementwise_fma(-alpha, T, T);
+                const bool v0 = !done0 && !(power.x > 0.0f) && !(alpha.x < ALPHA_MIN);
+                const bool v1 = !done1 && !(power.y > 0.0f) && !(alpha.y < ALPHA_MIN);
+                const bool stop0 = v0 && test_T.x < T_EPS, stop1 = v1 && test_T.y < T_EPS;
+                done0 = done0 || stop0;
+                done1 = done1 || stop1;
+                const bool b0 = v0 && !stop0, b1 = v1 && !stop1;
+                const f32x2 aeff = {b0 ? alpha.x : 0.0f, b1 ? alpha.y : 0.0f};
+                const f32x2 w = aeff * T;
+                Cr = __builtin_elementwise_fma((f32x2){b.z, b.z}, w, Cr);
+                Cg = __builtin_elementwise_fma((f32x2){b.w, b.w}, w, Cg);
+                Cb = __builtin_elementwise_fma((f32x2){c.x, c.x}, w, Cb);
+                D = __builtin_elementwise_fma((f32x2){c.y, c.y}, w, D);
+                T = __builtin_elementwise_fma(-aeff, T, T);
+                if (AUX) {
+                    const uint32_t idx = (uint32_t)(base + j + 1);
+                    last0 = b0 ? idx : last0;
+                    last1 = b1 ? idx : last1;
+                }
+            }
+            if (__all(done0 && done1)) goto finished;
+        }
+    }
+finished:
+    const size_t P = (size_t)W * H;
+    if (in0) {
+        const size_t pix = (size_t)py0 * W + px;
+        o.color[0 * P + pix] = fmaf(T.x, cam.bg[0], Cr.x);
+        o.color[1 * P + pix] = fmaf(T.x, cam.bg[1], Cg.x);
+        o.color[2 * P + pix] = fmaf(T.x, cam.bg[2], Cb.x);
+        o.depth[pix] = D.x;
+        if (AUX) {
+            if (o.final_T) o.final_T[pix] = T.x;
+            if (o.n_contrib) o.n_contrib[pix] = last0;
+        }
+    }
+    if (in1) {
+        const size_t pix = (size_t)py1 * W + px;
+        o.color[0 * P + pix] = fmaf(T.y, cam.bg[0], Cr.y);
+        o.color[1 * P + pix] = fmaf(T.y, cam.bg[1], Cg.y);
+        o.color[2 * P + pix] = fmaf(T.y, cam.bg[2], Cb.y);
+        o.depth[pix] = D.y;
+        if (AUX) {
+            if (o.final_T) o.final_T[pix] = T.y;
+            if (o.n_contrib) o.n_contrib[pix] = last1;
+        }
+    }
+}
+
+// Work ordering for the wave compositor: half-tile work items sorted by DESCENDING list length
+// (256 log-spaced length classes), so the long lists start first and the short ones back-fill the
+// SIMDs that finish early (longest-processing-time-first).  Order never affects results.
+constexpr int ORDER_CLASSES = 256;
+
+__device__ __forceinline__ int length_class(uint32_t len) {
+    if (len == 0) return 0;
+    const int msb = 31 - __clz((int)len);
+    const uint32_t frac = msb >= 3 ? (len >> (msb - 3)) & 7u : (len << (3 - msb)) & 7u;
+    return msb * 8 + (int)frac + 1;   // 1..256 -> clamp below
+}
+
+// counters: [ORDER_CLASSES] zero-filled by the caller; grid = (ceil(tiles/256), n_views)
+__global__ void order_count_kernel(const ViewEntry* __restrict__ views, int tiles, uint32_t* __restrict__ class_count) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles) return;
+    const uint2 r = views[blockIdx.y].ranges[t];
+    const int c = min(length_class(r.y - r.x), ORDER_CLASSES - 1);
+    atomicAdd(&class_count[ORDER_CLASSES - 1 - c], 2u);   // descending; two half tiles per tile
+}
+
+__global__ void order_scan_kernel(uint32_t* __restrict__ class_count) {   // 1 block of ORDER_CLASSES threads
+    __shared__ uint32_t s[ORDER_CLASSES];
+    const int t = threadIdx.x;
+    s[t] = class_count[t];
+    __syncthreads();
+    uint32_t acc = 0;
+    for (int i = 0; i < t; ++i) acc += s[i];
+    class_count[t] = acc;   // exclusive prefix = running cursor of each class
+}
+
+__global__ void order_scatter_kernel(const ViewEntry* __restrict__ views, int tiles,
+                                     uint32_t* __restrict__ class_cursor, uint32_t* __restrict__ work_order) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles) return;
+    const uint2 r = views[blockIdx.y].ranges[t];
+    const int c = min(length_class(r.y - r.x), ORDER_CLASSES - 1);
+    const uint32_t pos = atomicAdd(&class_cursor[ORDER_CLASSES - 1 - c], 2u);
+    const uint32_t item = (uint32_t)blockIdx.y * 2u * (uint32_t)tiles + 2u * (uint32_t)t;
+    work_order[pos] = item;
+    work_order[pos + 1] = item + 1u;
 }
 
 // ---- frame post-processing ---------------------------------------

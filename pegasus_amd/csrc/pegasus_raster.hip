@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 #include <rocprim/rocprim.hpp>
 
 #include "binning.hip.h"
@@ -41,12 +43,15 @@ static Layout make_layout(int32_t n, int32_t width, int32_t height, int64_t max_
     L.rgb = take(N * 16);
     L.tiles_touched = take(N * 4);
     L.offsets = take(N * 4);
+    L.radii = take(N * 4);
     L.block_sums = take((size_t)L.n_blocks * 4);
     L.keys_unsorted = take(I * 8);
     L.vals_unsorted = take(I * 4);
     L.keys_sorted = take(I * 8);
     L.vals_sorted = take(I * 4);
     L.ranges = take((size_t)L.tiles * 8);
+    L.work_order = take((size_t)L.tiles * 2 * 4);
+    L.order_classes = take(ORDER_CLASSES * 4);
     L.sort_temp_bytes = SORT_TEMP_FIXED + I * 12;
     L.sort_temp = take(L.sort_temp_bytes);
     L.total = off;
@@ -88,149 +93,235 @@ const char* pgr_status_string(int32_t status) {
 
 const char* pgr_last_hip_error(void) { return g_hip_error; }
 
-size_t pgr_workspace_bytes(int32_t n, int32_t width, int32_t height, int64_t max_instances) {
-    if (n < 0 || width <= 0 || height <= 0 || max_instances < 0 || max_instances > 0x7fffffffLL) return 0;
-    return make_layout(n, width, height, max_instances).total;
+}  // extern "C"
+
+// Per-view slice of a workspace.
+struct ViewWs {
+    CameraDev* cam;
+    uint32_t* counters;
+    float2* xy;
+    float* depth;
+    float4* conop;
+    float4* rgbd;
+    uint32_t *tiles_touched, *offsets, *block_sums;
+    int32_t* radii;   // per-view home of radii when the caller passes no radii output
+    uint64_t *keys_u, *keys_s;
+    uint32_t *vals_u, *vals_s;
+    uint2* ranges;
+    char* sort_temp;
+};
+
+static ViewWs carve(char* ws, const Layout& L) {
+    ViewWs v;
+    v.cam = reinterpret_cast<CameraDev*>(ws + L.cam);
+    v.counters = reinterpret_cast<uint32_t*>(ws + L.counters);
+    v.xy = reinterpret_cast<float2*>(ws + L.xy);
+    v.depth = reinterpret_cast<float*>(ws + L.depth);
+    v.conop = reinterpret_cast<float4*>(ws + L.conic_opacity);
+    v.rgbd = reinterpret_cast<float4*>(ws + L.rgb);
+    v.tiles_touched = reinterpret_cast<uint32_t*>(ws + L.tiles_touched);
+    v.offsets = reinterpret_cast<uint32_t*>(ws + L.offsets);
+    v.radii = reinterpret_cast<int32_t*>(ws + L.radii);
+    v.block_sums = reinterpret_cast<uint32_t*>(ws + L.block_sums);
+    v.keys_u = reinterpret_cast<uint64_t*>(ws + L.keys_unsorted);
+    v.vals_u = reinterpret_cast<uint32_t*>(ws + L.vals_unsorted);
+    v.keys_s = reinterpret_cast<uint64_t*>(ws + L.keys_sorted);
+    v.vals_s = reinterpret_cast<uint32_t*>(ws + L.vals_sorted);
+    v.ranges = reinterpret_cast<uint2*>(ws + L.ranges);
+    v.sort_temp = ws + L.sort_temp;
+    return v;
 }
 
-int32_t pgr_workspace_view(void* workspace, size_t workspace_bytes, int32_t n, int32_t width, int32_t height,
-                           int64_t max_instances, PgrWorkspaceView* v) {
-    if (!workspace || !v || n < 0 || width <= 0 || height <= 0 || max_instances < 0) return PGR_ERR_INVALID_ARGUMENT;
-    const Layout L = make_layout(n, width, height, max_instances);
-    if (workspace_bytes < L.total) return PGR_ERR_WORKSPACE_TOO_SMALL;
-    char* w = static_cast<char*>(workspace);
-    v->xy = reinterpret_cast<const float*>(w + L.xy);
-    v->depth = reinterpret_cast<const float*>(w + L.depth);
-    v->conic_opacity = reinterpret_cast<const float*>(w + L.conic_opacity);
-    v->rgb = reinterpret_cast<const float*>(w + L.rgb);
-    v->tiles_touched = reinterpret_cast<const uint32_t*>(w + L.tiles_touched);
-    v->offsets = reinterpret_cast<const uint32_t*>(w + L.offsets);
-    v->keys_sorted = reinterpret_cast<const uint64_t*>(w + L.keys_sorted);
-    v->gauss_sorted = reinterpret_cast<const uint32_t*>(w + L.vals_sorted);
-    v->ranges = reinterpret_cast<const uint32_t*>(w + L.ranges);
-    v->num_instances = reinterpret_cast<const uint32_t*>(w + L.counters);
+// Batch header placed in front of the per-view slices.
+struct BatchLayout {
+    size_t view_table, order_classes, work_order, views, total;
+    size_t per_view;
+};
+
+static BatchLayout make_batch_layout(const Layout& L, int n_views, int32_t n) {
+    BatchLayout B{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes ? bytes : 1); return o; };
+    B.view_table = take((size_t)n_views * sizeof(ViewEntry));
+    B.order_classes = take(ORDER_CLASSES * 4);
+    B.work_order = take((size_t)n_views * L.tiles * 2 * 4);
+    B.views = off;
+    B.per_view = align_up(L.total);
+    B.total = off + (size_t)n_views * B.per_view;
+    return B;
+}
+
+static int check_camera(const PgrCamera* cam, const PgrOutputs* out) {
+    if (!cam || !out || cam->image_width <= 0 || cam->image_height <= 0 || !(cam->tanfovx > 0.f) ||
+        !(cam->tanfovy > 0.f) || !cam->viewmatrix || !cam->projmatrix || !cam->campos || !cam->bg || !out->color ||
+        !out->depth)
+        return PGR_ERR_INVALID_ARGUMENT;
     return PGR_OK;
 }
 
-}  // extern "C"
+static int zero_outputs(const PgrOutputs* out, size_t P, hipStream_t stream) {
+    if (!hip_ok(hipMemsetAsync(out->color, 0, 3 * P * sizeof(float), stream), "memset color") ||
+        !hip_ok(hipMemsetAsync(out->depth, 0, P * sizeof(float), stream), "memset depth"))
+        return PGR_ERR_LAUNCH_FAILURE;
+    if (out->final_T && !hip_ok(hipMemsetAsync(out->final_T, 0, P * sizeof(float), stream), "memset T"))
+        return PGR_ERR_LAUNCH_FAILURE;
+    if (out->n_contrib && !hip_ok(hipMemsetAsync(out->n_contrib, 0, P * sizeof(uint32_t), stream), "memset n"))
+        return PGR_ERR_LAUNCH_FAILURE;
+    return PGR_OK;
+}
 
-// ev: optional PGR_NUM_STAGES+1 events recorded at the stage boundaries (profiling entry point only)
-static int32_t forward_impl(const PgrScene* scene, const PgrCamera* cam, const PgrOutputs* out, void* workspace,
-                            size_t workspace_bytes, int64_t max_instances, int64_t* num_instances,
-                            hipStream_t stream, hipEvent_t* ev) {
+// The whole hot path for a batch of views of ONE scene.  All views share the image size.
+// ev: optional PGR_NUM_STAGES+1 events recorded at the stage boundaries (profiling entry point only);
+// each stage is run for every view of the batch before the next stage starts.
+static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrCamera* cams, const PgrOutputs* outs,
+                                  void* workspace, size_t workspace_bytes, int64_t max_instances,
+                                  int64_t* num_instances, hipStream_t stream, hipEvent_t* ev) {
     auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], stream); };
-    if (num_instances) *num_instances = 0;
+    if (n_views <= 0 || !cams || !outs) return PGR_ERR_INVALID_ARGUMENT;
+    if (num_instances) for (int v = 0; v < n_views; ++v) num_instances[v] = 0;
     if (int rc = check_scene(scene)) return rc;
-    if (!cam || !out || cam->image_width <= 0 || cam->image_height <= 0 || !(cam->tanfovx > 0.f) ||
-        !(cam->tanfovy > 0.f) || !cam->viewmatrix || !cam->projmatrix || !cam->campos || !cam->bg || !out->color ||
-        !out->depth || (scene->n > 0 && !out->radii) || max_instances < 0 || max_instances > 0x7fffffffLL)
-        return PGR_ERR_INVALID_ARGUMENT;
-    const int W = cam->image_width, H = cam->image_height, N = scene->n;
+    if (max_instances < 0 || max_instances > 0x7fffffffLL) return PGR_ERR_INVALID_ARGUMENT;
+    const int W = cams[0].image_width, H = cams[0].image_height, N = scene->n;
+    for (int v = 0; v < n_views; ++v) {
+        if (int rc = check_camera(&cams[v], &outs[v])) return rc;
+        if (cams[v].image_width != W || cams[v].image_height != H) return PGR_ERR_INVALID_ARGUMENT;
+    }
     const size_t P = (size_t)W * H;
 
     // N == 0: outputs stay zero-filled, no background (SURVEY.md section 8a "Edge cases")
     if (N == 0) {
-        if (!hip_ok(hipMemsetAsync(out->color, 0, 3 * P * sizeof(float), stream), "memset color") ||
-            !hip_ok(hipMemsetAsync(out->depth, 0, P * sizeof(float), stream), "memset depth"))
-            return PGR_ERR_LAUNCH_FAILURE;
-        if (out->final_T && !hip_ok(hipMemsetAsync(out->final_T, 0, P * sizeof(float), stream), "memset T"))
-            return PGR_ERR_LAUNCH_FAILURE;
-        if (out->n_contrib && !hip_ok(hipMemsetAsync(out->n_contrib, 0, P * sizeof(uint32_t), stream), "memset n"))
-            return PGR_ERR_LAUNCH_FAILURE;
+        for (int v = 0; v < n_views; ++v)
+            if (int rc = zero_outputs(&outs[v], P, stream)) return rc;
         return PGR_OK;
     }
 
     if (!workspace) return PGR_ERR_INVALID_ARGUMENT;
     const Layout L = make_layout(N, W, H, max_instances);
-    if (workspace_bytes < L.total) return PGR_ERR_WORKSPACE_TOO_SMALL;
+    const BatchLayout B = make_batch_layout(L, n_views, N);
+    if (workspace_bytes < B.total) return PGR_ERR_WORKSPACE_TOO_SMALL;
     char* ws = static_cast<char*>(workspace);
-    auto* camd = reinterpret_cast<CameraDev*>(ws + L.cam);
-    auto* counters = reinterpret_cast<uint32_t*>(ws + L.counters);
-    auto* xy = reinterpret_cast<float2*>(ws + L.xy);
-    auto* depth = reinterpret_cast<float*>(ws + L.depth);
-    auto* conop = reinterpret_cast<float4*>(ws + L.conic_opacity);
-    auto* rgbd = reinterpret_cast<float4*>(ws + L.rgb);
-    auto* tiles_touched = reinterpret_cast<uint32_t*>(ws + L.tiles_touched);
-    auto* offsets = reinterpret_cast<uint32_t*>(ws + L.offsets);
-    auto* block_sums = reinterpret_cast<uint32_t*>(ws + L.block_sums);
-    auto* keys_u = reinterpret_cast<uint64_t*>(ws + L.keys_unsorted);
-    auto* vals_u = reinterpret_cast<uint32_t*>(ws + L.vals_unsorted);
-    auto* keys_s = reinterpret_cast<uint64_t*>(ws + L.keys_sorted);
-    auto* vals_s = reinterpret_cast<uint32_t*>(ws + L.vals_sorted);
-    auto* ranges = reinterpret_cast<uint2*>(ws + L.ranges);
+    auto* view_table = reinterpret_cast<ViewEntry*>(ws + B.view_table);
+    auto* classes = reinterpret_cast<uint32_t*>(ws + B.order_classes);
+    auto* work_order = reinterpret_cast<uint32_t*>(ws + B.work_order);
+    std::vector<ViewWs> vw((size_t)n_views);
+    std::vector<ViewEntry> table((size_t)n_views);
+    bool want_aux = false;
+    for (int v = 0; v < n_views; ++v) {
+        vw[v] = carve(ws + B.views + (size_t)v * B.per_view, L);
+        ViewEntry& e = table[v];
+        memset(&e, 0, sizeof(e));
+        e.cam = vw[v].cam; e.ranges = vw[v].ranges; e.gauss_sorted = vw[v].vals_s; e.xy = vw[v].xy;
+        e.conic_opacity = vw[v].conop; e.rgbd = vw[v].rgbd;
+        e.out = CompOut{outs[v].color, outs[v].depth, outs[v].final_T, outs[v].n_contrib};
+        want_aux = want_aux || outs[v].final_T || outs[v].n_contrib;
+    }
+    if (!hip_ok(hipMemcpyAsync(view_table, table.data(), table.size() * sizeof(ViewEntry), hipMemcpyHostToDevice,
+                               stream), "memcpy view table"))
+        return PGR_ERR_LAUNCH_FAILURE;
 
-    pack_camera_kernel<<<1, 64, 0, stream>>>(cam->viewmatrix, cam->projmatrix, cam->campos, cam->bg, cam->tanfovx,
-                                             cam->tanfovy, W, H, camd);
+    // ---- stage 0: camera pack + per-Gaussian preprocess
     mark(0);
-
-    PreOut po{xy, depth, conop, rgbd, tiles_touched, out->radii, block_sums};
-    preprocess_kernel<<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, camd, po);
+    for (int v = 0; v < n_views; ++v) {
+        const PgrCamera& c = cams[v];
+        pack_camera_kernel<<<1, 64, 0, stream>>>(c.viewmatrix, c.projmatrix, c.campos, c.bg, c.tanfovx, c.tanfovy, W, H,
+                                                 vw[v].cam);
+        // radii is part of the per-view contract; when the caller does not want it, it lands in scratch
+        PreOut po{vw[v].xy, vw[v].depth, vw[v].conop, vw[v].rgbd, vw[v].tiles_touched,
+                  outs[v].radii ? outs[v].radii : vw[v].radii, vw[v].block_sums};
+        preprocess_kernel<<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, vw[v].cam, po);
+    }
     mark(1);
-    scan_block_sums_kernel<<<1, SCAN_THREADS, 0, stream>>>(block_sums, L.n_blocks, counters, (uint32_t)max_instances);
-
-    // Host reads num_rendered here, as the reference does (sizes the sort, reports overflow).
-    uint32_t h_counters[2] = {0, 0};
-    if (!hip_ok(hipMemcpyAsync(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost, stream), "memcpy") ||
-        !hip_ok(hipStreamSynchronize(stream), "sync after scan"))
-        return PGR_ERR_LAUNCH_FAILURE;
-    const uint32_t total = h_counters[0];
-    if (num_instances) *num_instances = (int64_t)total;
-    if (h_counters[1] || (int64_t)total > max_instances) return PGR_ERR_INSTANCE_OVERFLOW;
-
-    if (!hip_ok(hipMemsetAsync(ranges, 0, (size_t)L.tiles * sizeof(uint2), stream), "memset ranges"))
-        return PGR_ERR_LAUNCH_FAILURE;
-
+    // ---- stage 1: offset scan; the host reads the instance counts ONCE per batch (the reference
+    // reads num_rendered once per view), sizing the sorts and reporting overflow instead of rendering it.
+    for (int v = 0; v < n_views; ++v)
+        scan_block_sums_kernel<<<1, SCAN_THREADS, 0, stream>>>(vw[v].block_sums, L.n_blocks, vw[v].counters,
+                                                               (uint32_t)max_instances);
+    std::vector<uint32_t> h_counters((size_t)n_views * 2, 0u);
+    for (int v = 0; v < n_views; ++v)
+        if (!hip_ok(hipMemcpyAsync(&h_counters[2 * v], vw[v].counters, 8, hipMemcpyDeviceToHost, stream), "memcpy"))
+            return PGR_ERR_LAUNCH_FAILURE;
+    if (!hip_ok(hipStreamSynchronize(stream), "sync after scan")) return PGR_ERR_LAUNCH_FAILURE;
+    bool overflow = false;
+    for (int v = 0; v < n_views; ++v) {
+        if (num_instances) num_instances[v] = (int64_t)h_counters[2 * v];
+        overflow = overflow || h_counters[2 * v + 1] || (int64_t)h_counters[2 * v] > max_instances;
+    }
+    if (overflow) return PGR_ERR_INSTANCE_OVERFLOW;
     mark(2);
-    if (total > 0) {
-        emit_kernel<<<L.n_blocks, PRE_BLOCK, 0, stream>>>(N, camd, xy, depth, out->radii, tiles_touched, block_sums,
-                                                          counters, offsets, keys_u, vals_u);
-        mark(3);
-        int tbits = 0;
-        while ((1 << tbits) < L.tiles) ++tbits;
+    // ---- stage 2: (tile, depth) instance emission
+    for (int v = 0; v < n_views; ++v) {
+        if (!hip_ok(hipMemsetAsync(vw[v].ranges, 0, (size_t)L.tiles * sizeof(uint2), stream), "memset ranges"))
+            return PGR_ERR_LAUNCH_FAILURE;
+        emit_kernel<<<L.n_blocks, PRE_BLOCK, 0, stream>>>(N, vw[v].cam, vw[v].xy, vw[v].depth,
+                                                          outs[v].radii ? outs[v].radii : vw[v].radii,
+                                                          vw[v].tiles_touched, vw[v].block_sums, vw[v].counters,
+                                                          vw[v].offsets, vw[v].keys_u, vw[v].vals_u);
+    }
+    mark(3);
+    // ---- stage 3: stable sort by (tile, depth bits)
+    int tbits = 0;
+    while ((1 << tbits) < L.tiles) ++tbits;
+    for (int v = 0; v < n_views; ++v) {
+        const size_t total = h_counters[2 * v];
+        if (total == 0) continue;
         size_t temp_bytes = 0;
-        if (!hip_ok(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_u, keys_s, vals_u, vals_s, (size_t)total, 0u,
-                                              (unsigned)(32 + tbits), stream),
+        if (!hip_ok(rocprim::radix_sort_pairs(nullptr, temp_bytes, vw[v].keys_u, vw[v].keys_s, vw[v].vals_u,
+                                              vw[v].vals_s, total, 0u, (unsigned)(32 + tbits), stream),
                     "radix_sort size query"))
             return PGR_ERR_LAUNCH_FAILURE;
         if (temp_bytes > L.sort_temp_bytes) return PGR_ERR_WORKSPACE_TOO_SMALL;
-        if (!hip_ok(rocprim::radix_sort_pairs(ws + L.sort_temp, temp_bytes, keys_u, keys_s, vals_u, vals_s,
-                                              (size_t)total, 0u, (unsigned)(32 + tbits), stream),
+        if (!hip_ok(rocprim::radix_sort_pairs(vw[v].sort_temp, temp_bytes, vw[v].keys_u, vw[v].keys_s, vw[v].vals_u,
+                                              vw[v].vals_s, total, 0u, (unsigned)(32 + tbits), stream),
                     "radix_sort_pairs"))
             return PGR_ERR_LAUNCH_FAILURE;
-        mark(4);
-        tile_ranges_kernel<<<(total + 255) / 256, 256, 0, stream>>>(counters, keys_s, ranges);
-        mark(5);
-    } else {
-        emit_kernel<<<L.n_blocks, PRE_BLOCK, 0, stream>>>(N, camd, xy, depth, out->radii, tiles_touched, block_sums,
-                                                          counters, offsets, keys_u, vals_u);
-        mark(3); mark(4); mark(5);
     }
-
-    CompOut co{out->color, out->depth, out->final_T, out->n_contrib};
-    composite_kernel<<<L.tiles, COMP_THREADS, 0, stream>>>(camd, ranges, vals_s, xy, conop, rgbd, co);
+    mark(4);
+    // ---- stage 4: tile ranges
+    for (int v = 0; v < n_views; ++v) {
+        const uint32_t total = h_counters[2 * v];
+        if (total)
+            tile_ranges_kernel<<<(total + 255) / 256, 256, 0, stream>>>(vw[v].counters, vw[v].keys_s, vw[v].ranges);
+    }
+    mark(5);
+    // ---- stage 5: compositing of every (view, tile, half) work item in ONE launch, longest lists first
+    static const int variant = [] { const char* e = getenv("PGR_COMPOSITE"); return e ? atoi(e) : 2; }();
+    if (variant == 0) {
+        for (int v = 0; v < n_views; ++v)
+            composite_kernel<<<L.tiles, COMP_THREADS, 0, stream>>>(vw[v].cam, vw[v].ranges, vw[v].vals_s, vw[v].xy,
+                                                                   vw[v].conop, vw[v].rgbd, table[v].out);
+    } else {
+        const uint32_t* order = nullptr;
+        if (variant == 2) {
+            if (!hip_ok(hipMemsetAsync(classes, 0, ORDER_CLASSES * 4, stream), "memset classes"))
+                return PGR_ERR_LAUNCH_FAILURE;
+            const dim3 og((L.tiles + 255) / 256, n_views);
+            order_count_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, classes);
+            order_scan_kernel<<<1, ORDER_CLASSES, 0, stream>>>(classes);
+            order_scatter_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, classes, work_order);
+            order = work_order;
+        }
+        const uint32_t items_per_view = 2u * (uint32_t)L.tiles;
+        const uint32_t items = items_per_view * (uint32_t)n_views;
+        if (want_aux)
+            composite_wave_kernel<true><<<items, WAVE, 0, stream>>>(view_table, items_per_view, order);
+        else
+            composite_wave_kernel<false><<<items, WAVE, 0, stream>>>(view_table, items_per_view, order);
+    }
     mark(6);
     if (!hip_ok(hipGetLastError(), "kernel launch")) return PGR_ERR_LAUNCH_FAILURE;
     return PGR_OK;
 }
 
-extern "C" {
-
-int32_t pgr_forward(const PgrScene* scene, const PgrCamera* cam, const PgrOutputs* out, void* workspace,
-                    size_t workspace_bytes, int64_t max_instances, int64_t* num_instances, void* stream_v) {
-    return forward_impl(scene, cam, out, workspace, workspace_bytes, max_instances, num_instances,
-                        static_cast<hipStream_t>(stream_v), nullptr);
-}
-
-int32_t pgr_forward_profiled(const PgrScene* scene, const PgrCamera* cam, const PgrOutputs* out, void* workspace,
-                             size_t workspace_bytes, int64_t max_instances, int64_t* num_instances, void* stream_v,
-                             float* stage_ms) {
+static int32_t profiled(const PgrScene* scene, int n_views, const PgrCamera* cams, const PgrOutputs* outs,
+                        void* workspace, size_t workspace_bytes, int64_t max_instances, int64_t* num_instances,
+                        hipStream_t stream, float* stage_ms) {
     if (!stage_ms) return PGR_ERR_INVALID_ARGUMENT;
-    hipStream_t stream = static_cast<hipStream_t>(stream_v);
     hipEvent_t ev[PGR_NUM_STAGES + 1];
     for (auto& e : ev)
         if (!hip_ok(hipEventCreate(&e), "hipEventCreate")) return PGR_ERR_LAUNCH_FAILURE;
     for (int k = 0; k < PGR_NUM_STAGES; ++k) stage_ms[k] = 0.f;
-    int32_t rc = forward_impl(scene, cam, out, workspace, workspace_bytes, max_instances, num_instances, stream, ev);
+    int32_t rc = forward_batch_impl(scene, n_views, cams, outs, workspace, workspace_bytes, max_instances,
+                                    num_instances, stream, ev);
     if (rc == PGR_OK && scene->n > 0) {
         if (!hip_ok(hipStreamSynchronize(stream), "sync")) rc = PGR_ERR_LAUNCH_FAILURE;
         for (int k = 0; rc == PGR_OK && k < PGR_NUM_STAGES; ++k)
@@ -239,6 +330,62 @@ int32_t pgr_forward_profiled(const PgrScene* scene, const PgrCamera* cam, const 
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
     return rc;
+}
+
+extern "C" {
+
+size_t pgr_batch_workspace_bytes(int32_t n, int32_t width, int32_t height, int64_t max_instances, int32_t n_views) {
+    if (n < 0 || width <= 0 || height <= 0 || max_instances < 0 || max_instances > 0x7fffffffLL || n_views <= 0)
+        return 0;
+    return make_batch_layout(make_layout(n, width, height, max_instances), n_views, n).total;
+}
+
+size_t pgr_workspace_bytes(int32_t n, int32_t width, int32_t height, int64_t max_instances) {
+    return pgr_batch_workspace_bytes(n, width, height, max_instances, 1);
+}
+
+int32_t pgr_workspace_view(void* workspace, size_t workspace_bytes, int32_t n, int32_t width, int32_t height,
+                           int64_t max_instances, int32_t n_views, int32_t view_index, PgrWorkspaceView* v) {
+    if (!workspace || !v || n < 0 || width <= 0 || height <= 0 || max_instances < 0 || n_views <= 0 ||
+        view_index < 0 || view_index >= n_views)
+        return PGR_ERR_INVALID_ARGUMENT;
+    const Layout L = make_layout(n, width, height, max_instances);
+    const BatchLayout B = make_batch_layout(L, n_views, n);
+    if (workspace_bytes < B.total) return PGR_ERR_WORKSPACE_TOO_SMALL;
+    const ViewWs w = carve(static_cast<char*>(workspace) + B.views + (size_t)view_index * B.per_view, L);
+    v->xy = reinterpret_cast<const float*>(w.xy);
+    v->depth = w.depth;
+    v->conic_opacity = reinterpret_cast<const float*>(w.conop);
+    v->rgb = reinterpret_cast<const float*>(w.rgbd);
+    v->tiles_touched = w.tiles_touched;
+    v->offsets = w.offsets;
+    v->keys_sorted = w.keys_s;
+    v->gauss_sorted = w.vals_s;
+    v->ranges = reinterpret_cast<const uint32_t*>(w.ranges);
+    v->num_instances = w.counters;
+    return PGR_OK;
+}
+
+int32_t pgr_forward(const PgrScene* scene, const PgrCamera* cam, const PgrOutputs* out, void* workspace,
+                    size_t workspace_bytes, int64_t max_instances, int64_t* num_instances, void* stream_v) {
+    if (scene && scene->n > 0 && out && !out->radii) return PGR_ERR_INVALID_ARGUMENT;
+    return forward_batch_impl(scene, 1, cam, out, workspace, workspace_bytes, max_instances, num_instances,
+                              static_cast<hipStream_t>(stream_v), nullptr);
+}
+
+int32_t pgr_forward_batch(const PgrScene* scene, int32_t n_views, const PgrCamera* cameras, const PgrOutputs* outs,
+                          void* workspace, size_t workspace_bytes, int64_t max_instances_per_view,
+                          int64_t* num_instances, void* stream_v) {
+    return forward_batch_impl(scene, n_views, cameras, outs, workspace, workspace_bytes, max_instances_per_view,
+                              num_instances, static_cast<hipStream_t>(stream_v), nullptr);
+}
+
+int32_t pgr_forward_batch_profiled(const PgrScene* scene, int32_t n_views, const PgrCamera* cameras,
+                                   const PgrOutputs* outs, void* workspace, size_t workspace_bytes,
+                                   int64_t max_instances_per_view, int64_t* num_instances, void* stream_v,
+                                   float* stage_ms) {
+    return profiled(scene, n_views, cameras, outs, workspace, workspace_bytes, max_instances_per_view, num_instances,
+                    static_cast<hipStream_t>(stream_v), stage_ms);
 }
 
 int32_t pgr_mark_visible(int32_t n, const float* means3d, const float* viewmatrix, uint8_t* present, void* stream_v) {

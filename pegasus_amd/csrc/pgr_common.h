@@ -34,8 +34,8 @@ static_assert(sizeof(CameraDev) == 256, "CameraDev must be 256 B");
 
 // Workspace carve-up (all offsets multiples of 256 B).
 struct Layout {
-    size_t cam, counters, xy, depth, conic_opacity, rgb, tiles_touched, offsets, block_sums,
-        keys_unsorted, vals_unsorted, keys_sorted, vals_sorted, ranges, sort_temp, total;
+    size_t cam, counters, xy, depth, conic_opacity, rgb, tiles_touched, offsets, radii, block_sums,
+        keys_unsorted, vals_unsorted, keys_sorted, vals_sorted, ranges, work_order, order_classes, sort_temp, total;
     size_t sort_temp_bytes;
     int32_t tiles;
     int32_t n_blocks;

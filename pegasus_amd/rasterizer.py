@@ -1,0 +1,174 @@
+"""Host side of the rasterizer: turns torch tensors into the C-ABI structs of
+include/pegasus_raster.h, manages the torch-owned workspace, and handles instance-capacity growth.
+
+``forward_views`` renders a batch of views of one scene through ``pgr_forward_batch``; the
+drop-in ``GaussianRasterizer`` (pegasus_amd.diff_gaussian_rasterization) is the n_views == 1 case.
+There is no CPU fallback anywhere in this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+
+@dataclass
+class ViewSpec:
+    """What GaussianRasterizationSettings says about one view (tensors stay on the device)."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    campos: torch.Tensor
+
+
+class _Workspace:
+    """Per-device scratch from torch's caching allocator; grown on demand, reused across calls."""
+
+    def __init__(self):
+        self.buf = {}
+        self.capacity_hint = {}
+
+    def get(self, device, nbytes: int) -> torch.Tensor:
+        t = self.buf.get(device)
+        if t is None or t.numel() < nbytes:
+            self.buf[device] = None
+            del t
+            t = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+            self.buf[device] = t
+        return t
+
+
+_WS = _Workspace()
+_LAST_INFO: dict = {}
+
+
+def last_forward_info() -> dict:
+    """Bookkeeping of the most recent forward: num_instances per view, capacities, workspace tensor."""
+    return dict(_LAST_INFO)
+
+
+def dev_f32(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != device:
+        t = t.to(device)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, colors_precomp=None, scales=None,
+                  rotations=None, cov3D_precomp=None, sh_degree=0, scale_modifier=1.0, want_radii=True,
+                  want_aux=False, stage_ms: Optional[list] = None, outputs: Optional[list] = None):
+    """Renders ``len(views)`` views of one scene.  Returns a list of dicts with keys
+    color[3,H,W], depth[1,H,W], radii[N] (or None), and final_T / n_contrib when ``want_aux``.
+
+    ``stage_ms``: pass an empty list to use the profiling entry point; it receives the per-stage
+    milliseconds (whole batch) measured with HIP events on the launch stream.
+    ``outputs``: optional pre-allocated list of dicts (same keys) to render into.
+    """
+    L = _lib.lib()
+    device = means3D.device
+    if device.type != "cuda":
+        raise RuntimeError("the rasterizer needs tensors on a HIP device (torch device 'cuda'); there is no CPU path")
+    nv = len(views)
+    if nv == 0:
+        return []
+    H, W = int(views[0].image_height), int(views[0].image_width)
+    n = int(means3D.shape[0])
+    means3D = dev_f32(means3D, device)
+    opacities = dev_f32(opacities, device)
+    shs = dev_f32(shs, device)
+    colors_precomp = dev_f32(colors_precomp, device)
+    scales = dev_f32(scales, device)
+    rotations = dev_f32(rotations, device)
+    cov3D_precomp = dev_f32(cov3D_precomp, device)
+
+    scene = _lib.PgrScene(
+        n=n, means3d=_ptr(means3D), opacities=_ptr(opacities), scales=_ptr(scales), rotations=_ptr(rotations),
+        cov3d_precomp=_ptr(cov3D_precomp), shs=_ptr(shs), colors_precomp=_ptr(colors_precomp),
+        sh_degree=int(sh_degree), sh_stride=int(shs.shape[1]) if shs is not None else 0,
+        scale_modifier=float(scale_modifier))
+
+    cams = (_lib.PgrCamera * nv)()
+    outs = (_lib.PgrOutputs * nv)()
+    keep = []
+    results: List[dict] = []
+    for i, v in enumerate(views):
+        if int(v.image_height) != H or int(v.image_width) != W:
+            raise ValueError("all views of a batch must share the image size")
+        bg, vm, pm, cp = (dev_f32(t, device) for t in (v.bg, v.viewmatrix, v.projmatrix, v.campos))
+        keep.append((bg, vm, pm, cp))
+        cams[i] = _lib.PgrCamera(image_width=W, image_height=H, tanfovx=float(v.tanfovx), tanfovy=float(v.tanfovy),
+                                 viewmatrix=_ptr(vm), projmatrix=_ptr(pm), campos=_ptr(cp), bg=_ptr(bg))
+        if outputs is not None:
+            r = outputs[i]
+        else:
+            r = dict(color=torch.empty((3, H, W), dtype=torch.float32, device=device),
+                     depth=torch.empty((1, H, W), dtype=torch.float32, device=device),
+                     radii=torch.empty((n,), dtype=torch.int32, device=device) if want_radii else None)
+            if want_aux:
+                r["final_T"] = torch.empty((H, W), dtype=torch.float32, device=device)
+                r["n_contrib"] = torch.empty((H, W), dtype=torch.int32, device=device)
+        outs[i] = _lib.PgrOutputs(color=_ptr(r["color"]), depth=_ptr(r["depth"]), radii=_ptr(r.get("radii")),
+                                  final_T=_ptr(r.get("final_T")), n_contrib=_ptr(r.get("n_contrib")))
+        results.append(r)
+
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    key = (device, n, W, H)
+    max_inst = _WS.capacity_hint.get(key, max(1 << 20, 6 * n))
+    need = (C.c_int64 * nv)()
+    ms = (C.c_float * _lib.PGR_NUM_STAGES)()
+    with torch.cuda.device(device):
+        for _attempt in range(3):
+            nbytes = L.pgr_batch_workspace_bytes(n, W, H, max_inst, nv)
+            if nbytes == 0:
+                raise ValueError("pgr_batch_workspace_bytes: invalid sizes")
+            ws = _WS.get(device, nbytes)
+            if stage_ms is not None:
+                status = L.pgr_forward_batch_profiled(C.byref(scene), nv, cams, outs, C.c_void_p(ws.data_ptr()),
+                                                      ws.numel(), max_inst, need, stream, ms)
+            else:
+                status = L.pgr_forward_batch(C.byref(scene), nv, cams, outs, C.c_void_p(ws.data_ptr()), ws.numel(),
+                                             max_inst, need, stream)
+            if status != _lib.PGR_ERR_INSTANCE_OVERFLOW:
+                break
+            max_inst = int(max(need) * 1.25) + 1024   # grow to what the largest view needs, then retry
+        _lib.check(status, "pgr_forward_batch")
+    used_max_inst = max_inst
+    peak = max(need) if nv else 0
+    if peak > 0.8 * max_inst:
+        max_inst = int(peak * 1.3) + 1024
+    _WS.capacity_hint[key] = max_inst
+    if stage_ms is not None:
+        stage_ms[:] = list(ms)
+    _LAST_INFO.clear()
+    _LAST_INFO.update(num_instances=[int(x) for x in need], max_instances=int(max_inst),
+                      used_max_instances=int(used_max_inst), n=n, width=W, height=H, n_views=nv,
+                      workspace=ws, workspace_bytes=int(ws.numel()))
+    del keep
+    return results
+
+
+def workspace_view(view_index: int = 0) -> dict:
+    """Device pointers (as ints) of view ``view_index`` inside the last forward's workspace."""
+    L = _lib.lib()
+    info = _LAST_INFO
+    ws = info["workspace"]
+    v = _lib.PgrWorkspaceView()
+    _lib.check(L.pgr_workspace_view(C.c_void_p(ws.data_ptr()), ws.numel(), info["n"], info["width"], info["height"],
+                                    info["used_max_instances"], info["n_views"], view_index, C.byref(v)),
+               "pgr_workspace_view")
+    return {k: getattr(v, k) for k, _ in _lib.PgrWorkspaceView._fields_}

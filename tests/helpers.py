@@ -30,36 +30,38 @@ def gpu_forward(act: dict, view, sh_degree=3, bg=(0.0, 0.0, 0.0), device="cuda:0
     r = dict(color=color.cpu().numpy(), out_depth=depth.cpu().numpy(), radii=radii.cpu().numpy(),
              final_T=final_T.cpu().numpy(), n_contrib=n_contrib.cpu().numpy().astype(np.uint32))
     info = dgr.last_forward_info()
-    r["num_instances"] = info["num_instances"]
+    r["num_instances"] = info["num_instances"][0]
     n = means.shape[0]
     if fetch_intermediates and n > 0:
-        L = _lib.lib()
-        ws = info["workspace"]
-        v = _lib.PgrWorkspaceView()
-        _lib.check(L.pgr_workspace_view(C.c_void_p(ws.data_ptr()), ws.numel(), n, view.width, view.height,
-                                        _max_inst(info), C.byref(v)))
-        I = info["num_instances"]
-        tiles = ((view.width + 15) // 16) * ((view.height + 15) // 16)
-        base = ws.data_ptr()
-
-        def grab(ptr, count, dtype):
-            nbytes = count * np.dtype(dtype).itemsize
-            off = ptr - base
-            return ws[off:off + nbytes].cpu().numpy().view(dtype).copy()
-        r["xy"] = grab(v.xy, 2 * n, np.float32).reshape(n, 2)
-        r["depth"] = grab(v.depth, n, np.float32)
-        r["conic_opacity"] = grab(v.conic_opacity, 4 * n, np.float32).reshape(n, 4)
-        r["rgb4"] = grab(v.rgb, 4 * n, np.float32).reshape(n, 4)
-        r["tiles_touched"] = grab(v.tiles_touched, n, np.uint32).astype(np.int32)
-        r["offsets"] = grab(v.offsets, n, np.uint32)
-        r["keys_sorted"] = grab(v.keys_sorted, I, np.uint64)
-        r["gauss_sorted"] = grab(v.gauss_sorted, I, np.uint32)
-        r["ranges"] = grab(v.ranges, 2 * tiles, np.uint32).reshape(tiles, 2)
+        r.update(fetch_workspace(0, n, view.width, view.height))
     return r
 
 
-def _max_inst(info):
-    return info["used_max_instances"] if "used_max_instances" in info else info["max_instances"]
+def fetch_workspace(view_index, n, width, height):
+    """Copies one view's intermediate arrays out of the last forward's workspace (via pgr_workspace_view)."""
+    from pegasus_amd import rasterizer
+    info = rasterizer.last_forward_info()
+    ws = info["workspace"]
+    v = rasterizer.workspace_view(view_index)
+    I = info["num_instances"][view_index]
+    tiles = ((width + 15) // 16) * ((height + 15) // 16)
+    base = ws.data_ptr()
+
+    def grab(ptr, count, dtype):
+        nbytes = count * np.dtype(dtype).itemsize
+        off = ptr - base
+        return ws[off:off + nbytes].cpu().numpy().view(dtype).copy()
+    r = {}
+    r["xy"] = grab(v["xy"], 2 * n, np.float32).reshape(n, 2)
+    r["depth"] = grab(v["depth"], n, np.float32)
+    r["conic_opacity"] = grab(v["conic_opacity"], 4 * n, np.float32).reshape(n, 4)
+    r["rgb4"] = grab(v["rgb"], 4 * n, np.float32).reshape(n, 4)
+    r["tiles_touched"] = grab(v["tiles_touched"], n, np.uint32).astype(np.int32)
+    r["offsets"] = grab(v["offsets"], n, np.uint32)
+    r["keys_sorted"] = grab(v["keys_sorted"], I, np.uint64)
+    r["gauss_sorted"] = grab(v["gauss_sorted"], I, np.uint32)
+    r["ranges"] = grab(v["ranges"], 2 * tiles, np.uint32).reshape(tiles, 2)
+    return r
 
 
 def assert_preprocess_bit_exact(g, o):

@@ -161,3 +161,46 @@ def test_masks_and_quantisation(oracle, gpu_device):
     # and against numpy's own casts, which is what the reference executes (pegasus.py:347,355)
     np.testing.assert_array_equal(o_rgb, (img.transpose(1, 2, 0) * 255).astype(np.uint8))
     np.testing.assert_array_equal(o_mm, (depth * 1000).astype(np.uint16))
+
+
+def test_batch_matches_single_view_and_oracle(oracle, gpu_device):
+    """pgr_forward_batch: every view of a batch equals the single-view result bit for bit, and the oracle."""
+    import torch
+    from helpers import assert_images_match, fetch_workspace, gpu_forward
+    from pegasus_amd import rasterizer
+    cloud, views = scenes.scene_c3(scale=0.05, n_views=5)
+    act = cloud.activated()
+    dev = gpu_device
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    bgs = [(0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (0.2, 0.4, 0.6), (0.0, 0.0, 0.0), (0.5, 0.5, 0.5)]
+    specs = [rasterizer.ViewSpec(v.height, v.width, v.tanfovx, v.tanfovy, t(np.asarray(bg, np.float32)),
+                                 t(v.world_view_transform), t(v.full_proj_transform), t(v.camera_center))
+             for v, bg in zip(views, bgs)]
+    res = rasterizer.forward_views(t(act["means3d"]), t(act["opacities"]), specs, shs=t(act["shs"]),
+                                   scales=t(act["scales"]), rotations=t(act["rotations"]), sh_degree=3,
+                                   want_radii=True, want_aux=True)
+    torch.cuda.synchronize()
+    info = rasterizer.last_forward_info()
+    batch = []
+    for k, (r, v) in enumerate(zip(res, views)):
+        d = dict(color=r["color"].cpu().numpy(), out_depth=r["depth"].cpu().numpy(), radii=r["radii"].cpu().numpy(),
+                 final_T=r["final_T"].cpu().numpy(), n_contrib=r["n_contrib"].cpu().numpy().astype(np.uint32),
+                 num_instances=info["num_instances"][k])
+        d.update(fetch_workspace(k, cloud.n, v.width, v.height))
+        batch.append(d)
+    # same batch without radii / aux outputs (the throughput configuration): identical frames
+    res2 = rasterizer.forward_views(t(act["means3d"]), t(act["opacities"]), specs, shs=t(act["shs"]),
+                                    scales=t(act["scales"]), rotations=t(act["rotations"]), sh_degree=3,
+                                    want_radii=False)
+    torch.cuda.synchronize()
+    for k in range(len(views)):
+        assert res2[k]["radii"] is None
+        np.testing.assert_array_equal(res2[k]["color"].cpu().numpy(), batch[k]["color"])
+        np.testing.assert_array_equal(res2[k]["depth"].cpu().numpy(), batch[k]["out_depth"])
+    for k, (v, bg) in enumerate(zip(views, bgs)):
+        single = gpu_forward(act, v, bg=bg, device=str(dev))
+        for key in ("color", "out_depth", "radii", "final_T", "n_contrib", "gauss_sorted", "ranges"):
+            np.testing.assert_array_equal(batch[k][key], single[key], err_msg=f"view {k} {key}")
+        o = oracle.forward(**act, sh_degree=3, **v.raster_kwargs(bg), num_threads=8)
+        np.testing.assert_array_equal(batch[k]["gauss_sorted"], o["gauss_sorted"])
+        assert_images_match(batch[k], o)
