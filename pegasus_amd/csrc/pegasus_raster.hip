@@ -4,11 +4,13 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 #include <rocprim/rocprim.hpp>
 
 #include "binning.hip.h"
+#include "tilebin.hip.h"
 #include "composite.hip.h"
 #include "pgr_common.h"
 #include "preprocess.hip.h"
@@ -25,6 +27,8 @@ static bool hip_ok(hipError_t e, const char* what) {
 
 static size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
+// first length class that can hold a list longer than SORT_SMALL_MAX (4096 = 2^12 -> msb 12, frac 0)
+constexpr int LONG_LIST_CLASS = 12 * 8 + 0 + 1;
 constexpr size_t SORT_TEMP_FIXED = 32u << 20;  // histograms / look-back state of the device radix sort
 
 static Layout make_layout(int32_t n, int32_t width, int32_t height, int64_t max_instances) {
@@ -44,6 +48,10 @@ static Layout make_layout(int32_t n, int32_t width, int32_t height, int64_t max_
     L.tiles_touched = take(N * 4);
     L.offsets = take(N * 4);
     L.radii = take(N * 4);
+    L.rects = take(N * 8);
+    L.n_chunks = (int)((N + BIN_CHUNK - 1) / BIN_CHUNK);
+    L.tile_count = take((size_t)L.tiles * 4);
+    L.rel = take((size_t)L.n_chunks * L.tiles * 4);
     L.block_sums = take((size_t)L.n_blocks * 4);
     L.keys_unsorted = take(I * 8);
     L.vals_unsorted = take(I * 4);
@@ -105,6 +113,8 @@ struct ViewWs {
     float4* rgbd;
     uint32_t *tiles_touched, *offsets, *block_sums;
     int32_t* radii;   // per-view home of radii when the caller passes no radii output
+    uint2* rects;
+    uint32_t *tile_count, *rel;
     uint64_t *keys_u, *keys_s;
     uint32_t *vals_u, *vals_s;
     uint2* ranges;
@@ -122,6 +132,9 @@ static ViewWs carve(char* ws, const Layout& L) {
     v.tiles_touched = reinterpret_cast<uint32_t*>(ws + L.tiles_touched);
     v.offsets = reinterpret_cast<uint32_t*>(ws + L.offsets);
     v.radii = reinterpret_cast<int32_t*>(ws + L.radii);
+    v.rects = reinterpret_cast<uint2*>(ws + L.rects);
+    v.tile_count = reinterpret_cast<uint32_t*>(ws + L.tile_count);
+    v.rel = reinterpret_cast<uint32_t*>(ws + L.rel);
     v.block_sums = reinterpret_cast<uint32_t*>(ws + L.block_sums);
     v.keys_u = reinterpret_cast<uint64_t*>(ws + L.keys_unsorted);
     v.vals_u = reinterpret_cast<uint32_t*>(ws + L.vals_unsorted);
@@ -134,7 +147,7 @@ static ViewWs carve(char* ws, const Layout& L) {
 
 // Batch header placed in front of the per-view slices.
 struct BatchLayout {
-    size_t view_table, order_classes, work_order, views, total;
+    size_t view_table, bin_table, order_classes, work_order, views, total;
     size_t per_view;
 };
 
@@ -143,7 +156,8 @@ static BatchLayout make_batch_layout(const Layout& L, int n_views, int32_t n) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes ? bytes : 1); return o; };
     B.view_table = take((size_t)n_views * sizeof(ViewEntry));
-    B.order_classes = take(ORDER_CLASSES * 4);
+    B.bin_table = take((size_t)n_views * sizeof(BinView));
+    B.order_classes = take((ORDER_CLASSES + 1) * 4);
     B.work_order = take((size_t)n_views * L.tiles * 2 * 4);
     B.views = off;
     B.per_view = align_up(L.total);
@@ -205,6 +219,8 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     auto* work_order = reinterpret_cast<uint32_t*>(ws + B.work_order);
     std::vector<ViewWs> vw((size_t)n_views);
     std::vector<ViewEntry> table((size_t)n_views);
+    std::vector<BinView> bins((size_t)n_views);
+    auto* bin_table = reinterpret_cast<BinView*>(ws + B.bin_table);
     bool want_aux = false;
     for (int v = 0; v < n_views; ++v) {
         vw[v] = carve(ws + B.views + (size_t)v * B.per_view, L);
@@ -213,10 +229,15 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         e.cam = vw[v].cam; e.ranges = vw[v].ranges; e.gauss_sorted = vw[v].vals_s; e.xy = vw[v].xy;
         e.conic_opacity = vw[v].conop; e.rgbd = vw[v].rgbd;
         e.out = CompOut{outs[v].color, outs[v].depth, outs[v].final_T, outs[v].n_contrib};
+        e.counters = vw[v].counters;
         want_aux = want_aux || outs[v].final_T || outs[v].n_contrib;
+        bins[v] = BinView{vw[v].rects, vw[v].depth, vw[v].tile_count, vw[v].rel, vw[v].ranges, vw[v].counters,
+                          reinterpret_cast<uint2*>(vw[v].keys_u), vw[v].vals_s};
     }
     if (!hip_ok(hipMemcpyAsync(view_table, table.data(), table.size() * sizeof(ViewEntry), hipMemcpyHostToDevice,
-                               stream), "memcpy view table"))
+                               stream), "memcpy view table") ||
+        !hip_ok(hipMemcpyAsync(bin_table, bins.data(), bins.size() * sizeof(BinView), hipMemcpyHostToDevice, stream),
+                "memcpy bin table"))
         return PGR_ERR_LAUNCH_FAILURE;
 
     // ---- stage 0: camera pack + per-Gaussian preprocess
@@ -226,63 +247,93 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         pack_camera_kernel<<<1, 64, 0, stream>>>(c.viewmatrix, c.projmatrix, c.campos, c.bg, c.tanfovx, c.tanfovy, W, H,
                                                  vw[v].cam);
         // radii is part of the per-view contract; when the caller does not want it, it lands in scratch
-        PreOut po{vw[v].xy, vw[v].depth, vw[v].conop, vw[v].rgbd, vw[v].tiles_touched,
+        PreOut po{vw[v].xy, vw[v].depth, vw[v].conop, vw[v].rgbd, vw[v].tiles_touched, vw[v].rects,
                   outs[v].radii ? outs[v].radii : vw[v].radii, vw[v].block_sums};
         preprocess_kernel<<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, vw[v].cam, po);
     }
     mark(1);
-    // ---- stage 1: offset scan; the host reads the instance counts ONCE per batch (the reference
-    // reads num_rendered once per view), sizing the sorts and reporting overflow instead of rendering it.
-    for (int v = 0; v < n_views; ++v)
-        scan_block_sums_kernel<<<1, SCAN_THREADS, 0, stream>>>(vw[v].block_sums, L.n_blocks, vw[v].counters,
-                                                               (uint32_t)max_instances);
+    static const int binning = [] { const char* e = getenv("PGR_BINNING"); return e ? atoi(e) : 1; }();
     std::vector<uint32_t> h_counters((size_t)n_views * 2, 0u);
-    for (int v = 0; v < n_views; ++v)
-        if (!hip_ok(hipMemcpyAsync(&h_counters[2 * v], vw[v].counters, 8, hipMemcpyDeviceToHost, stream), "memcpy"))
+    const int grid_x = (W + TILE - 1) / TILE;
+    bool order_ready = false;
+    if (binning == 1) {
+        // ---- stage 1: per-chunk LDS tile histograms + slice reservation, then the tile scan (device only)
+        const size_t lds = (size_t)std::min(L.tiles, BIN_LDS_TILES) * 4;
+        for (int v = 0; v < n_views; ++v)
+            if (!hip_ok(hipMemsetAsync(vw[v].tile_count, 0, (size_t)L.tiles * 4, stream), "memset tile_count"))
+                return PGR_ERR_LAUNCH_FAILURE;
+        bin_count_kernel<<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(bin_table, N, grid_x, L.tiles);
+        tile_scan_kernel<<<n_views, 1024, 0, stream>>>(bin_table, L.tiles, (uint32_t)max_instances);
+        mark(2);
+        // ---- stage 2: scatter (depth bits, index) into the tiles' slices
+        bin_scatter_kernel<<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(bin_table, N, grid_x, L.tiles);
+        mark(3);
+        // ---- stage 3: per-tile (depth, index) sort, longest lists first
+        if (!hip_ok(hipMemsetAsync(classes, 0, ORDER_CLASSES * 4, stream), "memset classes"))
             return PGR_ERR_LAUNCH_FAILURE;
-    if (!hip_ok(hipStreamSynchronize(stream), "sync after scan")) return PGR_ERR_LAUNCH_FAILURE;
-    bool overflow = false;
-    for (int v = 0; v < n_views; ++v) {
-        if (num_instances) num_instances[v] = (int64_t)h_counters[2 * v];
-        overflow = overflow || h_counters[2 * v + 1] || (int64_t)h_counters[2 * v] > max_instances;
+        const dim3 og((L.tiles + 255) / 256, n_views);
+        order_count_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, classes);
+        order_scan_kernel<<<1, ORDER_CLASSES, 0, stream>>>(classes, LONG_LIST_CLASS);
+        order_scatter_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, classes, work_order);
+        order_ready = true;
+        tile_sort_large_kernel<<<std::min(n_views * L.tiles, 1024), SORT_LARGE_THREADS, 0, stream>>>(
+            bin_table, L.tiles, work_order, classes + ORDER_CLASSES);
+        tile_sort_kernel<<<n_views * L.tiles, SORT_THREADS, 0, stream>>>(bin_table, L.tiles, work_order);
+        mark(4);
+        mark(5);
+    } else {
+        // ---- stage 1: offset scan; the host reads the instance counts ONCE per batch (the reference
+        // reads num_rendered once per view), sizing the sorts and reporting overflow instead of rendering it.
+        for (int v = 0; v < n_views; ++v)
+            scan_block_sums_kernel<<<1, SCAN_THREADS, 0, stream>>>(vw[v].block_sums, L.n_blocks, vw[v].counters,
+                                                                   (uint32_t)max_instances);
+        for (int v = 0; v < n_views; ++v)
+            if (!hip_ok(hipMemcpyAsync(&h_counters[2 * v], vw[v].counters, 8, hipMemcpyDeviceToHost, stream), "memcpy"))
+                return PGR_ERR_LAUNCH_FAILURE;
+        if (!hip_ok(hipStreamSynchronize(stream), "sync after scan")) return PGR_ERR_LAUNCH_FAILURE;
+        bool overflow = false;
+        for (int v = 0; v < n_views; ++v) {
+            if (num_instances) num_instances[v] = (int64_t)h_counters[2 * v];
+            overflow = overflow || h_counters[2 * v + 1] || (int64_t)h_counters[2 * v] > max_instances;
+        }
+        if (overflow) return PGR_ERR_INSTANCE_OVERFLOW;
+        mark(2);
+        // ---- stage 2: (tile, depth) instance emission
+        for (int v = 0; v < n_views; ++v) {
+            if (!hip_ok(hipMemsetAsync(vw[v].ranges, 0, (size_t)L.tiles * sizeof(uint2), stream), "memset ranges"))
+                return PGR_ERR_LAUNCH_FAILURE;
+            emit_kernel<<<L.n_blocks, PRE_BLOCK, 0, stream>>>(N, vw[v].cam, vw[v].xy, vw[v].depth,
+                                                              outs[v].radii ? outs[v].radii : vw[v].radii,
+                                                              vw[v].tiles_touched, vw[v].block_sums, vw[v].counters,
+                                                              vw[v].offsets, vw[v].keys_u, vw[v].vals_u);
+        }
+        mark(3);
+        // ---- stage 3: stable sort by (tile, depth bits)
+        int tbits = 0;
+        while ((1 << tbits) < L.tiles) ++tbits;
+        for (int v = 0; v < n_views; ++v) {
+            const size_t total = h_counters[2 * v];
+            if (total == 0) continue;
+            size_t temp_bytes = 0;
+            if (!hip_ok(rocprim::radix_sort_pairs(nullptr, temp_bytes, vw[v].keys_u, vw[v].keys_s, vw[v].vals_u,
+                                                  vw[v].vals_s, total, 0u, (unsigned)(32 + tbits), stream),
+                        "radix_sort size query"))
+                return PGR_ERR_LAUNCH_FAILURE;
+            if (temp_bytes > L.sort_temp_bytes) return PGR_ERR_WORKSPACE_TOO_SMALL;
+            if (!hip_ok(rocprim::radix_sort_pairs(vw[v].sort_temp, temp_bytes, vw[v].keys_u, vw[v].keys_s, vw[v].vals_u,
+                                                  vw[v].vals_s, total, 0u, (unsigned)(32 + tbits), stream),
+                        "radix_sort_pairs"))
+                return PGR_ERR_LAUNCH_FAILURE;
+        }
+        mark(4);
+        // ---- stage 4: tile ranges
+        for (int v = 0; v < n_views; ++v) {
+            const uint32_t total = h_counters[2 * v];
+            if (total)
+                tile_ranges_kernel<<<(total + 255) / 256, 256, 0, stream>>>(vw[v].counters, vw[v].keys_s, vw[v].ranges);
+        }
+        mark(5);
     }
-    if (overflow) return PGR_ERR_INSTANCE_OVERFLOW;
-    mark(2);
-    // ---- stage 2: (tile, depth) instance emission
-    for (int v = 0; v < n_views; ++v) {
-        if (!hip_ok(hipMemsetAsync(vw[v].ranges, 0, (size_t)L.tiles * sizeof(uint2), stream), "memset ranges"))
-            return PGR_ERR_LAUNCH_FAILURE;
-        emit_kernel<<<L.n_blocks, PRE_BLOCK, 0, stream>>>(N, vw[v].cam, vw[v].xy, vw[v].depth,
-                                                          outs[v].radii ? outs[v].radii : vw[v].radii,
-                                                          vw[v].tiles_touched, vw[v].block_sums, vw[v].counters,
-                                                          vw[v].offsets, vw[v].keys_u, vw[v].vals_u);
-    }
-    mark(3);
-    // ---- stage 3: stable sort by (tile, depth bits)
-    int tbits = 0;
-    while ((1 << tbits) < L.tiles) ++tbits;
-    for (int v = 0; v < n_views; ++v) {
-        const size_t total = h_counters[2 * v];
-        if (total == 0) continue;
-        size_t temp_bytes = 0;
-        if (!hip_ok(rocprim::radix_sort_pairs(nullptr, temp_bytes, vw[v].keys_u, vw[v].keys_s, vw[v].vals_u,
-                                              vw[v].vals_s, total, 0u, (unsigned)(32 + tbits), stream),
-                    "radix_sort size query"))
-            return PGR_ERR_LAUNCH_FAILURE;
-        if (temp_bytes > L.sort_temp_bytes) return PGR_ERR_WORKSPACE_TOO_SMALL;
-        if (!hip_ok(rocprim::radix_sort_pairs(vw[v].sort_temp, temp_bytes, vw[v].keys_u, vw[v].keys_s, vw[v].vals_u,
-                                              vw[v].vals_s, total, 0u, (unsigned)(32 + tbits), stream),
-                    "radix_sort_pairs"))
-            return PGR_ERR_LAUNCH_FAILURE;
-    }
-    mark(4);
-    // ---- stage 4: tile ranges
-    for (int v = 0; v < n_views; ++v) {
-        const uint32_t total = h_counters[2 * v];
-        if (total)
-            tile_ranges_kernel<<<(total + 255) / 256, 256, 0, stream>>>(vw[v].counters, vw[v].keys_s, vw[v].ranges);
-    }
-    mark(5);
     // ---- stage 5: compositing of every (view, tile, half) work item in ONE launch, longest lists first
     static const int variant = [] { const char* e = getenv("PGR_COMPOSITE"); return e ? atoi(e) : 2; }();
     if (variant == 0) {
@@ -291,12 +342,14 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
                                                                    vw[v].conop, vw[v].rgbd, table[v].out);
     } else {
         const uint32_t* order = nullptr;
-        if (variant == 2) {
+        if (variant == 2 && order_ready) {
+            order = work_order;
+        } else if (variant == 2) {
             if (!hip_ok(hipMemsetAsync(classes, 0, ORDER_CLASSES * 4, stream), "memset classes"))
                 return PGR_ERR_LAUNCH_FAILURE;
             const dim3 og((L.tiles + 255) / 256, n_views);
             order_count_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, classes);
-            order_scan_kernel<<<1, ORDER_CLASSES, 0, stream>>>(classes);
+            order_scan_kernel<<<1, ORDER_CLASSES, 0, stream>>>(classes, LONG_LIST_CLASS);
             order_scatter_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, classes, work_order);
             order = work_order;
         }
@@ -309,6 +362,19 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     }
     mark(6);
     if (!hip_ok(hipGetLastError(), "kernel launch")) return PGR_ERR_LAUNCH_FAILURE;
+    if (binning == 1) {
+        // the only host read of the batch: instance counts + overflow flags, after everything is enqueued
+        for (int v = 0; v < n_views; ++v)
+            if (!hip_ok(hipMemcpyAsync(&h_counters[2 * v], vw[v].counters, 8, hipMemcpyDeviceToHost, stream), "memcpy"))
+                return PGR_ERR_LAUNCH_FAILURE;
+        if (!hip_ok(hipStreamSynchronize(stream), "sync at batch end")) return PGR_ERR_LAUNCH_FAILURE;
+        bool overflow = false;
+        for (int v = 0; v < n_views; ++v) {
+            if (num_instances) num_instances[v] = (int64_t)h_counters[2 * v];
+            overflow = overflow || h_counters[2 * v + 1];
+        }
+        if (overflow) return PGR_ERR_INSTANCE_OVERFLOW;
+    }
     return PGR_OK;
 }
 

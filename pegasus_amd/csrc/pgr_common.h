@@ -34,12 +34,24 @@ static_assert(sizeof(CameraDev) == 256, "CameraDev must be 256 B");
 
 // Workspace carve-up (all offsets multiples of 256 B).
 struct Layout {
-    size_t cam, counters, xy, depth, conic_opacity, rgb, tiles_touched, offsets, radii, block_sums,
+    size_t cam, counters, xy, depth, conic_opacity, rgb, tiles_touched, offsets, radii, rects, tile_count, rel, block_sums,
         keys_unsorted, vals_unsorted, keys_sorted, vals_sorted, ranges, work_order, order_classes, sort_temp, total;
     size_t sort_temp_bytes;
     int32_t tiles;
     int32_t n_blocks;
+    int32_t n_chunks;
 };
+
+// Work ordering: half-tile work items sorted by DESCENDING list length in 256 log-spaced classes, so long
+// lists start first and short ones back-fill the SIMDs that finish early.  Order never affects results.
+constexpr int ORDER_CLASSES = 256;
+
+__device__ __forceinline__ int length_class(uint32_t len) {
+    if (len == 0) return 0;
+    const int msb = 31 - __clz((int)len);
+    const uint32_t frac = msb >= 3 ? (len >> (msb - 3)) & 7u : (len << (3 - msb)) & 7u;
+    return msb * 8 + (int)frac + 1;   // 1..256 -> clamp below
+}
 
 constexpr int PRE_BLOCK = 256;               // Gaussians per preprocess workgroup
 

@@ -125,6 +125,7 @@ struct PreOut {
     float4* conic_opacity;
     float4* rgb;             // (r,g,b,depth)
     uint32_t* tiles_touched;
+    uint2* rects;            // packed tile rectangle (4 x uint16), all zero when culled
     int32_t* radii;
     uint32_t* block_sums;    // [gridDim.x] sum of tiles_touched per workgroup
 };
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_kernel(PgrScene sc, cons
     const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
     uint32_t touched = 0;
     int radius = 0;
+    uint2 rect = make_uint2(0u, 0u);
 
     if (i < sc.n) {
         const float px = sc.means3d[3 * i + 0], py = sc.means3d[3 * i + 1], pz = sc.means3d[3 * i + 2];
@@ -217,6 +219,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_kernel(PgrScene sc, cons
                     }
                     radius = rad;
                     touched = (uint32_t)(w * h);
+                    rect = make_uint2((uint32_t)r.minx | ((uint32_t)r.miny << 16),
+                                      (uint32_t)r.maxx | ((uint32_t)r.maxy << 16));
                     o.xy[i] = make_float2(pix_x, pix_y);
                     o.depth[i] = tz;
                     o.conic_opacity[i] = make_float4(con_x, con_y, con_z, sc.opacities[i]);
@@ -226,6 +230,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_kernel(PgrScene sc, cons
         }
         o.radii[i] = radius;
         o.tiles_touched[i] = touched;
+        o.rects[i] = rect;
     }
 
     // workgroup sum of tiles_touched -> block_sums (feeds the offset scan without re-reading HBM)

@@ -58,7 +58,6 @@ def fetch_workspace(view_index, n, width, height):
     r["rgb4"] = grab(v["rgb"], 4 * n, np.float32).reshape(n, 4)
     r["tiles_touched"] = grab(v["tiles_touched"], n, np.uint32).astype(np.int32)
     r["offsets"] = grab(v["offsets"], n, np.uint32)
-    r["keys_sorted"] = grab(v["keys_sorted"], I, np.uint64)
     r["gauss_sorted"] = grab(v["gauss_sorted"], I, np.uint32)
     r["ranges"] = grab(v["ranges"], 2 * tiles, np.uint32).reshape(tiles, 2)
     return r
