@@ -70,10 +70,9 @@ def algorithmic_bytes(N, V, I, P):
     per-stage split it is the sum of."""
     per_stage = {
         "preprocess": 12 * N + 224 * V + 4 * N + 48 * V,
-        "scan": 0,
-        "emit": 12 * I,
-        "sort": 24 * I,
-        "ranges": 8 * I,
+        "bin_count": 0,
+        "bin_scatter": 12 * I,
+        "tile_sort": 24 * I + 8 * I,
         "composite": 44 * I + 16 * P,
     }
     return 16 * N + 272 * V + 88 * I + 16 * P, per_stage
@@ -191,7 +190,7 @@ def main():
         "stage_ms_per_view": {k: round(float(m) / B, 4) for k, m in zip(_lib.STAGE_NAMES, mean_ms)},
         "whole_path": {"bytes_per_view": int(B_view), "achieved": round(B_view * value / world / 1e9, 2),
                        "frac": round(B_view * value / world / 1e9 / HBM_PEAK_GBS, 5)},
-        "composite_evals_per_s": round(evals * B / (mean_ms[5] * 1e-3), 1) if mean_ms[5] > 0 else None,
+        "composite_evals_per_s": round(evals * B / (mean_ms[4] * 1e-3), 1) if mean_ms[4] > 0 else None,
         "N": N, "V": round(V), "I": round(I), "P": P,
     }
 

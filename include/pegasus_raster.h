@@ -41,7 +41,7 @@ typedef enum PgrStatus {
     PGR_OK = 0,
     PGR_ERR_INVALID_ARGUMENT = -1,   /* NULL / inconsistent pointers, bad sizes, bad sh_degree */
     PGR_ERR_WORKSPACE_TOO_SMALL = -2,/* workspace_bytes < pgr_workspace_bytes(...) */
-    PGR_ERR_INSTANCE_OVERFLOW = -3,  /* sum(tiles_touched) > max_instances; *num_instances holds the need */
+    PGR_ERR_INSTANCE_OVERFLOW = -3,  /* listed instances > max_instances; *num_instances holds the need */
     PGR_ERR_LAUNCH_FAILURE = -4,     /* a HIP call failed; see pgr_last_hip_error */
     PGR_ERR_NO_DEVICE = -5
 } PgrStatus;
@@ -80,18 +80,16 @@ typedef struct PgrOutputs {
     uint32_t *n_contrib;         /* [H,W]    optional (NULL) */
 } PgrOutputs;
 
-/* Device pointers into a workspace, for stage-level parity tests and for backward. */
+/* Device pointers into one view's slice of a workspace, for stage-level parity tests and for backward. */
 typedef struct PgrWorkspaceView {
-    const float *xy;             /* [n,2] */
-    const float *depth;          /* [n]   */
+    const float *xy;             /* [n,2] pixel centre */
+    const float *depth;          /* [n]   view-space z */
     const float *conic_opacity;  /* [n,4] */
-    const float *rgb;            /* [n,4] (r,g,b,unused) */
-    const uint32_t *tiles_touched; /* [n] */
-    const uint32_t *offsets;     /* [n] inclusive scan */
-    const uint64_t *keys_sorted; /* [num_instances] (tile << 32) | depth bits */
-    const uint32_t *gauss_sorted;/* [num_instances] */
-    const uint32_t *ranges;      /* [tiles,2] */
-    const uint32_t *num_instances; /* [1] device counter */
+    const float *rgb;            /* [n,4] (r,g,b,depth) */
+    const uint16_t *rects;       /* [n,4] tile rectangle minx,miny,maxx,maxy (max exclusive); zeros = culled */
+    const uint32_t *gauss_sorted;/* [num_instances] Gaussian index, tile-major, (depth, index) ascending per tile */
+    const uint32_t *ranges;      /* [tiles,2] start,end into gauss_sorted */
+    const uint32_t *num_instances; /* [0] listed instances, [1] overflow flag */
 } PgrWorkspaceView;
 
 int32_t pgr_abi_version(void);
@@ -107,9 +105,10 @@ size_t pgr_workspace_bytes(int32_t n, int32_t width, int32_t height, int64_t max
 size_t pgr_batch_workspace_bytes(int32_t n, int32_t width, int32_t height, int64_t max_instances_per_view,
                                  int32_t n_views);
 
-/* Render one view.  `num_instances` (host, optional) receives sum(tiles_touched).  The call
- * synchronises `stream` once, after the offset scan, exactly where the reference reads
- * num_rendered back, so that an overflow is reported instead of rendered. */
+/* Render one view.  `num_instances` (host, optional) receives the number of listed (Gaussian, tile)
+ * instances.  Everything is enqueued on `stream`; the call synchronises the stream once, at the end, to
+ * read the instance count and the overflow flag (the reference synchronises mid-pipeline to read
+ * num_rendered), so that an overflow is reported instead of returned as an image. */
 int32_t pgr_forward(const PgrScene *scene, const PgrCamera *camera, const PgrOutputs *out,
                     void *workspace, size_t workspace_bytes, int64_t max_instances,
                     int64_t *num_instances, void *stream);
@@ -118,8 +117,8 @@ int32_t pgr_forward(const PgrScene *scene, const PgrCamera *camera, const PgrOut
  * render() once per camera over the same merged cloud; this is that loop as one call).  `cameras` and
  * `outs` are HOST arrays of n_views entries; all views share the image size; outs[v].radii may be NULL.
  * The batch is what fills an MI355X: the compositing of every (view, tile) list is one launch, ordered
- * longest list first, so no view waits on its own slowest tile.  One stream synchronisation per batch
- * (instance counts), `num_instances` (host, optional) receives n_views counts. */
+ * longest list first, so no view waits on its own slowest tile.  One stream synchronisation per batch, at
+ * its end (instance counts + overflow flags); `num_instances` (host, optional) receives n_views counts. */
 int32_t pgr_forward_batch(const PgrScene *scene, int32_t n_views, const PgrCamera *cameras,
                           const PgrOutputs *outs, void *workspace, size_t workspace_bytes,
                           int64_t max_instances_per_view, int64_t *num_instances, void *stream);
@@ -127,10 +126,13 @@ int32_t pgr_forward_batch(const PgrScene *scene, int32_t n_views, const PgrCamer
 /* Profiling twin of pgr_forward_batch (bench / rocprof only): records HIP events on `stream` at the
  * stage boundaries (each stage runs for all views before the next starts), synchronises, and writes the
  * elapsed milliseconds of each stage for the whole batch to stage_ms[PGR_NUM_STAGES] in PgrStage order. */
-#define PGR_NUM_STAGES 6
+#define PGR_NUM_STAGES 5
 typedef enum PgrStage {
-    PGR_STAGE_PREPROCESS = 0, PGR_STAGE_SCAN = 1, PGR_STAGE_EMIT = 2, PGR_STAGE_SORT = 3,
-    PGR_STAGE_RANGES = 4, PGR_STAGE_COMPOSITE = 5
+    PGR_STAGE_PREPROCESS = 0,  /* camera pack + per-Gaussian projection / EWA / SH */
+    PGR_STAGE_BIN_COUNT = 1,   /* per-chunk tile histograms, slice reservation, tile scan */
+    PGR_STAGE_BIN_SCATTER = 2, /* (depth, index) pairs into the tiles' slices */
+    PGR_STAGE_TILE_SORT = 3,   /* work order + per-tile (depth, index) sort */
+    PGR_STAGE_COMPOSITE = 4    /* front-to-back alpha compositing of all views */
 } PgrStage;
 int32_t pgr_forward_batch_profiled(const PgrScene *scene, int32_t n_views, const PgrCamera *cameras,
                                    const PgrOutputs *outs, void *workspace, size_t workspace_bytes,

@@ -40,7 +40,7 @@ class _In(C.Structure):
         ("sh_degree", C.c_int32), ("sh_stride", C.c_int32), ("scale_modifier", C.c_float),
         ("width", C.c_int32), ("height", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
         ("viewmatrix", C.c_float * 16), ("projmatrix", C.c_float * 16),
-        ("campos", C.c_float * 3), ("bg", C.c_float * 3),
+        ("campos", C.c_float * 3), ("bg", C.c_float * 3), ("cull_mode", C.c_int32),
     ]
 
 
@@ -74,6 +74,9 @@ def lib():
         _lib.pgr_oracle_color_masks.restype = C.c_int
         _lib.pgr_oracle_quantize.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         _lib.pgr_oracle_quantize.restype = C.c_int
+        _lib.pgr_oracle_tile_may_contribute.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                                         C.c_int32]
+        _lib.pgr_oracle_tile_may_contribute.restype = C.c_int
         _lib.pgr_oracle_version.restype = C.c_char_p
     return _lib
 
@@ -93,7 +96,7 @@ def _ptr(a):
 
 def _make_in(means3d, opacities, *, scales=None, rotations=None, cov3d_precomp=None, shs=None,
              colors_precomp=None, sh_degree=0, scale_modifier=1.0, width, height, tanfovx, tanfovy,
-             viewmatrix, projmatrix, campos, bg):
+             viewmatrix, projmatrix, campos, bg, cull_mode=0):
     means3d = _f32(means3d).reshape(-1, 3)
     n = means3d.shape[0]
     keep = dict(means3d=means3d, opacities=_f32(opacities).reshape(-1) if n or opacities is not None else None,
@@ -113,6 +116,7 @@ def _make_in(means3d, opacities, *, scales=None, rotations=None, cov3d_precomp=N
     i.projmatrix = (C.c_float * 16)(*_f32(projmatrix).reshape(16))
     i.campos = (C.c_float * 3)(*_f32(campos).reshape(3))
     i.bg = (C.c_float * 3)(*_f32(bg).reshape(3))
+    i.cull_mode = int(cull_mode)
     return i, keep, n
 
 
@@ -160,6 +164,9 @@ def forward(means3d, opacities, *, num_threads=1, want_binning=True, stage="all"
     if rc:
         raise ValueError(f"pgr_oracle_forward failed: {rc}")
     r["num_instances"] = int(o.num_instances)
+    if want_binning:   # cull_mode 1 emits fewer instances than the rectangle count the arrays were sized for
+        r["keys_sorted"] = r["keys_sorted"][:r["num_instances"]]
+        r["gauss_sorted"] = r["gauss_sorted"][:r["num_instances"]]
     del keep
     return r
 
@@ -195,6 +202,12 @@ def quantize(img_chw, depth_hw):
     if rc:
         raise ValueError("pgr_oracle_quantize failed")
     return rgb, mm
+
+
+def tile_may_contribute(xy, conic_opacity, tx, ty, width, height) -> bool:
+    a = _f32(xy).reshape(2)
+    b = _f32(conic_opacity).reshape(4)
+    return bool(lib().pgr_oracle_tile_may_contribute(_ptr(a), _ptr(b), int(tx), int(ty), int(width), int(height)))
 
 
 def version() -> str:

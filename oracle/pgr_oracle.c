@@ -15,7 +15,7 @@
 #include <omp.h>
 #endif
 
-const char *pgr_oracle_version(void) { return "pgr-oracle 1.0 (spec rev 1)"; }
+const char *pgr_oracle_version(void) { return "pgr-oracle 1.1 (spec rev 2: tight lists)"; }
 
 /* ---- real spherical-harmonics constants (published 3DGS basis) ---- */
 static const float SH_C0 = 0.28209479177387814f;
@@ -103,6 +103,51 @@ static void sh_basis(int deg, float x, float y, float z, float b[16])
             }
         }
     }
+}
+
+
+/* ---- tight-list predicate (cull_mode 1) ------------------------------------------------------------
+ * A (Gaussian, tile) instance only matters if alpha = min(0.99, op*exp(power)) >= 1/255 at some pixel of
+ * the tile.  With q = A dx^2 + 2B dx dy + C dy^2 (power = -q/2) that needs q <= 2 ln(255 op) somewhere.
+ * The test below bounds q from BELOW over the continuous pixel rectangle of the tile (exact minimum of the
+ * convex form: 0 if the centre is inside, else the smallest of the four edge minima) and 2 ln(255 op) from
+ * ABOVE (exponent + chord of log2 on the mantissa + 0.0861), adds a rounding margin, and keeps the instance
+ * unless the lower bound clears the upper bound.  Dropped instances would have been skipped at every pixel,
+ * so every pixel's arithmetic is unchanged.  No transcendental: identical bits on CPU and GPU. */
+static inline float edge_min_q(float A, float B, float C, float r, float d_fixed, float lo, float hi)
+{
+    /* minimise over t in [lo,hi]:  A*d^2 + 2*B*d*t + C*t^2   (d = d_fixed, C > 0, r = B / C) */
+    float t = -(d_fixed * r);
+    t = fminf(hi, fmaxf(lo, t));
+    return A * d_fixed * d_fixed + 2.0f * B * d_fixed * t + C * t * t;
+}
+
+int pgr_oracle_tile_may_contribute(const float xy[2], const float co[4], int32_t tx, int32_t ty, int32_t W, int32_t H)
+{
+    const float A = co[0], B = co[1], C = co[2], op = co[3];
+    if (op < PGR_ALPHA_MIN) return 0;            /* alpha <= op < 1/255 at every pixel, exactly */
+    if (!(A > 0.0f) || !(C > 0.0f)) return 1;    /* degenerate conic: no claim */
+    const float x0 = (float)(tx * PGR_TILE), y0 = (float)(ty * PGR_TILE);
+    const float x1 = fminf(x0 + (float)(PGR_TILE - 1), (float)(W - 1));
+    const float y1 = fminf(y0 + (float)(PGR_TILE - 1), (float)(H - 1));
+    const float mx = xy[0], my = xy[1];
+    if (mx >= x0 && mx <= x1 && my >= y0 && my <= y1) return 1;
+    const float dx0 = x0 - mx, dx1 = x1 - mx, dy0 = y0 - my, dy1 = y1 - my;
+    const float rBC = B / C, rBA = B / A;
+    float q = edge_min_q(A, B, C, rBC, dx0, dy0, dy1);
+    q = fminf(q, edge_min_q(A, B, C, rBC, dx1, dy0, dy1));
+    q = fminf(q, edge_min_q(C, B, A, rBA, dy0, dx0, dx1));
+    q = fminf(q, edge_min_q(C, B, A, rBA, dy1, dx0, dx1));
+    /* upper bound of 2 ln(255 op): 255 op = m 2^e, log2 m <= (m-1) + 0.0861 */
+    const float t = 255.0f * op;
+    const uint32_t bits = float_to_bits(t);
+    const float e = (float)((int32_t)((bits >> 23) & 0xffu) - 127);
+    const float m = bits_to_float((bits & 0x007fffffu) | 0x3f800000u);
+    const float tau = 1.3862944f * (e + (m - 1.0f) + 0.0861f);
+    /* rounding margin: 1e-5 of the largest the three terms get anywhere in the rectangle, + 0.01 */
+    const float DX = fmaxf(fabsf(dx0), fabsf(dx1)), DY = fmaxf(fabsf(dy0), fabsf(dy1));
+    const float M = A * DX * DX + 2.0f * fabsf(B) * DX * DY + C * DY * DY;
+    return q > tau + 0.00001f * M + 0.01f ? 0 : 1;   /* a NaN anywhere keeps the instance */
 }
 
 /* ---- preprocess: one Gaussian ---- */
@@ -381,10 +426,27 @@ int pgr_oracle_forward(const PgrOracleIn *in, PgrOracleOut *out, int num_threads
 
     int rc = pgr_oracle_preprocess(in, &o, num_threads);
 
-    /* a6: inclusive scan of tiles_touched */
+    /* a6: inclusive scan of the per-Gaussian instance counts (cull_mode 1: only the tiles that may contribute) */
     int64_t total = 0;
     int64_t *offs = (int64_t *)malloc((size_t)n * sizeof(int64_t));
-    for (int32_t i = 0; i < n; ++i) { total += tt[i]; offs[i] = total; }
+    int32_t *kept = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+#pragma omp parallel for schedule(static) num_threads(num_threads)
+    for (int32_t i = 0; i < n; ++i) {
+        kept[i] = tt[i];
+        if (in->cull_mode == 1 && tt[i] > 0) {
+            const float rf = (float)radii[i], px = xy[2 * i], py = xy[2 * i + 1];
+            const int32_t minx = clamp_trunc((px - rf) / (float)PGR_TILE, grid_x);
+            const int32_t miny = clamp_trunc((py - rf) / (float)PGR_TILE, grid_y);
+            const int32_t maxx = clamp_trunc((px + rf + (float)(PGR_TILE - 1)) / (float)PGR_TILE, grid_x);
+            const int32_t maxy = clamp_trunc((py + rf + (float)(PGR_TILE - 1)) / (float)PGR_TILE, grid_y);
+            int32_t c = 0;
+            for (int32_t y = miny; y < maxy; ++y)
+                for (int32_t x = minx; x < maxx; ++x)
+                    c += pgr_oracle_tile_may_contribute(xy + 2 * i, conop + 4 * i, x, y, W, H);
+            kept[i] = c;
+        }
+    }
+    for (int32_t i = 0; i < n; ++i) { total += kept[i]; offs[i] = total; }
     out->num_instances = total;
 
     uint64_t *keys = NULL;
@@ -399,16 +461,18 @@ int pgr_oracle_forward(const PgrOracleIn *in, PgrOracleOut *out, int num_threads
         /* a7: emission, Gaussian-major, then tile row-major; recompute the rectangle exactly as preprocess did */
 #pragma omp parallel for schedule(static) num_threads(num_threads)
         for (int32_t i = 0; i < n; ++i) {
-            if (tt[i] == 0) continue;
+            if (kept[i] == 0) continue;
             const float rf = (float)radii[i], px = xy[2 * i], py = xy[2 * i + 1];
             const int32_t minx = clamp_trunc((px - rf) / (float)PGR_TILE, grid_x);
             const int32_t miny = clamp_trunc((py - rf) / (float)PGR_TILE, grid_y);
             const int32_t maxx = clamp_trunc((px + rf + (float)(PGR_TILE - 1)) / (float)PGR_TILE, grid_x);
             const int32_t maxy = clamp_trunc((py + rf + (float)(PGR_TILE - 1)) / (float)PGR_TILE, grid_y);
-            int64_t off = offs[i] - tt[i];
+            int64_t off = offs[i] - kept[i];
             const uint64_t dbits = float_to_bits(depth[i]);
             for (int32_t y = miny; y < maxy; ++y)
                 for (int32_t x = minx; x < maxx; ++x) {
+                    if (in->cull_mode == 1 && !pgr_oracle_tile_may_contribute(xy + 2 * i, conop + 4 * i, x, y, W, H))
+                        continue;
                     keys[off] = ((uint64_t)(uint32_t)(y * grid_x + x) << 32) | dbits;
                     vals[off] = (uint32_t)i;
                     ++off;
@@ -428,6 +492,7 @@ int pgr_oracle_forward(const PgrOracleIn *in, PgrOracleOut *out, int num_threads
         }
     }
     free(offs);
+    free(kept);
 
     /* a10: compositor, every tile (empty tiles produce bg colour, zero depth, T = 1) */
     if (rc == 0) {

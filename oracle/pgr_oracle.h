@@ -61,6 +61,10 @@ typedef struct PgrOracleIn {
     float projmatrix[16];
     float campos[3];
     float bg[3];
+    int32_t cull_mode;              /* 0 = reference lists (every tile of the 3-sigma rectangle);
+                                       1 = tight lists: instances that provably cannot reach alpha >= 1/255 at
+                                           any pixel of their tile are dropped (pgr_oracle_tile_may_contribute).
+                                           Images are bit-identical in both modes; n_contrib indexes the list. */
 } PgrOracleIn;
 
 typedef struct PgrOracleOut {
@@ -102,6 +106,11 @@ int pgr_oracle_color_masks(const float *img_chw, int32_t width, int32_t height, 
 /* output quantisation (reference: pegasus.py:347,355): rgb (img*255).astype(uint8) wraps, depth (d*1000).astype(uint16) */
 int pgr_oracle_quantize(const float *img_chw, const float *depth_hw, int32_t width, int32_t height,
                         uint8_t *rgb_hwc, uint16_t *depth_mm_hw);
+
+/* The tight-list predicate (cull_mode 1): 1 if the splat (xy, conic+opacity) may reach alpha >= 1/255 at some
+ * pixel centre of tile (tx,ty), 0 if it provably cannot.  Pure fp32 +,-,*,/ and integer ops: bit-reproducible. */
+int pgr_oracle_tile_may_contribute(const float xy[2], const float conic_opacity[4], int32_t tx, int32_t ty,
+                                   int32_t width, int32_t height);
 
 const char *pgr_oracle_version(void);
 

@@ -15,8 +15,8 @@ PGR_ERR_INVALID_ARGUMENT = -1
 PGR_ERR_WORKSPACE_TOO_SMALL = -2
 PGR_ERR_INSTANCE_OVERFLOW = -3
 PGR_ERR_LAUNCH_FAILURE = -4
-PGR_NUM_STAGES = 6
-STAGE_NAMES = ("preprocess", "scan", "emit", "sort", "ranges", "composite")
+PGR_NUM_STAGES = 5
+STAGE_NAMES = ("preprocess", "bin_count", "bin_scatter", "tile_sort", "composite")
 
 
 class PgrScene(C.Structure):
@@ -41,8 +41,8 @@ class PgrOutputs(C.Structure):
 
 
 class PgrWorkspaceView(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("xy", "depth", "conic_opacity", "rgb", "tiles_touched", "offsets",
-                                          "keys_sorted", "gauss_sorted", "ranges", "num_instances")]
+    _fields_ = [(k, C.c_void_p) for k in ("xy", "depth", "conic_opacity", "rgb", "rects", "gauss_sorted", "ranges",
+                                          "num_instances")]
 
 
 # every symbol include/pegasus_raster.h declares: name -> (restype, argtypes)

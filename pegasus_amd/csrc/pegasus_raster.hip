@@ -1,19 +1,23 @@
 // pegasus_raster.hip -- C ABI of libpegasus_raster.so (see include/pegasus_raster.h).
 // gfx950 only.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC
+//
+// Pipeline of one batch of views of one scene (all stages enqueued on the caller's stream, no host
+// round trip until the end-of-batch status read):
+//   per view : pack_camera, preprocess                           (preprocess.hip.h)
+//   batch    : bin_count -> tile_scan -> bin_scatter -> work order -> tile_sort(_large)   (tilebin.hip.h)
+//   batch    : composite_wave over every (view, tile, half) work item, longest lists first (composite.hip.h)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
-#include <algorithm>
 #include <cstring>
 #include <vector>
-#include <rocprim/rocprim.hpp>
 
-#include "binning.hip.h"
-#include "tilebin.hip.h"
 #include "composite.hip.h"
 #include "pgr_common.h"
 #include "preprocess.hip.h"
+#include "tilebin.hip.h"
 
 namespace pgr {
 
@@ -29,7 +33,6 @@ static size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // first length class that can hold a list longer than SORT_SMALL_MAX (4096 = 2^12 -> msb 12, frac 0)
 constexpr int LONG_LIST_CLASS = 12 * 8 + 0 + 1;
-constexpr size_t SORT_TEMP_FIXED = 32u << 20;  // histograms / look-back state of the device radix sort
 
 static Layout make_layout(int32_t n, int32_t width, int32_t height, int64_t max_instances) {
     Layout L{};
@@ -37,6 +40,7 @@ static Layout make_layout(int32_t n, int32_t width, int32_t height, int64_t max_
     const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
     L.tiles = gx * gy;
     L.n_blocks = (int)((N + PRE_BLOCK - 1) / PRE_BLOCK);
+    L.n_chunks = (int)((N + BIN_CHUNK - 1) / BIN_CHUNK);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes ? bytes : 1); return o; };
     L.cam = take(sizeof(CameraDev));
@@ -45,23 +49,14 @@ static Layout make_layout(int32_t n, int32_t width, int32_t height, int64_t max_
     L.depth = take(N * 4);
     L.conic_opacity = take(N * 16);
     L.rgb = take(N * 16);
-    L.tiles_touched = take(N * 4);
-    L.offsets = take(N * 4);
     L.radii = take(N * 4);
     L.rects = take(N * 8);
-    L.n_chunks = (int)((N + BIN_CHUNK - 1) / BIN_CHUNK);
     L.tile_count = take((size_t)L.tiles * 4);
     L.rel = take((size_t)L.n_chunks * L.tiles * 4);
-    L.block_sums = take((size_t)L.n_blocks * 4);
-    L.keys_unsorted = take(I * 8);
-    L.vals_unsorted = take(I * 4);
-    L.keys_sorted = take(I * 8);
-    L.vals_sorted = take(I * 4);
     L.ranges = take((size_t)L.tiles * 8);
-    L.work_order = take((size_t)L.tiles * 2 * 4);
-    L.order_classes = take(ORDER_CLASSES * 4);
-    L.sort_temp_bytes = SORT_TEMP_FIXED + I * 12;
-    L.sort_temp = take(L.sort_temp_bytes);
+    L.bucket = take(I * 8);
+    L.alt = take(I * 8);
+    L.gauss_sorted = take(I * 4);
     L.total = off;
     return L;
 }
@@ -78,31 +73,6 @@ static int check_scene(const PgrScene* s) {
     return PGR_OK;
 }
 
-}  // namespace pgr
-
-using namespace pgr;
-
-extern "C" {
-
-int32_t pgr_abi_version(void) { return PGR_ABI_VERSION; }
-const char* pgr_version(void) { return "pegasus_raster 0.1 (gfx950)"; }
-
-const char* pgr_status_string(int32_t status) {
-    switch (status) {
-        case PGR_OK: return "ok";
-        case PGR_ERR_INVALID_ARGUMENT: return "invalid argument";
-        case PGR_ERR_WORKSPACE_TOO_SMALL: return "workspace too small";
-        case PGR_ERR_INSTANCE_OVERFLOW: return "instance buffer overflow";
-        case PGR_ERR_LAUNCH_FAILURE: return "HIP launch failure";
-        case PGR_ERR_NO_DEVICE: return "no HIP device";
-        default: return "unknown status";
-    }
-}
-
-const char* pgr_last_hip_error(void) { return g_hip_error; }
-
-}  // extern "C"
-
 // Per-view slice of a workspace.
 struct ViewWs {
     CameraDev* cam;
@@ -111,14 +81,13 @@ struct ViewWs {
     float* depth;
     float4* conop;
     float4* rgbd;
-    uint32_t *tiles_touched, *offsets, *block_sums;
     int32_t* radii;   // per-view home of radii when the caller passes no radii output
     uint2* rects;
     uint32_t *tile_count, *rel;
-    uint64_t *keys_u, *keys_s;
-    uint32_t *vals_u, *vals_s;
     uint2* ranges;
-    char* sort_temp;
+    uint2* bucket;
+    uint64_t* alt;
+    uint32_t* gauss_sorted;
 };
 
 static ViewWs carve(char* ws, const Layout& L) {
@@ -129,19 +98,14 @@ static ViewWs carve(char* ws, const Layout& L) {
     v.depth = reinterpret_cast<float*>(ws + L.depth);
     v.conop = reinterpret_cast<float4*>(ws + L.conic_opacity);
     v.rgbd = reinterpret_cast<float4*>(ws + L.rgb);
-    v.tiles_touched = reinterpret_cast<uint32_t*>(ws + L.tiles_touched);
-    v.offsets = reinterpret_cast<uint32_t*>(ws + L.offsets);
     v.radii = reinterpret_cast<int32_t*>(ws + L.radii);
     v.rects = reinterpret_cast<uint2*>(ws + L.rects);
     v.tile_count = reinterpret_cast<uint32_t*>(ws + L.tile_count);
     v.rel = reinterpret_cast<uint32_t*>(ws + L.rel);
-    v.block_sums = reinterpret_cast<uint32_t*>(ws + L.block_sums);
-    v.keys_u = reinterpret_cast<uint64_t*>(ws + L.keys_unsorted);
-    v.vals_u = reinterpret_cast<uint32_t*>(ws + L.vals_unsorted);
-    v.keys_s = reinterpret_cast<uint64_t*>(ws + L.keys_sorted);
-    v.vals_s = reinterpret_cast<uint32_t*>(ws + L.vals_sorted);
     v.ranges = reinterpret_cast<uint2*>(ws + L.ranges);
-    v.sort_temp = ws + L.sort_temp;
+    v.bucket = reinterpret_cast<uint2*>(ws + L.bucket);
+    v.alt = reinterpret_cast<uint64_t*>(ws + L.alt);
+    v.gauss_sorted = reinterpret_cast<uint32_t*>(ws + L.gauss_sorted);
     return v;
 }
 
@@ -151,7 +115,7 @@ struct BatchLayout {
     size_t per_view;
 };
 
-static BatchLayout make_batch_layout(const Layout& L, int n_views, int32_t n) {
+static BatchLayout make_batch_layout(const Layout& L, int n_views) {
     BatchLayout B{};
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes ? bytes : 1); return o; };
@@ -170,6 +134,9 @@ static int check_camera(const PgrCamera* cam, const PgrOutputs* out) {
         !(cam->tanfovy > 0.f) || !cam->viewmatrix || !cam->projmatrix || !cam->campos || !cam->bg || !out->color ||
         !out->depth)
         return PGR_ERR_INVALID_ARGUMENT;
+    // tile coordinates are packed into 16 bits
+    if ((cam->image_width + TILE - 1) / TILE > 0xffff || (cam->image_height + TILE - 1) / TILE > 0xffff)
+        return PGR_ERR_INVALID_ARGUMENT;
     return PGR_OK;
 }
 
@@ -185,8 +152,7 @@ static int zero_outputs(const PgrOutputs* out, size_t P, hipStream_t stream) {
 }
 
 // The whole hot path for a batch of views of ONE scene.  All views share the image size.
-// ev: optional PGR_NUM_STAGES+1 events recorded at the stage boundaries (profiling entry point only);
-// each stage is run for every view of the batch before the next stage starts.
+// ev: optional PGR_NUM_STAGES+1 events recorded at the stage boundaries (profiling entry point only).
 static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrCamera* cams, const PgrOutputs* outs,
                                   void* workspace, size_t workspace_bytes, int64_t max_instances,
                                   int64_t* num_instances, hipStream_t stream, hipEvent_t* ev) {
@@ -211,28 +177,28 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
 
     if (!workspace) return PGR_ERR_INVALID_ARGUMENT;
     const Layout L = make_layout(N, W, H, max_instances);
-    const BatchLayout B = make_batch_layout(L, n_views, N);
+    const BatchLayout B = make_batch_layout(L, n_views);
     if (workspace_bytes < B.total) return PGR_ERR_WORKSPACE_TOO_SMALL;
     char* ws = static_cast<char*>(workspace);
     auto* view_table = reinterpret_cast<ViewEntry*>(ws + B.view_table);
+    auto* bin_table = reinterpret_cast<BinView*>(ws + B.bin_table);
     auto* classes = reinterpret_cast<uint32_t*>(ws + B.order_classes);
     auto* work_order = reinterpret_cast<uint32_t*>(ws + B.work_order);
     std::vector<ViewWs> vw((size_t)n_views);
     std::vector<ViewEntry> table((size_t)n_views);
     std::vector<BinView> bins((size_t)n_views);
-    auto* bin_table = reinterpret_cast<BinView*>(ws + B.bin_table);
     bool want_aux = false;
     for (int v = 0; v < n_views; ++v) {
         vw[v] = carve(ws + B.views + (size_t)v * B.per_view, L);
         ViewEntry& e = table[v];
         memset(&e, 0, sizeof(e));
-        e.cam = vw[v].cam; e.ranges = vw[v].ranges; e.gauss_sorted = vw[v].vals_s; e.xy = vw[v].xy;
+        e.cam = vw[v].cam; e.ranges = vw[v].ranges; e.gauss_sorted = vw[v].gauss_sorted; e.xy = vw[v].xy;
         e.conic_opacity = vw[v].conop; e.rgbd = vw[v].rgbd;
         e.out = CompOut{outs[v].color, outs[v].depth, outs[v].final_T, outs[v].n_contrib};
         e.counters = vw[v].counters;
         want_aux = want_aux || outs[v].final_T || outs[v].n_contrib;
-        bins[v] = BinView{vw[v].rects, vw[v].depth, vw[v].tile_count, vw[v].rel, vw[v].ranges, vw[v].counters,
-                          reinterpret_cast<uint2*>(vw[v].keys_u), vw[v].vals_s};
+        bins[v] = BinView{vw[v].rects, vw[v].depth, vw[v].xy, vw[v].conop, vw[v].tile_count, vw[v].rel, vw[v].ranges,
+                          vw[v].counters, vw[v].bucket, vw[v].gauss_sorted, vw[v].alt};
     }
     if (!hip_ok(hipMemcpyAsync(view_table, table.data(), table.size() * sizeof(ViewEntry), hipMemcpyHostToDevice,
                                stream), "memcpy view table") ||
@@ -246,164 +212,86 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         const PgrCamera& c = cams[v];
         pack_camera_kernel<<<1, 64, 0, stream>>>(c.viewmatrix, c.projmatrix, c.campos, c.bg, c.tanfovx, c.tanfovy, W, H,
                                                  vw[v].cam);
-        // radii is part of the per-view contract; when the caller does not want it, it lands in scratch
-        PreOut po{vw[v].xy, vw[v].depth, vw[v].conop, vw[v].rgbd, vw[v].tiles_touched, vw[v].rects,
-                  outs[v].radii ? outs[v].radii : vw[v].radii, vw[v].block_sums};
+        // radii is part of the per-view contract; when the caller does not want it, it lands in the workspace
+        PreOut po{vw[v].xy, vw[v].depth, vw[v].conop, vw[v].rgbd, vw[v].rects,
+                  outs[v].radii ? outs[v].radii : vw[v].radii};
         preprocess_kernel<<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, vw[v].cam, po);
     }
     mark(1);
-    static const int binning = [] { const char* e = getenv("PGR_BINNING"); return e ? atoi(e) : 1; }();
-    std::vector<uint32_t> h_counters((size_t)n_views * 2, 0u);
+    // ---- stage 1: per-chunk LDS tile histograms + slice reservation, then the tile scan (device only)
     const int grid_x = (W + TILE - 1) / TILE;
-    bool order_ready = false;
-    if (binning == 1) {
-        // ---- stage 1: per-chunk LDS tile histograms + slice reservation, then the tile scan (device only)
-        const size_t lds = (size_t)std::min(L.tiles, BIN_LDS_TILES) * 4;
-        for (int v = 0; v < n_views; ++v)
-            if (!hip_ok(hipMemsetAsync(vw[v].tile_count, 0, (size_t)L.tiles * 4, stream), "memset tile_count"))
-                return PGR_ERR_LAUNCH_FAILURE;
-        bin_count_kernel<<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(bin_table, N, grid_x, L.tiles);
-        tile_scan_kernel<<<n_views, 1024, 0, stream>>>(bin_table, L.tiles, (uint32_t)max_instances);
-        mark(2);
-        // ---- stage 2: scatter (depth bits, index) into the tiles' slices
-        bin_scatter_kernel<<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(bin_table, N, grid_x, L.tiles);
-        mark(3);
-        // ---- stage 3: per-tile (depth, index) sort, longest lists first
-        if (!hip_ok(hipMemsetAsync(classes, 0, ORDER_CLASSES * 4, stream), "memset classes"))
+    const size_t lds = (size_t)std::min(L.tiles, BIN_LDS_TILES) * 4;
+    for (int v = 0; v < n_views; ++v)
+        if (!hip_ok(hipMemsetAsync(vw[v].tile_count, 0, (size_t)L.tiles * 4, stream), "memset tile_count"))
             return PGR_ERR_LAUNCH_FAILURE;
-        const dim3 og((L.tiles + 255) / 256, n_views);
-        order_count_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, classes);
-        order_scan_kernel<<<1, ORDER_CLASSES, 0, stream>>>(classes, LONG_LIST_CLASS);
-        order_scatter_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, classes, work_order);
-        order_ready = true;
-        tile_sort_large_kernel<<<std::min(n_views * L.tiles, 1024), SORT_LARGE_THREADS, 0, stream>>>(
-            bin_table, L.tiles, work_order, classes + ORDER_CLASSES);
-        tile_sort_kernel<<<n_views * L.tiles, SORT_THREADS, 0, stream>>>(bin_table, L.tiles, work_order);
-        mark(4);
-        mark(5);
-    } else {
-        // ---- stage 1: offset scan; the host reads the instance counts ONCE per batch (the reference
-        // reads num_rendered once per view), sizing the sorts and reporting overflow instead of rendering it.
-        for (int v = 0; v < n_views; ++v)
-            scan_block_sums_kernel<<<1, SCAN_THREADS, 0, stream>>>(vw[v].block_sums, L.n_blocks, vw[v].counters,
-                                                                   (uint32_t)max_instances);
-        for (int v = 0; v < n_views; ++v)
-            if (!hip_ok(hipMemcpyAsync(&h_counters[2 * v], vw[v].counters, 8, hipMemcpyDeviceToHost, stream), "memcpy"))
-                return PGR_ERR_LAUNCH_FAILURE;
-        if (!hip_ok(hipStreamSynchronize(stream), "sync after scan")) return PGR_ERR_LAUNCH_FAILURE;
-        bool overflow = false;
-        for (int v = 0; v < n_views; ++v) {
-            if (num_instances) num_instances[v] = (int64_t)h_counters[2 * v];
-            overflow = overflow || h_counters[2 * v + 1] || (int64_t)h_counters[2 * v] > max_instances;
-        }
-        if (overflow) return PGR_ERR_INSTANCE_OVERFLOW;
-        mark(2);
-        // ---- stage 2: (tile, depth) instance emission
-        for (int v = 0; v < n_views; ++v) {
-            if (!hip_ok(hipMemsetAsync(vw[v].ranges, 0, (size_t)L.tiles * sizeof(uint2), stream), "memset ranges"))
-                return PGR_ERR_LAUNCH_FAILURE;
-            emit_kernel<<<L.n_blocks, PRE_BLOCK, 0, stream>>>(N, vw[v].cam, vw[v].xy, vw[v].depth,
-                                                              outs[v].radii ? outs[v].radii : vw[v].radii,
-                                                              vw[v].tiles_touched, vw[v].block_sums, vw[v].counters,
-                                                              vw[v].offsets, vw[v].keys_u, vw[v].vals_u);
-        }
-        mark(3);
-        // ---- stage 3: stable sort by (tile, depth bits)
-        int tbits = 0;
-        while ((1 << tbits) < L.tiles) ++tbits;
-        for (int v = 0; v < n_views; ++v) {
-            const size_t total = h_counters[2 * v];
-            if (total == 0) continue;
-            size_t temp_bytes = 0;
-            if (!hip_ok(rocprim::radix_sort_pairs(nullptr, temp_bytes, vw[v].keys_u, vw[v].keys_s, vw[v].vals_u,
-                                                  vw[v].vals_s, total, 0u, (unsigned)(32 + tbits), stream),
-                        "radix_sort size query"))
-                return PGR_ERR_LAUNCH_FAILURE;
-            if (temp_bytes > L.sort_temp_bytes) return PGR_ERR_WORKSPACE_TOO_SMALL;
-            if (!hip_ok(rocprim::radix_sort_pairs(vw[v].sort_temp, temp_bytes, vw[v].keys_u, vw[v].keys_s, vw[v].vals_u,
-                                                  vw[v].vals_s, total, 0u, (unsigned)(32 + tbits), stream),
-                        "radix_sort_pairs"))
-                return PGR_ERR_LAUNCH_FAILURE;
-        }
-        mark(4);
-        // ---- stage 4: tile ranges
-        for (int v = 0; v < n_views; ++v) {
-            const uint32_t total = h_counters[2 * v];
-            if (total)
-                tile_ranges_kernel<<<(total + 255) / 256, 256, 0, stream>>>(vw[v].counters, vw[v].keys_s, vw[v].ranges);
-        }
-        mark(5);
-    }
-    // ---- stage 5: compositing of every (view, tile, half) work item in ONE launch, longest lists first
-    static const int variant = [] { const char* e = getenv("PGR_COMPOSITE"); return e ? atoi(e) : 2; }();
-    if (variant == 0) {
-        for (int v = 0; v < n_views; ++v)
-            composite_kernel<<<L.tiles, COMP_THREADS, 0, stream>>>(vw[v].cam, vw[v].ranges, vw[v].vals_s, vw[v].xy,
-                                                                   vw[v].conop, vw[v].rgbd, table[v].out);
-    } else {
-        const uint32_t* order = nullptr;
-        if (variant == 2 && order_ready) {
-            order = work_order;
-        } else if (variant == 2) {
-            if (!hip_ok(hipMemsetAsync(classes, 0, ORDER_CLASSES * 4, stream), "memset classes"))
-                return PGR_ERR_LAUNCH_FAILURE;
-            const dim3 og((L.tiles + 255) / 256, n_views);
-            order_count_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, classes);
-            order_scan_kernel<<<1, ORDER_CLASSES, 0, stream>>>(classes, LONG_LIST_CLASS);
-            order_scatter_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, classes, work_order);
-            order = work_order;
-        }
-        const uint32_t items_per_view = 2u * (uint32_t)L.tiles;
-        const uint32_t items = items_per_view * (uint32_t)n_views;
-        if (want_aux)
-            composite_wave_kernel<true><<<items, WAVE, 0, stream>>>(view_table, items_per_view, order);
-        else
-            composite_wave_kernel<false><<<items, WAVE, 0, stream>>>(view_table, items_per_view, order);
-    }
-    mark(6);
+    bin_kernel<false><<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(bin_table, N, grid_x, L.tiles, W, H);
+    tile_scan_kernel<<<n_views, 1024, 0, stream>>>(bin_table, L.tiles, (uint32_t)max_instances);
+    mark(2);
+    // ---- stage 2: scatter (depth bits, index) into the tiles' slices
+    bin_kernel<true><<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(bin_table, N, grid_x, L.tiles, W, H);
+    mark(3);
+    // ---- stage 3: work order (longest lists first) + per-tile (depth, index) sort
+    if (!hip_ok(hipMemsetAsync(classes, 0, (ORDER_CLASSES + 1) * 4, stream), "memset classes"))
+        return PGR_ERR_LAUNCH_FAILURE;
+    const dim3 og((L.tiles + 255) / 256, n_views);
+    order_count_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, classes);
+    order_scan_kernel<<<1, ORDER_CLASSES, 0, stream>>>(classes, LONG_LIST_CLASS);
+    order_scatter_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, classes, work_order);
+    tile_sort_large_kernel<<<std::min(n_views * L.tiles, 1024), SORT_LARGE_THREADS, 0, stream>>>(
+        bin_table, L.tiles, work_order, classes + ORDER_CLASSES);
+    tile_sort_kernel<<<n_views * L.tiles, SORT_THREADS, 0, stream>>>(bin_table, L.tiles, work_order);
+    mark(4);
+    // ---- stage 4: compositing of every (view, tile, half) work item in ONE launch, longest lists first
+    const uint32_t items_per_view = 2u * (uint32_t)L.tiles;
+    const uint32_t items = items_per_view * (uint32_t)n_views;
+    if (want_aux)
+        composite_wave_kernel<true><<<items, WAVE, 0, stream>>>(view_table, items_per_view, work_order);
+    else
+        composite_wave_kernel<false><<<items, WAVE, 0, stream>>>(view_table, items_per_view, work_order);
+    mark(5);
     if (!hip_ok(hipGetLastError(), "kernel launch")) return PGR_ERR_LAUNCH_FAILURE;
-    if (binning == 1) {
-        // the only host read of the batch: instance counts + overflow flags, after everything is enqueued
-        for (int v = 0; v < n_views; ++v)
-            if (!hip_ok(hipMemcpyAsync(&h_counters[2 * v], vw[v].counters, 8, hipMemcpyDeviceToHost, stream), "memcpy"))
-                return PGR_ERR_LAUNCH_FAILURE;
-        if (!hip_ok(hipStreamSynchronize(stream), "sync at batch end")) return PGR_ERR_LAUNCH_FAILURE;
-        bool overflow = false;
-        for (int v = 0; v < n_views; ++v) {
-            if (num_instances) num_instances[v] = (int64_t)h_counters[2 * v];
-            overflow = overflow || h_counters[2 * v + 1];
-        }
-        if (overflow) return PGR_ERR_INSTANCE_OVERFLOW;
+
+    // the only host read of the batch: instance counts + overflow flags, after everything is enqueued
+    std::vector<uint32_t> h_counters((size_t)n_views * 2, 0u);
+    for (int v = 0; v < n_views; ++v)
+        if (!hip_ok(hipMemcpyAsync(&h_counters[2 * v], vw[v].counters, 8, hipMemcpyDeviceToHost, stream), "memcpy"))
+            return PGR_ERR_LAUNCH_FAILURE;
+    if (!hip_ok(hipStreamSynchronize(stream), "sync at batch end")) return PGR_ERR_LAUNCH_FAILURE;
+    bool overflow = false;
+    for (int v = 0; v < n_views; ++v) {
+        if (num_instances) num_instances[v] = (int64_t)h_counters[2 * v];
+        overflow = overflow || h_counters[2 * v + 1];
     }
-    return PGR_OK;
+    return overflow ? PGR_ERR_INSTANCE_OVERFLOW : PGR_OK;
 }
 
-static int32_t profiled(const PgrScene* scene, int n_views, const PgrCamera* cams, const PgrOutputs* outs,
-                        void* workspace, size_t workspace_bytes, int64_t max_instances, int64_t* num_instances,
-                        hipStream_t stream, float* stage_ms) {
-    if (!stage_ms) return PGR_ERR_INVALID_ARGUMENT;
-    hipEvent_t ev[PGR_NUM_STAGES + 1];
-    for (auto& e : ev)
-        if (!hip_ok(hipEventCreate(&e), "hipEventCreate")) return PGR_ERR_LAUNCH_FAILURE;
-    for (int k = 0; k < PGR_NUM_STAGES; ++k) stage_ms[k] = 0.f;
-    int32_t rc = forward_batch_impl(scene, n_views, cams, outs, workspace, workspace_bytes, max_instances,
-                                    num_instances, stream, ev);
-    if (rc == PGR_OK && scene->n > 0) {
-        if (!hip_ok(hipStreamSynchronize(stream), "sync")) rc = PGR_ERR_LAUNCH_FAILURE;
-        for (int k = 0; rc == PGR_OK && k < PGR_NUM_STAGES; ++k)
-            if (!hip_ok(hipEventElapsedTime(&stage_ms[k], ev[k], ev[k + 1]), "hipEventElapsedTime"))
-                rc = PGR_ERR_LAUNCH_FAILURE;
-    }
-    for (auto& e : ev) (void)hipEventDestroy(e);
-    return rc;
-}
+}  // namespace pgr
+
+using namespace pgr;
 
 extern "C" {
+
+int32_t pgr_abi_version(void) { return PGR_ABI_VERSION; }
+const char* pgr_version(void) { return "pegasus_raster 0.2 (gfx950)"; }
+
+const char* pgr_status_string(int32_t status) {
+    switch (status) {
+        case PGR_OK: return "ok";
+        case PGR_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case PGR_ERR_WORKSPACE_TOO_SMALL: return "workspace too small";
+        case PGR_ERR_INSTANCE_OVERFLOW: return "instance buffer overflow";
+        case PGR_ERR_LAUNCH_FAILURE: return "HIP launch failure";
+        case PGR_ERR_NO_DEVICE: return "no HIP device";
+        default: return "unknown status";
+    }
+}
+
+const char* pgr_last_hip_error(void) { return g_hip_error; }
 
 size_t pgr_batch_workspace_bytes(int32_t n, int32_t width, int32_t height, int64_t max_instances, int32_t n_views) {
     if (n < 0 || width <= 0 || height <= 0 || max_instances < 0 || max_instances > 0x7fffffffLL || n_views <= 0)
         return 0;
-    return make_batch_layout(make_layout(n, width, height, max_instances), n_views, n).total;
+    return make_batch_layout(make_layout(n, width, height, max_instances), n_views).total;
 }
 
 size_t pgr_workspace_bytes(int32_t n, int32_t width, int32_t height, int64_t max_instances) {
@@ -416,17 +304,15 @@ int32_t pgr_workspace_view(void* workspace, size_t workspace_bytes, int32_t n, i
         view_index < 0 || view_index >= n_views)
         return PGR_ERR_INVALID_ARGUMENT;
     const Layout L = make_layout(n, width, height, max_instances);
-    const BatchLayout B = make_batch_layout(L, n_views, n);
+    const BatchLayout B = make_batch_layout(L, n_views);
     if (workspace_bytes < B.total) return PGR_ERR_WORKSPACE_TOO_SMALL;
     const ViewWs w = carve(static_cast<char*>(workspace) + B.views + (size_t)view_index * B.per_view, L);
     v->xy = reinterpret_cast<const float*>(w.xy);
     v->depth = w.depth;
     v->conic_opacity = reinterpret_cast<const float*>(w.conop);
     v->rgb = reinterpret_cast<const float*>(w.rgbd);
-    v->tiles_touched = w.tiles_touched;
-    v->offsets = w.offsets;
-    v->keys_sorted = w.keys_s;
-    v->gauss_sorted = w.vals_s;
+    v->rects = reinterpret_cast<const uint16_t*>(w.rects);
+    v->gauss_sorted = w.gauss_sorted;
     v->ranges = reinterpret_cast<const uint32_t*>(w.ranges);
     v->num_instances = w.counters;
     return PGR_OK;
@@ -450,8 +336,21 @@ int32_t pgr_forward_batch_profiled(const PgrScene* scene, int32_t n_views, const
                                    const PgrOutputs* outs, void* workspace, size_t workspace_bytes,
                                    int64_t max_instances_per_view, int64_t* num_instances, void* stream_v,
                                    float* stage_ms) {
-    return profiled(scene, n_views, cameras, outs, workspace, workspace_bytes, max_instances_per_view, num_instances,
-                    static_cast<hipStream_t>(stream_v), stage_ms);
+    if (!stage_ms) return PGR_ERR_INVALID_ARGUMENT;
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    hipEvent_t ev[PGR_NUM_STAGES + 1];
+    for (auto& e : ev)
+        if (!hip_ok(hipEventCreate(&e), "hipEventCreate")) return PGR_ERR_LAUNCH_FAILURE;
+    for (int k = 0; k < PGR_NUM_STAGES; ++k) stage_ms[k] = 0.f;
+    int32_t rc = forward_batch_impl(scene, n_views, cameras, outs, workspace, workspace_bytes, max_instances_per_view,
+                                    num_instances, stream, ev);
+    if (rc == PGR_OK && scene->n > 0) {
+        for (int k = 0; rc == PGR_OK && k < PGR_NUM_STAGES; ++k)
+            if (!hip_ok(hipEventElapsedTime(&stage_ms[k], ev[k], ev[k + 1]), "hipEventElapsedTime"))
+                rc = PGR_ERR_LAUNCH_FAILURE;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
 }
 
 int32_t pgr_mark_visible(int32_t n, const float* means3d, const float* viewmatrix, uint8_t* present, void* stream_v) {

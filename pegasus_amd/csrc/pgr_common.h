@@ -34,9 +34,8 @@ static_assert(sizeof(CameraDev) == 256, "CameraDev must be 256 B");
 
 // Workspace carve-up (all offsets multiples of 256 B).
 struct Layout {
-    size_t cam, counters, xy, depth, conic_opacity, rgb, tiles_touched, offsets, radii, rects, tile_count, rel, block_sums,
-        keys_unsorted, vals_unsorted, keys_sorted, vals_sorted, ranges, work_order, order_classes, sort_temp, total;
-    size_t sort_temp_bytes;
+    size_t cam, counters, xy, depth, conic_opacity, rgb, radii, rects, tile_count, rel, ranges, bucket, alt,
+        gauss_sorted, total;
     int32_t tiles;
     int32_t n_blocks;
     int32_t n_chunks;

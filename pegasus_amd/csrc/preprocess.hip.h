@@ -8,7 +8,7 @@
 //
 // HBM-bound: reads 12 B (xyz) for every Gaussian, +28 B (scale, rotation) for the ones in front of
 // the near plane, +196 B (opacity, 48 SH floats) for the ones whose tile rectangle is non-empty;
-// writes 4+4 B (radius, tiles_touched) for every Gaussian and 44 B for survivors.
+// writes 4+8 B (radius, packed rectangle) for every Gaussian and 44 B for survivors.
 #pragma once
 #include "pgr_common.h"
 
@@ -124,17 +124,14 @@ struct PreOut {
     float* depth;
     float4* conic_opacity;
     float4* rgb;             // (r,g,b,depth)
-    uint32_t* tiles_touched;
-    uint2* rects;            // packed tile rectangle (4 x uint16), all zero when culled
+    uint2* rects;            // packed tile rectangle (4 x uint16: minx,miny,maxx,maxy), all zero when culled
     int32_t* radii;
-    uint32_t* block_sums;    // [gridDim.x] sum of tiles_touched per workgroup
 };
 
 __global__ __launch_bounds__(PRE_BLOCK) void preprocess_kernel(PgrScene sc, const CameraDev* __restrict__ camp,
                                                                PreOut o) {
     const CameraDev& cam = *camp;
     const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
-    uint32_t touched = 0;
     int radius = 0;
     uint2 rect = make_uint2(0u, 0u);
 
@@ -218,7 +215,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_kernel(PgrScene sc, cons
                         }
                     }
                     radius = rad;
-                    touched = (uint32_t)(w * h);
                     rect = make_uint2((uint32_t)r.minx | ((uint32_t)r.miny << 16),
                                       (uint32_t)r.maxx | ((uint32_t)r.maxy << 16));
                     o.xy[i] = make_float2(pix_x, pix_y);
@@ -229,23 +225,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_kernel(PgrScene sc, cons
             }
         }
         o.radii[i] = radius;
-        o.tiles_touched[i] = touched;
         o.rects[i] = rect;
     }
 
-    // workgroup sum of tiles_touched -> block_sums (feeds the offset scan without re-reading HBM)
-    uint32_t s = touched;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, WAVE);
-    __shared__ uint32_t wave_sums[PRE_BLOCK / WAVE];
-    if ((threadIdx.x & (WAVE - 1)) == 0) wave_sums[threadIdx.x / WAVE] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-#pragma unroll
-        for (int w = 0; w < PRE_BLOCK / WAVE; ++w) t += wave_sums[w];
-        o.block_sums[blockIdx.x] = t;
-    }
 }
 
 // packs the caller's four device-side camera tensors + host scalars into one CameraDev

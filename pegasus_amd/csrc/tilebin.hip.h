@@ -1,7 +1,8 @@
 // tilebin.hip.h -- sync-free tile binning for gfx950: (Gaussian, tile) instances -> per-tile lists
 // sorted by (depth bits, Gaussian index).  Replaces SURVEY.md section 8a rows a6-a9 (scan, emission,
 // global 44-bit radix sort, range search) of the reference design with a layout that never leaves the
-// chip's fast paths:
+// chip's fast paths.  Only instances that can reach alpha >= 1/255 somewhere in their tile are listed
+// (tile_may_contribute below): the images are unchanged, the lists are ~1.7x shorter.
 //
 //   bin_count    one workgroup per CHUNK of Gaussians: tile histogram in LDS (LDS atomics), then ONE
 //                coalesced global atomicAdd per (chunk, touched tile) that both accumulates the tile
@@ -37,39 +38,149 @@ __device__ __forceinline__ uint2 pack_rect(int minx, int miny, int maxx, int max
 struct BinView {                 // per-view pointers used by the binning kernels (device table)
     const uint2* rects;          // [n] packed tile rectangles
     const float* depth;          // [n]
+    const float2* xy;            // [n]
+    const float4* conic_opacity; // [n]
     uint32_t* tile_count;        // [tiles] zero-filled before bin_count
     uint32_t* rel;               // [chunks, tiles]
     uint2* ranges;               // [tiles]
     uint32_t* counters;          // [0] total instances, [1] overflow flag
     uint2* bucket;               // [max_instances] (depth bits, index), unsorted per tile
     uint32_t* gauss_sorted;      // [max_instances]
+    uint64_t* alt;               // [max_instances] second key buffer for lists beyond the LDS tiers
 };
 
-__global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(const BinView* __restrict__ views, int n, int grid_x,
-                                                                int tiles) {
-    extern __shared__ uint32_t hist[];
+
+// ---- tight-list predicate ----------------------------------------------------------------------
+// A (Gaussian, tile) instance only matters if alpha = min(0.99, op*exp(power)) >= 1/255 at some pixel of the
+// tile.  With q = A dx^2 + 2B dx dy + C dy^2 (power = -q/2) that needs q <= 2 ln(255 op) somewhere.  The
+// test bounds q from BELOW over the tile's continuous pixel rectangle (0 if the centre is inside, else the
+// smallest of the four edge minima of the convex form) and 2 ln(255 op) from ABOVE (exponent + chord of
+// log2 on the mantissa + 0.0861), adds a rounding margin, and keeps the instance unless the lower bound
+// clears the upper bound.  Dropped instances would be skipped at every pixel, so no pixel's arithmetic
+// changes (oracle: pgr_oracle_tile_may_contribute, same operation order, bit-identical decisions; measured
+// on the C3 scene: 55-63 % of the 3-sigma-rectangle instances survive).
+__device__ __forceinline__ float edge_min_q(float A, float B, float C, float r, float d_fixed, float lo, float hi) {
+    // minimise over t in [lo,hi]:  A*d^2 + 2*B*d*t + C*t^2   with r = B / C precomputed per Gaussian
+    float t = -(d_fixed * r);
+    t = fminf(hi, fmaxf(lo, t));
+    return A * d_fixed * d_fixed + 2.0f * B * d_fixed * t + C * t * t;
+}
+
+struct CullSplat { float mx, my, A, B, C, rBC, rBA, tau; uint32_t flags; };   // flags: 1 = never, 2 = always
+
+__device__ __forceinline__ CullSplat make_cull_splat(float2 xy, float4 co) {
+    CullSplat s;
+    s.mx = xy.x; s.my = xy.y; s.A = co.x; s.B = co.y; s.C = co.z;
+    s.flags = (co.w < ALPHA_MIN ? 1u : 0u)                      // alpha <= op < 1/255 at every pixel, exactly
+            | ((!(co.x > 0.0f) || !(co.z > 0.0f)) ? 2u : 0u);   // degenerate conic: no claim
+    s.rBC = co.y / co.z;
+    s.rBA = co.y / co.x;
+    const float t = 255.0f * co.w;
+    const uint32_t bits = __float_as_uint(t);
+    const float e = (float)((int)((bits >> 23) & 0xffu) - 127);
+    const float m = __uint_as_float((bits & 0x007fffffu) | 0x3f800000u);
+    s.tau = 1.3862944f * (e + (m - 1.0f) + 0.0861f);
+    return s;
+}
+
+__device__ __forceinline__ bool tile_may_contribute(const CullSplat& s, int tx, int ty, int W, int H) {
+    if (s.flags & 1u) return false;
+    if (s.flags & 2u) return true;
+    const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
+    const float x1 = fminf(x0 + (float)(TILE - 1), (float)(W - 1));
+    const float y1 = fminf(y0 + (float)(TILE - 1), (float)(H - 1));
+    if (s.mx >= x0 && s.mx <= x1 && s.my >= y0 && s.my <= y1) return true;
+    const float dx0 = x0 - s.mx, dx1 = x1 - s.mx, dy0 = y0 - s.my, dy1 = y1 - s.my;
+    float q = edge_min_q(s.A, s.B, s.C, s.rBC, dx0, dy0, dy1);
+    q = fminf(q, edge_min_q(s.A, s.B, s.C, s.rBC, dx1, dy0, dy1));
+    q = fminf(q, edge_min_q(s.C, s.B, s.A, s.rBA, dy0, dx0, dx1));
+    q = fminf(q, edge_min_q(s.C, s.B, s.A, s.rBA, dy1, dx0, dx1));
+    const float DX = fmaxf(fabsf(dx0), fabsf(dx1)), DY = fmaxf(fabsf(dy0), fabsf(dy1));
+    const float M = s.A * DX * DX + 2.0f * fabsf(s.B) * DX * DY + s.C * DY * DY;
+    return !(q > s.tau + 0.00001f * M + 0.01f);       // a NaN anywhere keeps the instance
+}
+
+// Both binning passes walk the same candidate space: every tile of every Gaussian's rectangle.  Rectangle
+// areas vary from 1 to hundreds of tiles, so a loop per Gaussian leaves most lanes idle (measured 6x on
+// MI355X).  Instead each wave takes 64 Gaussians, prefix-sums their areas, and its lanes sweep the
+// FLATTENED candidate index space 64 at a time: lane -> candidate c -> owning Gaussian g (binary search
+// over the wave's exclusive prefix with ds_bpermute) -> tile (x,y) of g's rectangle.  Every lane evaluates
+// exactly one candidate per iteration.
+//   SCATTER = false: lds[] = tile histogram; flushed with one coalesced reserving atomic per touched tile.
+//   SCATTER = true : lds[] = write cursors (range start + this chunk's reserved offset).
+template <bool SCATTER>
+__global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restrict__ views, int n, int grid_x,
+                                                          int tiles, int W, int H) {
+    extern __shared__ uint32_t lds[];
     const BinView& bv = views[blockIdx.y];
+    if (SCATTER && bv.counters[1]) return;   // overflow: reported by the host, nothing may be written past the buffers
     const int chunk = blockIdx.x;
     const int begin = chunk * BIN_CHUNK, end = min(n, begin + BIN_CHUNK);
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
     for (int lo = 0; lo < tiles; lo += BIN_LDS_TILES) {
         const int span = min(BIN_LDS_TILES, tiles - lo);
-        for (int t = threadIdx.x; t < span; t += BIN_THREADS) hist[t] = 0;
+        for (int t = threadIdx.x; t < span; t += BIN_THREADS)
+            lds[t] = SCATTER ? bv.ranges[lo + t].x + bv.rel[(size_t)chunk * tiles + lo + t] : 0u;
         __syncthreads();
-        for (int i = begin + threadIdx.x; i < end; i += BIN_THREADS) {
-            const uint2 r = bv.rects[i];
-            const int minx = r.x & 0xffff, miny = r.x >> 16, maxx = r.y & 0xffff, maxy = r.y >> 16;
-            for (int y = miny; y < maxy; ++y)
-                for (int x = minx; x < maxx; ++x) {
-                    const int t = y * grid_x + x - lo;
-                    if ((unsigned)t < (unsigned)span) atomicAdd(&hist[t], 1u);
+        for (int base = begin + wave * WAVE; base < end; base += BIN_THREADS) {
+            const int i = base + lane;
+            uint2 r = make_uint2(0u, 0u);
+            int area = 0;
+            CullSplat cs = {};
+            uint32_t dbits = 0;
+            if (i < end) {
+                r = bv.rects[i];
+                const int w = (int)(r.y & 0xffff) - (int)(r.x & 0xffff), h = (int)(r.y >> 16) - (int)(r.x >> 16);
+                if (w > 0 && h > 0) {
+                    area = w * h;
+                    cs = make_cull_splat(bv.xy[i], bv.conic_opacity[i]);
+                    if (SCATTER) dbits = __float_as_uint(bv.depth[i]);
                 }
+            }
+            int incl = area;
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) {
+                const int t = __shfl_up(incl, d, WAVE);
+                if (lane >= d) incl += t;
+            }
+            const int excl = incl - area;
+            const int total = __shfl(incl, WAVE - 1, WAVE);
+            for (int c0 = 0; c0 < total; c0 += WAVE) {
+                const int c = c0 + lane;
+                int g = 0;   // largest lane whose exclusive prefix is <= c
+#pragma unroll
+                for (int step = WAVE / 2; step >= 1; step >>= 1) {
+                    const int cand = g + step;
+                    const int e = __shfl(excl, cand & (WAVE - 1), WAVE);
+                    if (cand < WAVE && e <= c) g = cand;
+                }
+                const int k = c - __shfl(excl, g, WAVE);
+                const uint32_t rlo = __shfl(r.x, g, WAVE), rhi = __shfl(r.y, g, WAVE);
+                CullSplat s;
+                s.mx = __shfl(cs.mx, g, WAVE); s.my = __shfl(cs.my, g, WAVE);
+                s.A = __shfl(cs.A, g, WAVE); s.B = __shfl(cs.B, g, WAVE); s.C = __shfl(cs.C, g, WAVE);
+                s.rBC = __shfl(cs.rBC, g, WAVE); s.rBA = __shfl(cs.rBA, g, WAVE);
+                s.tau = __shfl(cs.tau, g, WAVE); s.flags = __shfl(cs.flags, g, WAVE);
+                const uint32_t db = SCATTER ? __shfl(dbits, g, WAVE) : 0u;
+                const int minx = (int)(rlo & 0xffff), miny = (int)(rlo >> 16);
+                const int w = max((int)(rhi & 0xffff) - minx, 1);
+                const int ty = k / w, tx = k - ty * w;
+                const int x = minx + tx, y = miny + ty;
+                const int t = y * grid_x + x - lo;
+                if (c < total && (unsigned)t < (unsigned)span && tile_may_contribute(s, x, y, W, H)) {
+                    const uint32_t slot = atomicAdd(&lds[t], 1u);
+                    if (SCATTER) bv.bucket[slot] = make_uint2(db, (uint32_t)(base + g));
+                }
+            }
         }
         __syncthreads();
-        for (int t = threadIdx.x; t < span; t += BIN_THREADS) {
-            const uint32_t c = hist[t];
-            bv.rel[(size_t)chunk * tiles + lo + t] = c ? atomicAdd(&bv.tile_count[lo + t], c) : 0u;
+        if (!SCATTER) {
+            for (int t = threadIdx.x; t < span; t += BIN_THREADS) {
+                const uint32_t cnt = lds[t];
+                bv.rel[(size_t)chunk * tiles + lo + t] = cnt ? atomicAdd(&bv.tile_count[lo + t], cnt) : 0u;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
@@ -105,36 +216,6 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const BinView* __restri
     if (threadIdx.x == 0) {
         bv.counters[0] = carry_s;
         bv.counters[1] = carry_s > max_instances ? 1u : 0u;
-    }
-}
-
-__global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(const BinView* __restrict__ views, int n, int grid_x,
-                                                                  int tiles) {
-    extern __shared__ uint32_t cursor[];
-    const BinView& bv = views[blockIdx.y];
-    if (bv.counters[1]) return;   // overflow: reported by the host, nothing may be written past the buffers
-    const int chunk = blockIdx.x;
-    const int begin = chunk * BIN_CHUNK, end = min(n, begin + BIN_CHUNK);
-    for (int lo = 0; lo < tiles; lo += BIN_LDS_TILES) {
-        const int span = min(BIN_LDS_TILES, tiles - lo);
-        for (int t = threadIdx.x; t < span; t += BIN_THREADS)
-            cursor[t] = bv.ranges[lo + t].x + bv.rel[(size_t)chunk * tiles + lo + t];
-        __syncthreads();
-        for (int i = begin + threadIdx.x; i < end; i += BIN_THREADS) {
-            const uint2 r = bv.rects[i];
-            const int minx = r.x & 0xffff, miny = r.x >> 16, maxx = r.y & 0xffff, maxy = r.y >> 16;
-            if (maxx <= minx || maxy <= miny) continue;
-            const uint32_t dbits = __float_as_uint(bv.depth[i]);
-            for (int y = miny; y < maxy; ++y)
-                for (int x = minx; x < maxx; ++x) {
-                    const int t = y * grid_x + x - lo;
-                    if ((unsigned)t < (unsigned)span) {
-                        const uint32_t slot = atomicAdd(&cursor[t], 1u);
-                        bv.bucket[slot] = make_uint2(dbits, (uint32_t)i);
-                    }
-                }
-        }
-        __syncthreads();
     }
 }
 
@@ -191,7 +272,7 @@ __device__ __forceinline__ int pad_idx(int i) {
 // skeys must hold THREADS*(E+1) keys.
 template <int THREADS, int E>
 __device__ __forceinline__ void merge_sort_tile(uint64_t* __restrict__ skeys, const uint2* __restrict__ bucket,
-                                                uint32_t* __restrict__ out, int n) {
+                                                uint32_t* __restrict__ out, int n, uint64_t* keys_out = nullptr) {
     const int t = threadIdx.x;
     uint64_t r[E];
     // the list is unordered, so WHICH keys a thread starts with is free: take them coalesced
@@ -238,35 +319,38 @@ __device__ __forceinline__ void merge_sort_tile(uint64_t* __restrict__ skeys, co
         for (int e = 0; e < E; ++e) skeys[t * (E + 1) + e] = r[e];
         __syncthreads();
     }
-    for (int i = t; i < n; i += THREADS) out[i] = (uint32_t)skeys[pad_idx<E>(i)];
+    if (keys_out) {
+        for (int i = t; i < n; i += THREADS) keys_out[i] = skeys[pad_idx<E>(i)];
+    } else {
+        for (int i = t; i < n; i += THREADS) out[i] = (uint32_t)skeys[pad_idx<E>(i)];
+    }
 }
 
-// All-ascending bitonic network on n keys padded virtually to npad (a power of two) with +inf: a
-// compare-exchange whose upper index is >= n is a no-op.  Only used, in place in global memory
-// (L2-resident), for lists that exceed the LDS tiers.
-__device__ __forceinline__ void bitonic_sort_global(uint64_t* keys, int n, int npad, int nthreads) {
-    const int half = npad >> 1;
-    for (int k = 2, lk = 1; k <= npad; k <<= 1, ++lk) {
-        const int hk = k >> 1;
-        for (int p = threadIdx.x; p < half; p += nthreads) {
-            const int blk = p >> (lk - 1), off = p & (hk - 1);
-            const int i = blk * k + off, j = blk * k + (k - 1 - off);
-            if (j < n) {
-                const uint64_t a = keys[i], b = keys[j];
-                if (a > b) { keys[i] = b; keys[j] = a; }
-            }
+// One merge round over sorted runs of length `run` held in global memory (L2-resident): src -> dst.
+// Each thread produces G consecutive outputs per step; co-ranking by binary search as in the LDS rounds.
+template <int THREADS, int G>
+__device__ __forceinline__ void merge_round_global(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, int n,
+                                                   int run) {
+    const int segments = (n + G - 1) / G;
+    for (int seg = threadIdx.x; seg < segments; seg += THREADS) {
+        const int o_glob = seg * G;
+        const int a0 = o_glob / (2 * run) * (2 * run), b0 = a0 + run;
+        const int lenA = min(run, n - a0), lenB = max(0, min(run, n - b0));
+        const int o = o_glob - a0;
+        int lo = o > lenB ? o - lenB : 0, hi = o < lenA ? o : lenA;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (src[a0 + mid - 1] <= src[b0 + o - mid]) lo = mid; else hi = mid - 1;
         }
-        __syncthreads();
-        for (int s = k >> 2, ls = lk - 2; s >= 1; s >>= 1, --ls) {
-            for (int p = threadIdx.x; p < half; p += nthreads) {
-                const int blk = p >> ls, off = p & (s - 1);
-                const int i = blk * 2 * s + off, j = i + s;
-                if (j < n) {
-                    const uint64_t a = keys[i], b = keys[j];
-                    if (a > b) { keys[i] = b; keys[j] = a; }
-                }
-            }
-            __syncthreads();
+        int i = lo, j = o - lo;
+        uint64_t av = i < lenA ? src[a0 + i] : KEY_INF;
+        uint64_t bv = j < lenB ? src[b0 + j] : KEY_INF;
+        const int cnt = min(G, n - o_glob);
+        for (int e = 0; e < cnt; ++e) {
+            const bool takeA = (j >= lenB) || (i < lenA && av <= bv);
+            dst[o_glob + e] = takeA ? av : bv;
+            if (takeA) { ++i; av = i < lenA ? src[a0 + i] : KEY_INF; }
+            else       { ++j; bv = j < lenB ? src[b0 + j] : KEY_INF; }
         }
     }
 }
@@ -277,7 +361,8 @@ constexpr int SORT_LARGE_MAX = SORT_LARGE_THREADS * 16; // 16384 keys, 136 KiB L
 
 __device__ __forceinline__ bool sort_item(const BinView* __restrict__ views, int tiles,
                                           const uint32_t* __restrict__ work_order, uint32_t index,
-                                          const uint2*& bucket, uint32_t*& out, int& n) {
+                                          const uint2*& bucket, uint32_t*& out, int& n,
+                                          uint64_t** alt = nullptr) {
     const uint32_t item = work_order[2 * index] >> 1;   // work items come in (half 0, half 1) pairs
     const uint32_t view = item / (uint32_t)tiles;
     const uint32_t tile = item - view * (uint32_t)tiles;
@@ -287,6 +372,7 @@ __device__ __forceinline__ bool sort_item(const BinView* __restrict__ views, int
     n = (int)(range.y - range.x);
     bucket = bv.bucket + range.x;
     out = bv.gauss_sorted + range.x;
+    if (alt) *alt = bv.alt + range.x;
     return n > 0;
 }
 
@@ -311,22 +397,27 @@ __global__ __launch_bounds__(SORT_LARGE_THREADS) void tile_sort_large_kernel(con
     __shared__ uint64_t skeys[SORT_LARGE_THREADS * 17];   // 136 KiB of the CU's 160 KiB
     const uint32_t cand = *n_candidates;
     for (uint32_t k = blockIdx.x; k < cand; k += gridDim.x) {
-        const uint2* bucket; uint32_t* out; int n;
-        const bool ok = sort_item(views, tiles, work_order, k, bucket, out, n);
+        const uint2* bucket; uint32_t* out; int n; uint64_t* alt;
+        const bool ok = sort_item(views, tiles, work_order, k, bucket, out, n, &alt);
         if (ok && n > SORT_SMALL_MAX) {
             if (n <= SORT_LARGE_MAX) {
                 merge_sort_tile<SORT_LARGE_THREADS, 16>(skeys, bucket, out, n);
             } else {
+                // Longer than the LDS holds: sort 16384-key chunks in LDS into 64-bit keys (in place over the
+                // (depth,index) pairs), then merge the runs through L2 between the list and its alt buffer.
                 uint64_t* gk = reinterpret_cast<uint64_t*>(const_cast<uint2*>(bucket));
-                for (int i = threadIdx.x; i < n; i += SORT_LARGE_THREADS) {
-                    const uint2 e = bucket[i];
-                    gk[i] = ((uint64_t)e.x << 32) | e.y;
+                for (int c0 = 0; c0 < n; c0 += SORT_LARGE_MAX) {
+                    merge_sort_tile<SORT_LARGE_THREADS, 16>(skeys, bucket + c0, nullptr, min(SORT_LARGE_MAX, n - c0),
+                                                            gk + c0);
+                    __syncthreads();
                 }
-                __syncthreads();
-                int npad = 1;
-                while (npad < n) npad <<= 1;
-                bitonic_sort_global(gk, n, npad, SORT_LARGE_THREADS);
-                for (int i = threadIdx.x; i < n; i += SORT_LARGE_THREADS) out[i] = (uint32_t)gk[i];
+                uint64_t *src = gk, *dst = alt;
+                for (int run = SORT_LARGE_MAX; run < n; run <<= 1) {
+                    merge_round_global<SORT_LARGE_THREADS, 16>(src, dst, n, run);
+                    __syncthreads();
+                    uint64_t* tmp = src; src = dst; dst = tmp;
+                }
+                for (int i = threadIdx.x; i < n; i += SORT_LARGE_THREADS) out[i] = (uint32_t)src[i];
             }
         }
         __syncthreads();   // skeys reuse across loop iterations

@@ -56,8 +56,9 @@ def fetch_workspace(view_index, n, width, height):
     r["depth"] = grab(v["depth"], n, np.float32)
     r["conic_opacity"] = grab(v["conic_opacity"], 4 * n, np.float32).reshape(n, 4)
     r["rgb4"] = grab(v["rgb"], 4 * n, np.float32).reshape(n, 4)
-    r["tiles_touched"] = grab(v["tiles_touched"], n, np.uint32).astype(np.int32)
-    r["offsets"] = grab(v["offsets"], n, np.uint32)
+    rects = grab(v["rects"], 4 * n, np.uint16).reshape(n, 4).astype(np.int32)
+    r["rects"] = rects
+    r["tiles_touched"] = (rects[:, 2] - rects[:, 0]) * (rects[:, 3] - rects[:, 1])
     r["gauss_sorted"] = grab(v["gauss_sorted"], I, np.uint32)
     r["ranges"] = grab(v["ranges"], 2 * tiles, np.uint32).reshape(tiles, 2)
     return r

@@ -13,8 +13,10 @@ pytestmark = pytest.mark.gpu
 def _run_both(oracle, cloud, view, gpu_device, sh_degree=3, bg=(0.0, 0.0, 0.0), **kw):
     from helpers import gpu_forward
     act = cloud.activated()
+    # cull_mode=1: the oracle lists only the instances that can contribute, exactly as the HIP binning does;
+    # tests/test_oracle_tight_lists.py proves that its images are bit-identical to the reference-list mode.
     o = oracle.forward(**act, sh_degree=sh_degree, **view.raster_kwargs(bg), num_threads=8,
-                       scale_modifier=kw.get("scale_modifier", 1.0))
+                       scale_modifier=kw.get("scale_modifier", 1.0), cull_mode=1)
     g = gpu_forward(act, view, sh_degree=sh_degree, bg=bg, device=str(gpu_device), **kw)
     return g, o
 
@@ -119,7 +121,7 @@ def test_precomputed_colour_and_cov(oracle, gpu_device):
     colors = np.random.default_rng(0).uniform(0, 1, size=(cloud.n, 3)).astype(np.float32)
     kw = dict(means3d=act["means3d"], opacities=act["opacities"], cov3d_precomp=base["cov3d"],
               colors_precomp=colors)
-    o = oracle.forward(**kw, **v.raster_kwargs(), num_threads=4)
+    o = oracle.forward(**kw, **v.raster_kwargs(), num_threads=4, cull_mode=1)
     g = gpu_forward(act, v, colors_precomp=colors, cov3d_precomp=base["cov3d"], device=str(gpu_device))
     np.testing.assert_array_equal(g["radii"], o["radii"])
     np.testing.assert_array_equal(g["gauss_sorted"], o["gauss_sorted"])
@@ -211,6 +213,22 @@ def test_batch_matches_single_view_and_oracle(oracle, gpu_device):
         single = gpu_forward(act, v, bg=bg, device=str(dev))
         for key in ("color", "out_depth", "radii", "final_T", "n_contrib", "gauss_sorted"):
             np.testing.assert_array_equal(batch[k][key], single[key], err_msg=f"view {k} {key}")
-        o = oracle.forward(**act, sh_degree=3, **v.raster_kwargs(bg), num_threads=8)
+        o = oracle.forward(**act, sh_degree=3, **v.raster_kwargs(bg), num_threads=8, cull_mode=1)
         np.testing.assert_array_equal(batch[k]["gauss_sorted"], o["gauss_sorted"])
         assert_images_match(batch[k], o)
+
+
+@pytest.mark.parametrize("n,spread", [(16000, 0.02), (90000, 0.05), (40000, 0.004)])
+def test_long_tile_lists(oracle, gpu_device, n, spread):
+    """Lists beyond the small LDS sort tier (4096), beyond the large tier (16384) and with many equal
+    depths: a dense clump of small, faint splats in front of the camera."""
+    rng = np.random.default_rng(n)
+    cloud, views = scenes.scene_c1(seed=3, n=n)
+    cloud.xyz[:] = rng.normal(0, spread, size=(n, 3)).astype(np.float32)
+    cloud.xyz[: n // 3, 2] = np.float32(0.125)            # thousands of exactly equal depths -> index tie-break
+    cloud.scaling[:] = np.log(0.004).astype(np.float32)
+    cloud.opacity[:] = rng.normal(-4.0, 0.5, size=(n, 1)).astype(np.float32)   # faint: no early saturation
+    g, o = _run_both(oracle, cloud, views[0], gpu_device)
+    lens = o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]
+    assert lens.max() > (16384 if n >= 40000 else 4096), lens.max()
+    _check_all(g, o)
