@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--views", type=int, default=64, help="distinct cameras cycled through")
     ap.add_argument("--batch", type=int, default=16, help="views per step (one pgr_forward_batch call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--raster-only", action="store_true", help="time only the full-scene RGB+depth pass (R), no masks")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--profile-steps", type=int, default=2, help="steps measured per-stage with HIP events")
     return ap.parse_args()
@@ -94,7 +95,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from pegasus_amd import _lib, rasterizer
+    from pegasus_amd import _lib, frames as F, rasterizer
     _lib.lib()
 
     # every rank builds the same scene (replicated: 472 MB at 2 M Gaussians) and takes views rank::world
@@ -103,23 +104,19 @@ def main():
     cloud, views, label = build_workload(args.workload, args.scale, n_views_total)
     my_views = views[rank::world] or views
     act = cloud.activated()
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    means, opac, scales, rots, shs = (t(act[k]) for k in ("means3d", "opacities", "scales", "rotations", "shs"))
-    bg = torch.zeros(3, device=dev)
-    specs = [rasterizer.ViewSpec(v.height, v.width, v.tanfovx, v.tanfovy, bg, t(v.world_view_transform),
-                                 t(v.full_proj_transform), t(v.camera_center)) for v in my_views]
+    fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"],
+                         cloud.object_id, sh_degree=3, device=dev)
+    specs = [fr.view_spec(v) for v in my_views]
     W, H = my_views[0].width, my_views[0].height
     P = W * H
-    # frame buffers of one batch, allocated once (the product writes frames in place)
-    frames = [dict(color=torch.empty((3, H, W), device=dev), depth=torch.empty((1, H, W), device=dev), radii=None)
-              for _ in range(B)]
+    with_masks = not args.raster_only and fr.K > 0
+    frames = fr.alloc_frames(B, H, W, masks=with_masks)      # one batch of frame buffers, reused every step
 
     def batch_views(i):
         return [specs[(i * B + k) % len(specs)] for k in range(B)]
 
     def step(i, **kw):
-        return rasterizer.forward_views(means, opac, batch_views(i), shs=shs, scales=scales, rotations=rots,
-                                        sh_degree=3, want_radii=False, outputs=frames, **kw)
+        return fr.render_batch(batch_views(i), frames, masks=with_masks, **kw)
 
     for i in range(args.warmup):
         step(i)
@@ -142,26 +139,32 @@ def main():
 
     # ---- per-view statistics and per-stage HIP-event timing of whole batches (outside the timed region) ----
     stage_ms = np.zeros((0, _lib.PGR_NUM_STAGES))
+    sem_ms = np.zeros((0, _lib.PGR_NUM_STAGES))
     stats = []
+    raster_only_fps = None
     if rank == 0:
-        rows = []
         for i in range(max(1, args.profile_steps)):
-            ms = []
-            res = rasterizer.forward_views(means, opac, batch_views(i), shs=shs, scales=scales, rotations=rots,
-                                           sh_degree=3, want_radii=True, want_aux=True, stage_ms=ms)
-            rows.append(ms)
+            res = rasterizer.forward_views(fr.means3d, fr.opacities, batch_views(i), shs=fr.shs, scales=fr.scales,
+                                           rotations=fr.rotations, sh_degree=3, want_radii=True, want_aux=True)
             info = rasterizer.last_forward_info()
             for k, r in enumerate(res):
                 stats.append(dict(V=int((r["radii"] > 0).sum().item()), I=info["num_instances"][k],
                                   evals=int(r["n_contrib"].sum(dtype=torch.int64).item())))
             del res
-        # aux outputs change the compositor's epilogue only; re-time the plain variant for the stage table
-        rows = []
+        rows, srows = [], []
         for i in range(max(1, args.profile_steps)):
-            ms = []
-            step(i, stage_ms=ms)
+            ms, sms = [], []
+            step(i, stage_ms=ms, sem_stage_ms=sms)
             rows.append(ms)
-        stage_ms = np.asarray(rows)
+            srows.append(sms if sms else [0.0] * _lib.PGR_NUM_STAGES)
+        stage_ms, sem_ms = np.asarray(rows), np.asarray(srows)
+        # R: raster-only rate (one full-scene RGB+depth forward per view), for the record next to F
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            fr.render_batch(batch_views(i), frames, masks=False)
+        torch.cuda.synchronize()
+        raster_only_fps = args.steps * B / (time.perf_counter() - t1)
 
     if rank != 0:
         if world > 1:
@@ -191,6 +194,8 @@ def main():
         "whole_path": {"bytes_per_view": int(B_view), "achieved": round(B_view * value / world / 1e9, 2),
                        "frac": round(B_view * value / world / 1e9 / HBM_PEAK_GBS, 5)},
         "composite_evals_per_s": round(evals * B / (mean_ms[4] * 1e-3), 1) if mean_ms[4] > 0 else None,
+        "semantic_pass_ms_per_view": {k: round(float(m) / B, 4) for k, m in zip(_lib.STAGE_NAMES, sem_ms.mean(axis=0))},
+        "raster_only_views_per_s": round(raster_only_fps, 2) if raster_only_fps else None,
         "N": N, "V": round(V), "I": round(I), "P": P,
     }
 
@@ -200,23 +205,34 @@ def main():
         oracle.build()
         cores = os.cpu_count() or 1
         n_done, t_cpu = 0, 0.0
+        n_env = fr.n_env
+        sem_shs = fr.sem_shs.cpu().numpy() if with_masks else None
         while n_done < len(my_views) and (n_done == 0 or t_cpu + t_cpu / n_done < args.cpu_budget_s):
             v = my_views[n_done]
             t1 = time.perf_counter()
             oracle.forward(**act, sh_degree=3, **v.raster_kwargs(), num_threads=cores, want_binning=False)
+            if with_masks:
+                seg = oracle.forward(act["means3d"][n_env:], act["opacities"][n_env:], scales=act["scales"][n_env:],
+                                     rotations=act["rotations"][n_env:], shs=sem_shs, sh_degree=0,
+                                     **v.raster_kwargs(), num_threads=cores, want_binning=False)
+                oracle.color_masks(seg["color"], fr.colors_np, 0.1)
             t_cpu += time.perf_counter() - t1
             n_done += 1
-        cpu = {"value": round(n_done / t_cpu, 4), "unit": "views/s", "cores": cores, "kind": "port",
-               "sample": f"first {n_done} view(s) of the same scene and cameras, oracle/pgr_oracle.c with OpenMP "
-                         f"({cores} threads); no reference CPU rasterizer exists"}
+        cpu = {"value": round(n_done / t_cpu, 4), "unit": "frames/s" if with_masks else "views/s", "cores": cores,
+               "kind": "port",
+               "sample": f"first {n_done} frame(s) of the same scene and cameras, oracle/pgr_oracle.c with OpenMP "
+                         f"({cores} threads), reference-style lists; no reference CPU rasterizer exists"}
 
     line = {
-        "metric": "rendered views/sec (RGB+depth) on 2M-Gaussian scene @800x800",
+        "metric": "rendered views/sec (RGB+depth+mask) on 2M-Gaussian scene @800x800" if with_masks else
+                  "rendered views/sec (RGB+depth, raster only) on 2M-Gaussian scene @800x800",
         "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": label, "gaussians": N, "width": W, "height": H, "views_per_step": B,
-                   "distinct_views": len(my_views), "outputs": "color[3,H,W] f32 + depth[1,H,W] f32 + radii",
+                   "distinct_views": len(my_views), "objects": fr.K,
+                   "outputs": ("color[3,H,W] f32 + depth[1,H,W] f32 + semantic image[3,H,W] f32 + masks[K,H,W] u8"
+                               if with_masks else "color[3,H,W] f32 + depth[1,H,W] f32"),
                    "parallelism": f"view-shard x{world}"},
         "roofline": roofline,
         "cpu_baseline": cpu,

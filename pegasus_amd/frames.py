@@ -1,0 +1,88 @@
+"""Batched frame production: what one iteration of PEGASUS's per-frame loop emits
+(/root/reference/pegasus.py:254-358 with data points ['rgb','depth','seg_vis'], pegasus.py:491):
+
+    rgb + depth   : the merged scene (environment + objects) rendered with its own SH colours
+    seg_vis       : the objects alone, each painted with its semantic colour (f_dc = RGB2SH(c_k), f_rest = 0,
+                    /root/reference/pegasus.py:230-232), thresholded into K masks (||img - c_k|| <= 0.1,
+                    /root/reference/src/gs/render.py:68-97)
+
+The reference does this one camera at a time with a deepcopy + 6 vstack per frame and host-side numpy
+masks; here a batch of cameras is two pgr_forward_batch calls over resident device tensors plus the mask
+kernel, and nothing leaves the GPU until the caller asks for it.
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from . import masks as M
+from . import rasterizer as R
+from .sh_utils import RGB2SH
+
+
+class FrameRenderer:
+    def __init__(self, means3d, opacities, scales, rotations, shs, object_id, sh_degree=3, device="cuda:0",
+                 bg=(0.0, 0.0, 0.0), color_mode="bgr"):
+        """All arrays are ACTIVATED values (numpy or torch), environment Gaussians first (object_id 0) and
+        each object's Gaussians after (object_id k = 1..K), as PEGASUS merges them."""
+        self.device = torch.device(device)
+        t = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a
+                                                        ).to(self.device, dt).contiguous()
+        self.means3d, self.opacities, self.scales, self.rotations, self.shs = (
+            t(means3d), t(opacities), t(scales), t(rotations), t(shs))
+        oid = np.asarray(object_id).astype(np.int64)
+        self.sh_degree = int(sh_degree)
+        self.bg = t(np.asarray(bg, np.float32))
+        self.n = int(self.means3d.shape[0])
+        self.K = int(oid.max()) if oid.size else 0
+        obj = np.nonzero(oid > 0)[0]
+        if obj.size and not np.all(np.diff(obj) == 1):
+            raise ValueError("object Gaussians must follow the environment Gaussians contiguously")
+        self.n_env = int(obj[0]) if obj.size else self.n
+        # semantic-colour cloud of the objects alone (environment masked out, render.py:81-83)
+        self.colors_np = M.generate_colors(max(self.K, 1), color_mode)[: self.K]
+        self.colors = t(self.colors_np) if self.K else None
+        if self.K:
+            dc = RGB2SH(self.colors_np[oid[self.n_env:] - 1]).astype(np.float32)       # [n_obj,3]
+            self.sem_shs = t(dc.reshape(-1, 1, 3))
+            s = slice(self.n_env, self.n)
+            self.obj = dict(means3d=self.means3d[s], opacities=self.opacities[s], scales=self.scales[s],
+                            rotations=self.rotations[s])
+
+    def view_spec(self, view) -> R.ViewSpec:
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+        return R.ViewSpec(view.height, view.width, view.tanfovx, view.tanfovy, self.bg,
+                          t(view.world_view_transform), t(view.full_proj_transform), t(view.camera_center))
+
+    def alloc_frames(self, batch: int, height: int, width: int, masks: bool = True):
+        dev = self.device
+        f = dict(color=torch.empty((batch, 3, height, width), device=dev),
+                 depth=torch.empty((batch, 1, height, width), device=dev))
+        if masks and self.K:
+            f["seg"] = torch.empty((batch, 3, height, width), device=dev)
+            f["seg_depth"] = torch.empty((batch, 1, height, width), device=dev)
+            f["masks"] = torch.empty((batch, self.K, height, width), dtype=torch.uint8, device=dev)
+        return f
+
+    def render_batch(self, specs: Sequence[R.ViewSpec], frames: dict = None, masks: bool = True,
+                     stage_ms: list = None, sem_stage_ms: list = None):
+        """Renders len(specs) frames into ``frames`` (allocated if None).  Returns the dict of batched
+        tensors: color [B,3,H,W], depth [B,1,H,W], and with masks: seg [B,3,H,W], masks [B,K,H,W] uint8."""
+        B = len(specs)
+        H, W = int(specs[0].image_height), int(specs[0].image_width)
+        if frames is None:
+            frames = self.alloc_frames(B, H, W, masks)
+        outs = [dict(color=frames["color"][i], depth=frames["depth"][i], radii=None) for i in range(B)]
+        R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales,
+                        rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False, outputs=outs,
+                        stage_ms=stage_ms)
+        if masks and self.K:
+            souts = [dict(color=frames["seg"][i], depth=frames["seg_depth"][i], radii=None) for i in range(B)]
+            R.forward_views(self.obj["means3d"], self.obj["opacities"], specs, shs=self.sem_shs,
+                            scales=self.obj["scales"], rotations=self.obj["rotations"], sh_degree=0,
+                            want_radii=False, outputs=souts, stage_ms=sem_stage_ms)
+            for i in range(B):
+                M.color_masks(frames["seg"][i], self.colors, M.MASK_THRESHOLD, out=frames["masks"][i])
+        return frames

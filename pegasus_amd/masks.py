@@ -1,0 +1,73 @@
+"""Per-object masks and frame quantisation on the device.
+
+Reference behaviour: /root/reference/src/gs/render.py:60-63,89-93 (``np.linalg.norm(img - c, axis=2) <= 0.1``
+per semantic colour, on the host) and /root/reference/pegasus.py:347,355 (uint8 / uint16-mm casts).
+Here both run as HIP kernels on the frames where they were rendered (pgr_color_masks,
+pgr_quantize_frame), so only the final small integers ever cross PCIe.
+"""
+from __future__ import annotations
+
+import colorsys
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+MASK_THRESHOLD = 0.1
+
+
+def generate_colors(n: int, mode: str = "bgr") -> np.ndarray:
+    """Semantic colour table: hue i/n, lightness 0.6, saturation 0.7, returned BGR by default, float32 [n,3].
+    Same values as /root/reference/src/utility/graphic_utils.py:40-60 (pinned by tests/golden/graphic_utils.npz)."""
+    colors = []
+    for i in range(n):
+        r, g, b = colorsys.hls_to_rgb(i / n, 0.6, 0.7)
+        if mode == "bgr":
+            colors.append((b, g, r))
+        elif mode == "rgb":
+            colors.append((r, g, b))
+        else:
+            raise ValueError("Color mode {} is not supported".format(mode))
+    return np.asarray(colors, dtype=np.float32).reshape(n, 3)
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def color_masks(img_chw: torch.Tensor, colors: torch.Tensor, threshold: float = MASK_THRESHOLD,
+                out: torch.Tensor = None) -> torch.Tensor:
+    """uint8 [K,H,W]: 1 where the rendered colour is within ``threshold`` (L2) of semantic colour k."""
+    L = _lib.lib()
+    if img_chw.device.type != "cuda":
+        raise RuntimeError("color_masks needs a HIP device tensor; there is no CPU path")
+    img = img_chw.contiguous().float()
+    colors = colors.to(img.device).contiguous().float().reshape(-1, 3)
+    _, H, W = img.shape
+    K = colors.shape[0]
+    if out is None:
+        out = torch.empty((K, H, W), dtype=torch.uint8, device=img.device)
+    with torch.cuda.device(img.device):
+        _lib.check(L.pgr_color_masks(C.c_void_p(img.data_ptr()), W, H, C.c_void_p(colors.data_ptr()), K,
+                                     float(threshold), C.c_void_p(out.data_ptr()), _stream(img.device)),
+                   "pgr_color_masks")
+    return out
+
+
+def quantize_frame(img_chw: torch.Tensor, depth: torch.Tensor):
+    """(uint8 [H,W,3], uint16-as-int16-storage [H,W]) exactly as the reference's numpy casts."""
+    L = _lib.lib()
+    if img_chw.device.type != "cuda":
+        raise RuntimeError("quantize_frame needs HIP device tensors; there is no CPU path")
+    img = img_chw.contiguous().float()
+    d = depth.contiguous().float()
+    _, H, W = img.shape
+    rgb = torch.empty((H, W, 3), dtype=torch.uint8, device=img.device)
+    mm = torch.empty((H, W), dtype=torch.int16, device=img.device)   # bit pattern of uint16 millimetres
+    with torch.cuda.device(img.device):
+        _lib.check(L.pgr_quantize_frame(C.c_void_p(img.data_ptr()), C.c_void_p(d.data_ptr()), W, H,
+                                        C.c_void_p(rgb.data_ptr()), C.c_void_p(mm.data_ptr()), _stream(img.device)),
+                   "pgr_quantize_frame")
+    return rgb, mm

@@ -232,3 +232,42 @@ def test_long_tile_lists(oracle, gpu_device, n, spread):
     lens = o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]
     assert lens.max() > (16384 if n >= 40000 else 4096), lens.max()
     _check_all(g, o)
+
+
+def test_frame_renderer_rgb_depth_masks(oracle, gpu_device):
+    """FrameRenderer = PEGASUS's per-frame outputs: scene RGB+depth, object-only semantic image, K masks."""
+    import torch
+    from helpers import assert_images_match
+    from pegasus_amd import frames as F, masks as M
+    cloud, views = scenes.scene_c3(scale=0.04, n_views=3, width=320, height=240)
+    act = cloud.activated()
+    fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"],
+                         cloud.object_id, sh_degree=3, device=gpu_device)
+    assert fr.K == 8 and fr.n_env == int((cloud.object_id == 0).sum())
+    out = fr.render_batch([fr.view_spec(v) for v in views])
+    torch.cuda.synchronize()
+    n_env = fr.n_env
+    sem_shs = fr.sem_shs.cpu().numpy()
+    for i, v in enumerate(views):
+        o = oracle.forward(**act, sh_degree=3, **v.raster_kwargs(), num_threads=8)
+        g = dict(color=out["color"][i].cpu().numpy(), out_depth=out["depth"][i].cpu().numpy())
+        amb = o["ambig"].astype(bool)
+        assert np.abs(g["color"] - o["color"])[:, ~amb].max() <= 1e-4
+        assert np.abs(g["out_depth"] - o["out_depth"])[:, ~amb].max() <= 1e-4
+        so = oracle.forward(act["means3d"][n_env:], act["opacities"][n_env:], scales=act["scales"][n_env:],
+                            rotations=act["rotations"][n_env:], shs=sem_shs, sh_degree=0, **v.raster_kwargs(),
+                            num_threads=8)
+        samb = so["ambig"].astype(bool)
+        seg = out["seg"][i].cpu().numpy()
+        assert np.abs(seg - so["color"])[:, ~samb].max() <= 1e-4
+        # masks: exact wherever the colour distance is not within 1e-4 of the 0.1 threshold
+        om = oracle.color_masks(so["color"], fr.colors_np, 0.1)
+        gm = out["masks"][i].cpu().numpy()
+        dist = np.stack([np.linalg.norm(so["color"].transpose(1, 2, 0) - c, axis=2) for c in fr.colors_np])
+        decided = (np.abs(dist - 0.1) > 2e-4) & ~samb[None]
+        np.testing.assert_array_equal(gm[decided], om[decided])
+        assert decided.mean() > 0.999
+        assert gm.sum() > 0      # the objects are visible
+        # and the device mask kernel is bit-exact against the oracle on the SAME image
+        np.testing.assert_array_equal(M.color_masks(out["seg"][i], fr.colors).cpu().numpy(),
+                                      oracle.color_masks(seg, fr.colors_np, 0.1))

@@ -1,0 +1,213 @@
+"""Analytic known-answer tests for the CPU oracle.  The reference holds no golden
+vectors for the rasterizer, so these closed-form cases are what pins the restatement."""
+import math
+
+import numpy as np
+import pytest
+
+C0 = 0.28209479177387814
+W = H = 64
+FOV = math.radians(60.0)
+TAN = math.tan(FOV / 2)
+FOCAL = W / (2 * TAN)
+
+
+def camera():
+    """Camera at the origin looking down +z, identity view matrix."""
+    from pegasus_amd import graphics as G
+    wvt, proj, full, center = G.camera_matrices(np.eye(3), np.zeros(3), FOV, FOV)
+    return dict(width=W, height=H, tanfovx=TAN, tanfovy=TAN, viewmatrix=wvt, projmatrix=full, campos=center)
+
+
+def splat(x, y, z, sigma_px, opacity, rgb):
+    """One isotropic Gaussian whose screen-space sigma is sigma_px at depth z, colour via SH degree 0."""
+    s = sigma_px * z / FOCAL
+    dc = (np.asarray(rgb, np.float64) - 0.5) / C0
+    return dict(mean=(x, y, z), scale=(s, s, s), rot=(1, 0, 0, 0), op=opacity, dc=dc)
+
+
+def run(oracle, splats, bg=(0, 0, 0), **kw):
+    n = len(splats)
+    shs = np.zeros((n, 16, 3), np.float32)
+    shs[:, 0] = [s["dc"] for s in splats]
+    cam = camera()
+    cam.update(kw)
+    return oracle.forward(
+        np.array([s["mean"] for s in splats], np.float32), np.array([s["op"] for s in splats], np.float32),
+        scales=np.array([s["scale"] for s in splats], np.float32),
+        rotations=np.array([s["rot"] for s in splats], np.float32), shs=shs, sh_degree=0,
+        bg=np.asarray(bg, np.float32), **cam)
+
+
+def pixel_of(x, y, z):
+    """Pixel coordinate the point projects to: ((ndc+1)*S-1)/2 with ndc = x/(z*tan)."""
+    return ((x / (z * TAN) + 1) * W - 1) / 2, ((y / (z * TAN) + 1) * H - 1) / 2
+
+
+def world_of(px, py, z):
+    return ((2 * px + 1) / W - 1) * z * TAN, ((2 * py + 1) / H - 1) * z * TAN
+
+
+def test_single_gaussian_centre_pixel(oracle):
+    x, y = world_of(20, 30, 2.0)
+    r = run(oracle, [splat(x, y, 2.0, 3.0, 0.6, (0.9, 0.5, 0.1))], bg=(0.2, 0.2, 0.2))
+    assert r["xy"][0] == pytest.approx([20, 30], abs=1e-3)
+    a = 0.6                                                  # exp(0) = 1 at the centre
+    np.testing.assert_allclose(r["color"][:, 30, 20], np.array([0.9, 0.5, 0.1]) * a + 0.2 * (1 - a), atol=2e-6)
+    assert r["out_depth"][0, 30, 20] == pytest.approx(2.0 * a, abs=1e-6)     # sum T alpha z, no normalisation
+    assert r["final_T"][30, 20] == pytest.approx(1 - a, abs=1e-6)
+    assert r["n_contrib"][30, 20] == 1
+    # a far corner sees only background
+    np.testing.assert_allclose(r["color"][:, 0, 63], 0.2, atol=1e-7)
+    assert r["out_depth"][0, 0, 63] == 0 and r["final_T"][0, 63] == 1
+
+
+def test_gaussian_falloff_and_radius(oracle):
+    sigma = 2.5
+    x, y = world_of(32, 32, 1.5)
+    r = run(oracle, [splat(x, y, 1.5, sigma, 0.9, (1, 1, 1))])
+    var = sigma * sigma + 0.3                                  # low-pass dilation
+    for d in (1, 2, 4):
+        expect = 0.9 * math.exp(-0.5 * d * d / var)
+        assert r["color"][0, 32, 32 + d] == pytest.approx(expect, rel=2e-4)
+        assert r["color"][0, 32 - d, 32] == pytest.approx(expect, rel=2e-4)
+    assert r["radii"][0] == math.ceil(3 * math.sqrt(var))
+    cx, cy, cz, op = r["conic_opacity"][0]
+    assert (cx, cz) == pytest.approx((1 / var, 1 / var), rel=1e-4) and abs(cy) < 1e-4 and op == np.float32(0.9)
+
+
+def test_two_gaussians_depth_order(oracle):
+    xa, ya = world_of(10, 10, 1.0)
+    xb, yb = world_of(10, 10, 3.0)
+    near = splat(xa, ya, 1.0, 2.0, 0.5, (1, 0, 0))
+    far = splat(xb, yb, 3.0, 2.0, 0.8, (0, 0, 1))
+    for order in ([near, far], [far, near]):                   # input order must not matter
+        r = run(oracle, order)
+        c = r["color"][:, 10, 10]
+        np.testing.assert_allclose(c, [0.5, 0, 0.8 * 0.5], atol=2e-6)       # c1 a1 + c2 a2 (1 - a1)
+        assert r["out_depth"][0, 10, 10] == pytest.approx(1.0 * 0.5 + 3.0 * 0.8 * 0.5, abs=2e-6)
+        assert r["final_T"][10, 10] == pytest.approx(0.5 * 0.2, abs=1e-6)
+
+
+def test_equal_depth_resolved_by_index(oracle):
+    x, y = world_of(40, 40, 2.0)
+    a = splat(x, y, 2.0, 2.0, 0.5, (1, 0, 0))
+    b = splat(x, y, 2.0, 2.0, 0.5, (0, 1, 0))
+    r = run(oracle, [a, b])
+    np.testing.assert_allclose(r["color"][:, 40, 40], [0.5, 0.25, 0], atol=2e-6)   # index 0 is in front
+    r = run(oracle, [b, a])
+    np.testing.assert_allclose(r["color"][:, 40, 40], [0.25, 0.5, 0], atol=2e-6)
+
+
+def test_alpha_thresholds(oracle):
+    x, y = world_of(5, 5, 1.0)
+    # alpha below 1/255 everywhere: the pixel is untouched
+    r = run(oracle, [splat(x, y, 1.0, 2.0, 0.0039, (1, 1, 1))], bg=(0.3, 0.3, 0.3))
+    assert r["n_contrib"][5, 5] == 0 and r["color"][0, 5, 5] == np.float32(0.3)
+    r = run(oracle, [splat(x, y, 1.0, 2.0, 0.004, (1, 1, 1))], bg=(0.3, 0.3, 0.3))
+    assert r["n_contrib"][5, 5] == 1
+    # opacity 1.0 is clamped to alpha 0.99
+    r = run(oracle, [splat(x, y, 1.0, 2.0, 1.0, (1, 1, 1))])
+    assert r["color"][0, 5, 5] == pytest.approx(0.99, abs=1e-7) and r["final_T"][5, 5] == pytest.approx(0.01, abs=1e-7)
+
+
+def test_near_plane_cull(oracle):
+    r = run(oracle, [splat(0, 0, 0.2, 2.0, 0.9, (1, 1, 1)), splat(0, 0, 0.2001, 2.0, 0.9, (1, 1, 1))])
+    assert r["radii"][0] == 0 and r["tiles_touched"][0] == 0        # z <= 0.2 culled
+    assert r["radii"][1] > 0
+
+
+def test_tile_rectangle_on_corner(oracle):
+    """A splat centred exactly between four tiles with a radius < 16 touches exactly those 4 tiles."""
+    x, y = world_of(15.5, 15.5, 2.0)
+    r = run(oracle, [splat(x, y, 2.0, 1.0, 0.9, (1, 1, 1))])
+    assert r["radii"][0] == math.ceil(3 * math.sqrt(1.3)) == 4
+    assert r["tiles_touched"][0] == 4
+    assert sorted((r["keys_sorted"] >> np.uint64(32)).tolist()) == [0, 1, 4, 5]       # 64/16 = 4 tiles per row
+
+
+def test_offscreen_splat_has_zero_radius(oracle):
+    x, y = world_of(500, 10, 2.0)
+    r = run(oracle, [splat(x, y, 2.0, 2.0, 0.9, (1, 1, 1))])
+    assert r["radii"][0] == 0 and r["num_instances"] == 0
+
+
+def test_sh_degree0_colour_and_clamp(oracle):
+    x, y = world_of(8, 8, 1.0)
+    r = run(oracle, [splat(x, y, 1.0, 2.0, 0.5, (0.25, 0.75, 0.5))])
+    np.testing.assert_allclose(r["rgb"][0], [0.25, 0.75, 0.5], atol=1e-6)       # C0*dc + 0.5
+    s = splat(x, y, 1.0, 2.0, 0.5, (0, 0, 0))
+    s["dc"] = np.array([-5.0, 0.0, 5.0])
+    r = run(oracle, [s])
+    np.testing.assert_allclose(r["rgb"][0], [0.0, 0.5, 0.5 + 5 * C0], atol=1e-6)  # clamped at 0 from below only
+
+
+def test_sh_degree1_direction(oracle):
+    """Band 1: colour = C0 dc + 0.5 - C1 y sh1 + C1 z sh2 - C1 x sh3 with (x,y,z) the unit view direction."""
+    C1 = 0.4886025119029199
+    cam = camera()
+    pos = np.array([[0.3, -0.2, 2.0]], np.float32)
+    d = pos[0] / np.linalg.norm(pos[0])
+    shs = np.zeros((1, 16, 3), np.float32)
+    shs[0, 1] = [1, 0, 0]; shs[0, 2] = [0, 1, 0]; shs[0, 3] = [0, 0, 1]
+    r = oracle.forward(pos, np.array([0.5], np.float32), scales=np.full((1, 3), 0.01, np.float32),
+                       rotations=np.array([[1, 0, 0, 0]], np.float32), shs=shs, sh_degree=1,
+                       bg=np.zeros(3, np.float32), stage="preprocess", **cam)
+    np.testing.assert_allclose(r["rgb"][0], [0.5 - C1 * d[1], 0.5 + C1 * d[2], 0.5 - C1 * d[0]], atol=1e-6)
+
+
+def test_early_termination_keeps_T_above_threshold(oracle):
+    x, y = world_of(12, 12, 1.0)
+    layers = [splat(*world_of(12, 12, 1.0 + 0.01 * k), 1.0 + 0.01 * k, 2.0, 0.9, (1, 1, 1)) for k in range(100)]
+    r = run(oracle, layers)
+    # T after k blends is 0.1^k; the 5th would give 1e-5 < 1e-4 and is NOT blended
+    assert r["n_contrib"][12, 12] == 4
+    assert r["final_T"][12, 12] == pytest.approx(1e-4, rel=1e-4) and r["final_T"][12, 12] >= 1e-4 * (1 - 1e-4)
+
+
+def test_empty_scene_stays_zero(oracle):
+    cam = camera()
+    r = oracle.forward(np.zeros((0, 3), np.float32), np.zeros(0, np.float32), scales=np.zeros((0, 3), np.float32),
+                       rotations=np.zeros((0, 4), np.float32), shs=np.zeros((0, 16, 3), np.float32), sh_degree=3,
+                       bg=np.ones(3, np.float32), **cam)
+    assert not r["color"].any() and not r["out_depth"].any()      # not the background: zeros
+
+
+def test_anisotropic_rotated_covariance(oracle):
+    """cov3D = R S^2 R^T and its EWA projection, against numpy float64."""
+    cam = camera()
+    q = np.array([0.8, 0.2, -0.4, 0.4]); q /= np.linalg.norm(q)
+    s = np.array([0.05, 0.01, 0.03])
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                  [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    S3 = R @ np.diag(s * s) @ R.T
+    pos = np.array([0.2, 0.1, 2.5])
+    J = np.array([[FOCAL / pos[2], 0, -FOCAL * pos[0] / pos[2] ** 2], [0, FOCAL / pos[2], -FOCAL * pos[1] / pos[2] ** 2]])
+    S2 = J @ S3 @ J.T + 0.3 * np.eye(2)
+    conic = np.linalg.inv(S2)
+    r = oracle.forward(pos[None].astype(np.float32), np.array([0.7], np.float32), scales=s[None].astype(np.float32),
+                       rotations=q[None].astype(np.float32), shs=np.zeros((1, 16, 3), np.float32), sh_degree=0,
+                       bg=np.zeros(3, np.float32), stage="preprocess", **cam)
+    np.testing.assert_allclose(r["cov3d"][0], S3[np.triu_indices(3)], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(r["conic_opacity"][0, :3], [conic[0, 0], conic[0, 1], conic[1, 1]], rtol=2e-4)
+    lam = np.linalg.eigvalsh(S2).max()
+    assert r["radii"][0] == math.ceil(3 * math.sqrt(lam))
+
+
+def test_masks_and_quantisation_match_numpy(oracle):
+    """The reference's host ops: np.linalg.norm(img - c, axis=2) <= 0.1 (src/gs/render.py:60-63,89-93) and
+    (img*255).astype(uint8), (depth*1000).astype(uint16) (pegasus.py:347,355)."""
+    rng = np.random.default_rng(0)
+    img = rng.uniform(0, 1.2, size=(3, 40, 50)).astype(np.float32)
+    colors = rng.uniform(0, 1, size=(4, 3)).astype(np.float32)
+    img[:, :10, :10] = colors[2][:, None, None] + 0.03
+    depth = rng.uniform(0, 60, size=(40, 50)).astype(np.float32)
+    m = oracle.color_masks(img, colors, 0.1)
+    hwc = img.transpose(1, 2, 0)
+    for k in range(4):
+        np.testing.assert_array_equal(m[k].astype(bool), np.linalg.norm(hwc - colors[k], axis=2) <= 0.1)
+    rgb8, mm = oracle.quantize(img, depth)
+    np.testing.assert_array_equal(rgb8, (hwc * 255).astype(np.uint8))
+    np.testing.assert_array_equal(mm, (depth * 1000).astype(np.uint16))

@@ -1,0 +1,74 @@
+"""The N>1 path on CPU: world_size-2 gloo processes, view sharding + frame gather (no rendering: the frame
+'renderer' is a deterministic stub, because the rasterizer has no CPU path by design)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _stub_frames(indices, h=6, w=5):
+    idx = torch.tensor(indices, dtype=torch.float32).view(-1, 1, 1, 1)
+    color = idx + torch.arange(3, dtype=torch.float32).view(1, 3, 1, 1) * 0.25 + torch.zeros(1, 3, h, w)
+    masks = (torch.tensor(indices).view(-1, 1, 1, 1) % 3 == torch.arange(2).view(1, 2, 1, 1)).to(torch.uint8) \
+        + torch.zeros(1, 2, h, w, dtype=torch.uint8)
+    return dict(color=color, masks=masks)
+
+
+def _worker(rank, world, port, n_views, batch, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pegasus_amd import view_shard as vs
+        calls = []
+
+        def render_batch(indices):
+            calls.append(list(indices))
+            return _stub_frames(indices)
+        out = vs.render_sharded(n_views, render_batch, batch, gather=True, dst=0)
+        mine = vs.shard_indices(n_views, rank, world)
+        assert [i for c in calls for i in c] == mine
+        assert all(len(c) <= batch for c in calls)
+        if rank == 0:
+            expect = _stub_frames(list(range(n_views)))
+            ok = all(torch.equal(out[k], expect[k]) for k in expect)
+            q.put(("ok" if ok else "mismatch", rank))
+        else:
+            q.put(("ok" if out is None else "non-root got frames", rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_views,batch", [(7, 2), (8, 4), (1, 3)])
+def test_two_rank_shard_and_gather(n_views, batch):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_views, batch, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [("ok", 0), ("ok", 1)]
+
+
+def test_shard_indices_partition():
+    from pegasus_amd import view_shard as vs
+    for n in (0, 1, 7, 4096):
+        for world in (1, 2, 8):
+            parts = [vs.shard_indices(n, r, world) for r in range(world)]
+            assert sorted(i for p in parts for i in p) == list(range(n))
+            assert max(len(p) for p in parts) == (vs.max_local(n, world) if n else 0)
