@@ -6,6 +6,7 @@
 // one v_exp_f32.  The tile's list is staged through LDS in batches so each entry's 44 B is
 // fetched from HBM/L2 once per tile and then broadcast-read by all four waves.
 #pragma once
+#include "cull.hip.h"
 #include "pgr_common.h"
 
 namespace pgr {
@@ -156,9 +157,11 @@ __global__ __launch_bounds__(WAVE) void composite_wave_kernel(const ViewEntry* _
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
 
-    __shared__ float4 s_a[2][WAVE_BATCH];  // x, y, hx, ny
-    __shared__ float4 s_b[2][WAVE_BATCH];  // hz, opacity, r, g
-    __shared__ float2 s_c[2][WAVE_BATCH];  // b, depth
+    constexpr int PADDED = WAVE_BATCH + 8;        // room for the null entries that pad a batch to a multiple of 8
+    __shared__ float4 s_a[2][PADDED];   // x, y, hx, ny
+    __shared__ float4 s_b[2][PADDED];   // hz, opacity, r, g
+    __shared__ float2 s_c[2][PADDED];   // b, depth
+    __shared__ uint32_t s_i[2][PADDED]; // 1-based position in the tile's list (n_contrib bookkeeping)
 
     f32x2 T = {1.0f, 1.0f}, Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f}, D = {0.f, 0.f};
     uint32_t last0 = 0, last1 = 0;
@@ -174,12 +177,34 @@ __global__ __launch_bounds__(WAVE) void composite_wave_kernel(const ViewEntry* _
         cd = rgbd[g];
     }
 
+    // the wave's pixel-centre rectangle (clipped to the image), for the per-entry skip test
+    const float rx0 = (float)(tile_x * TILE), ry0 = (float)(tile_y * TILE + half * HALF_ROWS);
+    const float rx1 = fminf(rx0 + (float)(TILE - 1), (float)(W - 1));
+    const float ry1 = fminf(ry0 + (float)(HALF_ROWS - 1), (float)(H - 1));
+
     int buf = 0;
     for (int base = 0; base < n; base += WAVE_BATCH, buf ^= 1) {
-        // park the prefetched batch (entries past the end are null splats: opacity 0 -> never valid)
-        s_a[buf][lane] = make_float4(p.x, p.y, -0.5f * co.x, -co.y);
-        s_b[buf][lane] = make_float4(-0.5f * co.z, co.w, cd.x, cd.y);
-        s_c[buf][lane] = make_float2(cd.z, cd.w);
+        // Skip + compact: lane j decides whether ITS entry can reach alpha >= 1/255 anywhere in this wave's
+        // 16x8 pixels (same conservative predicate as the binning, on the half tile).  Entries that cannot are
+        // no-ops for every lane, so only the live ones are parked in LDS, compacted in list order; the batch is
+        // padded to a multiple of 8 with null splats (opacity 0 -> never valid) for the unrolled loop.
+        const bool live = base + lane < n && rect_may_contribute(make_cull_splat(p, co), rx0, ry0, rx1, ry1);
+        const unsigned long long mask = __ballot(live);
+        const int cnt = __popcll(mask);
+        const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (live) {
+            s_a[buf][pos] = make_float4(p.x, p.y, -0.5f * co.x, -co.y);
+            s_b[buf][pos] = make_float4(-0.5f * co.z, co.w, cd.x, cd.y);
+            s_c[buf][pos] = make_float2(cd.z, cd.w);
+            if (AUX) s_i[buf][pos] = (uint32_t)(base + lane + 1);
+        }
+        if (lane < 8) {
+            s_a[buf][cnt + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            s_b[buf][cnt + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            s_c[buf][cnt + lane] = make_float2(0.f, 0.f);
+            if (AUX) s_i[buf][cnt + lane] = 0u;
+        }
         __syncthreads();
         // issue the gather of the NEXT batch now; it lands while this batch is composited
         p = make_float2(0.f, 0.f);
@@ -191,7 +216,6 @@ __global__ __launch_bounds__(WAVE) void composite_wave_kernel(const ViewEntry* _
             co = conic_opacity[g];
             cd = rgbd[g];
         }
-        const int cnt = min(WAVE_BATCH, n - base);
         for (int j0 = 0; j0 < cnt; j0 += 8) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -225,7 +249,7 @@ __global__ __launch_bounds__(WAVE) void composite_wave_kernel(const ViewEntry* _
                 D = __builtin_elementwise_fma((f32x2){c.y, c.y}, w, D);
                 T = __builtin_elementwise_fma(-aeff, T, T);
                 if (AUX) {
-                    const uint32_t idx = (uint32_t)(base + j + 1);
+                    const uint32_t idx = s_i[buf][j];
                     last0 = b0 ? idx : last0;
                     last1 = b1 ? idx : last1;
                 }

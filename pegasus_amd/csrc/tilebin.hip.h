@@ -21,6 +21,7 @@
 //
 // Everything is integer/bit work: bit-exact against the oracle's sorted lists.
 #pragma once
+#include "cull.hip.h"
 #include "pgr_common.h"
 
 namespace pgr {
@@ -49,56 +50,6 @@ struct BinView {                 // per-view pointers used by the binning kernel
     uint64_t* alt;               // [max_instances] second key buffer for lists beyond the LDS tiers
 };
 
-
-// ---- tight-list predicate ----------------------------------------------------------------------
-// A (Gaussian, tile) instance only matters if alpha = min(0.99, op*exp(power)) >= 1/255 at some pixel of the
-// tile.  With q = A dx^2 + 2B dx dy + C dy^2 (power = -q/2) that needs q <= 2 ln(255 op) somewhere.  The
-// test bounds q from BELOW over the tile's continuous pixel rectangle (0 if the centre is inside, else the
-// smallest of the four edge minima of the convex form) and 2 ln(255 op) from ABOVE (exponent + chord of
-// log2 on the mantissa + 0.0861), adds a rounding margin, and keeps the instance unless the lower bound
-// clears the upper bound.  Dropped instances would be skipped at every pixel, so no pixel's arithmetic
-// changes (oracle: pgr_oracle_tile_may_contribute, same operation order, bit-identical decisions; measured
-// on the C3 scene: 55-63 % of the 3-sigma-rectangle instances survive).
-__device__ __forceinline__ float edge_min_q(float A, float B, float C, float r, float d_fixed, float lo, float hi) {
-    // minimise over t in [lo,hi]:  A*d^2 + 2*B*d*t + C*t^2   with r = B / C precomputed per Gaussian
-    float t = -(d_fixed * r);
-    t = fminf(hi, fmaxf(lo, t));
-    return A * d_fixed * d_fixed + 2.0f * B * d_fixed * t + C * t * t;
-}
-
-struct CullSplat { float mx, my, A, B, C, rBC, rBA, tau; uint32_t flags; };   // flags: 1 = never, 2 = always
-
-__device__ __forceinline__ CullSplat make_cull_splat(float2 xy, float4 co) {
-    CullSplat s;
-    s.mx = xy.x; s.my = xy.y; s.A = co.x; s.B = co.y; s.C = co.z;
-    s.flags = (co.w < ALPHA_MIN ? 1u : 0u)                      // alpha <= op < 1/255 at every pixel, exactly
-            | ((!(co.x > 0.0f) || !(co.z > 0.0f)) ? 2u : 0u);   // degenerate conic: no claim
-    s.rBC = co.y / co.z;
-    s.rBA = co.y / co.x;
-    const float t = 255.0f * co.w;
-    const uint32_t bits = __float_as_uint(t);
-    const float e = (float)((int)((bits >> 23) & 0xffu) - 127);
-    const float m = __uint_as_float((bits & 0x007fffffu) | 0x3f800000u);
-    s.tau = 1.3862944f * (e + (m - 1.0f) + 0.0861f);
-    return s;
-}
-
-__device__ __forceinline__ bool tile_may_contribute(const CullSplat& s, int tx, int ty, int W, int H) {
-    if (s.flags & 1u) return false;
-    if (s.flags & 2u) return true;
-    const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
-    const float x1 = fminf(x0 + (float)(TILE - 1), (float)(W - 1));
-    const float y1 = fminf(y0 + (float)(TILE - 1), (float)(H - 1));
-    if (s.mx >= x0 && s.mx <= x1 && s.my >= y0 && s.my <= y1) return true;
-    const float dx0 = x0 - s.mx, dx1 = x1 - s.mx, dy0 = y0 - s.my, dy1 = y1 - s.my;
-    float q = edge_min_q(s.A, s.B, s.C, s.rBC, dx0, dy0, dy1);
-    q = fminf(q, edge_min_q(s.A, s.B, s.C, s.rBC, dx1, dy0, dy1));
-    q = fminf(q, edge_min_q(s.C, s.B, s.A, s.rBA, dy0, dx0, dx1));
-    q = fminf(q, edge_min_q(s.C, s.B, s.A, s.rBA, dy1, dx0, dx1));
-    const float DX = fmaxf(fabsf(dx0), fabsf(dx1)), DY = fmaxf(fabsf(dy0), fabsf(dy1));
-    const float M = s.A * DX * DX + 2.0f * fabsf(s.B) * DX * DY + s.C * DY * DY;
-    return !(q > s.tau + 0.00001f * M + 0.01f);       // a NaN anywhere keeps the instance
-}
 
 // Both binning passes walk the same candidate space: every tile of every Gaussian's rectangle.  Rectangle
 // areas vary from 1 to hundreds of tiles, so a loop per Gaussian leaves most lanes idle (measured 6x on
