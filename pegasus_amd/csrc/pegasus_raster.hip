@@ -111,7 +111,7 @@ static ViewWs carve(char* ws, const Layout& L) {
 
 // Batch header placed in front of the per-view slices.
 struct BatchLayout {
-    size_t view_table, bin_table, order_classes, work_order, views, total;
+    size_t view_table, bin_table, pre_table, cams, order_classes, work_order, views, total;
     size_t per_view;
 };
 
@@ -121,6 +121,8 @@ static BatchLayout make_batch_layout(const Layout& L, int n_views) {
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes ? bytes : 1); return o; };
     B.view_table = take((size_t)n_views * sizeof(ViewEntry));
     B.bin_table = take((size_t)n_views * sizeof(BinView));
+    B.pre_table = take((size_t)n_views * sizeof(PreOut));
+    B.cams = take((size_t)n_views * sizeof(CameraDev));
     B.order_classes = take((ORDER_CLASSES + 1) * 4);
     B.work_order = take((size_t)n_views * L.tiles * 2 * 4);
     B.views = off;
@@ -182,14 +184,18 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     char* ws = static_cast<char*>(workspace);
     auto* view_table = reinterpret_cast<ViewEntry*>(ws + B.view_table);
     auto* bin_table = reinterpret_cast<BinView*>(ws + B.bin_table);
+    auto* pre_table = reinterpret_cast<PreOut*>(ws + B.pre_table);
+    auto* cams_dev = reinterpret_cast<CameraDev*>(ws + B.cams);
     auto* classes = reinterpret_cast<uint32_t*>(ws + B.order_classes);
     auto* work_order = reinterpret_cast<uint32_t*>(ws + B.work_order);
     std::vector<ViewWs> vw((size_t)n_views);
     std::vector<ViewEntry> table((size_t)n_views);
     std::vector<BinView> bins((size_t)n_views);
+    std::vector<PreOut> pres((size_t)n_views);
     bool want_aux = false;
     for (int v = 0; v < n_views; ++v) {
         vw[v] = carve(ws + B.views + (size_t)v * B.per_view, L);
+        vw[v].cam = cams_dev + v;   // cameras of a batch are contiguous: preprocess walks them
         ViewEntry& e = table[v];
         memset(&e, 0, sizeof(e));
         e.cam = vw[v].cam; e.ranges = vw[v].ranges; e.gauss_sorted = vw[v].gauss_sorted; e.xy = vw[v].xy;
@@ -199,11 +205,16 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         want_aux = want_aux || outs[v].final_T || outs[v].n_contrib;
         bins[v] = BinView{vw[v].rects, vw[v].depth, vw[v].xy, vw[v].conop, vw[v].tile_count, vw[v].rel, vw[v].ranges,
                           vw[v].counters, vw[v].bucket, vw[v].gauss_sorted, vw[v].alt};
+        // radii is part of the per-view contract; when the caller does not want it, it lands in the workspace
+        pres[v] = PreOut{vw[v].xy, vw[v].depth, vw[v].conop, vw[v].rgbd, vw[v].rects,
+                         outs[v].radii ? outs[v].radii : vw[v].radii};
     }
     if (!hip_ok(hipMemcpyAsync(view_table, table.data(), table.size() * sizeof(ViewEntry), hipMemcpyHostToDevice,
                                stream), "memcpy view table") ||
         !hip_ok(hipMemcpyAsync(bin_table, bins.data(), bins.size() * sizeof(BinView), hipMemcpyHostToDevice, stream),
-                "memcpy bin table"))
+                "memcpy bin table") ||
+        !hip_ok(hipMemcpyAsync(pre_table, pres.data(), pres.size() * sizeof(PreOut), hipMemcpyHostToDevice, stream),
+                "memcpy pre table"))
         return PGR_ERR_LAUNCH_FAILURE;
 
     // ---- stage 0: camera pack + per-Gaussian preprocess
@@ -212,10 +223,13 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         const PgrCamera& c = cams[v];
         pack_camera_kernel<<<1, 64, 0, stream>>>(c.viewmatrix, c.projmatrix, c.campos, c.bg, c.tanfovx, c.tanfovy, W, H,
                                                  vw[v].cam);
-        // radii is part of the per-view contract; when the caller does not want it, it lands in the workspace
-        PreOut po{vw[v].xy, vw[v].depth, vw[v].conop, vw[v].rgbd, vw[v].rects,
-                  outs[v].radii ? outs[v].radii : vw[v].radii};
-        preprocess_kernel<<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, vw[v].cam, po);
+    }
+    // one pass over the Gaussians for the whole batch (scene data read once, per-view outputs written)
+    switch (scene->shs ? scene->sh_degree : 0) {
+        case 0: preprocess_batch_kernel<0><<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, cams_dev, pre_table, n_views); break;
+        case 1: preprocess_batch_kernel<1><<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, cams_dev, pre_table, n_views); break;
+        case 2: preprocess_batch_kernel<2><<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, cams_dev, pre_table, n_views); break;
+        default: preprocess_batch_kernel<3><<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, cams_dev, pre_table, n_views); break;
     }
     mark(1);
     // ---- stage 1: per-chunk LDS tile histograms + slice reservation, then the tile scan (device only)

@@ -128,15 +128,62 @@ struct PreOut {
     int32_t* radii;
 };
 
-__global__ __launch_bounds__(PRE_BLOCK) void preprocess_kernel(PgrScene sc, const CameraDev* __restrict__ camp,
-                                                               PreOut o) {
-    const CameraDev& cam = *camp;
-    const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
-    int radius = 0;
-    uint2 rect = make_uint2(0u, 0u);
+// SH coefficients of one Gaussian held in registers across the views of a batch.
+struct ShRegs { float v[48]; };
 
-    if (i < sc.n) {
-        const float px = sc.means3d[3 * i + 0], py = sc.means3d[3 * i + 1], pz = sc.means3d[3 * i + 2];
+template <int DEG>
+__device__ __forceinline__ float3 sh_regs_to_rgb(const ShRegs& sh, float dx, float dy, float dz) {
+    float b[16];
+    sh_basis<DEG>(dx, dy, dz, b);
+    constexpr int NC = (DEG + 1) * (DEG + 1);
+    float acc[3];
+    acc[0] = b[0] * sh.v[0];
+    acc[1] = b[0] * sh.v[1];
+    acc[2] = b[0] * sh.v[2];
+#pragma unroll
+    for (int k = 1; k < NC; ++k) {
+        acc[0] = fmaf(b[k], sh.v[3 * k + 0], acc[0]);
+        acc[1] = fmaf(b[k], sh.v[3 * k + 1], acc[1]);
+        acc[2] = fmaf(b[k], sh.v[3 * k + 2], acc[2]);
+    }
+    return make_float3(fmaxf(acc[0] + 0.5f, 0.0f), fmaxf(acc[1] + 0.5f, 0.0f), fmaxf(acc[2] + 0.5f, 0.0f));
+}
+
+template <int DEG>
+__device__ __forceinline__ void load_sh(ShRegs& sh, const float* __restrict__ p, bool vec4) {
+    constexpr int NF = 3 * (DEG + 1) * (DEG + 1);
+    if (vec4 && NF % 4 == 0) {                   // 16-B aligned rows (stride 16 coefficients): 12 x dwordx4 at degree 3
+#pragma unroll
+        for (int k = 0; k < NF / 4; ++k) {
+            const float4 q = reinterpret_cast<const float4*>(p)[k];
+            sh.v[4 * k + 0] = q.x; sh.v[4 * k + 1] = q.y; sh.v[4 * k + 2] = q.z; sh.v[4 * k + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NF; ++k) sh.v[k] = p[k];
+    }
+}
+
+// One thread per Gaussian, ALL views of the batch: the 236 B of scene data are read from HBM once per
+// batch instead of once per view (the view-independent 3D covariance is also built once), which turns the
+// kernel from read-bound (~356 MB/view) into write-bound (12 N + 44 V per view).  Per-view arithmetic is
+// unchanged, so the outputs are bit-identical to the single-view form and to the oracle.
+template <int DEG>
+__global__ __launch_bounds__(PRE_BLOCK) void preprocess_batch_kernel(PgrScene sc, const CameraDev* __restrict__ cams,
+                                                                     const PreOut* __restrict__ outs, int n_views) {
+    const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
+    if (i >= sc.n) return;
+    const float px = sc.means3d[3 * i + 0], py = sc.means3d[3 * i + 1], pz = sc.means3d[3 * i + 2];
+    float cov[6];
+    bool have_cov = false, have_sh = false;
+    ShRegs sh;
+    const bool vec4 = (sc.sh_stride * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(sc.shs) & 15u) == 0;
+
+    for (int v = 0; v < n_views; ++v) {
+        const CameraDev& cam = cams[v];
+        const PreOut& o = outs[v];
+        int radius = 0;
+        uint2 rect = make_uint2(0u, 0u);
         const float* vm = cam.view;
         const float* pm = cam.proj;
         float tx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
@@ -148,17 +195,17 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_kernel(PgrScene sc, cons
             const float hw = pm[3] * px + pm[7] * py + pm[11] * pz + pm[15];
             const float p_w = 1.0f / (hw + 0.0000001f);
             const float ndc_x = hx * p_w, ndc_y = hy * p_w;
-
-            float cov[6];
-            if (sc.cov3d_precomp) {
+            if (!have_cov) {
+                if (sc.cov3d_precomp) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) cov[k] = sc.cov3d_precomp[6 * (size_t)i + k];
-            } else {
-                const float4 q = reinterpret_cast<const float4*>(sc.rotations)[i];
-                cov3d_from_scale_rot(sc.scales[3 * i + 0], sc.scales[3 * i + 1], sc.scales[3 * i + 2],
-                                     sc.scale_modifier, q, cov);
+                    for (int k = 0; k < 6; ++k) cov[k] = sc.cov3d_precomp[6 * (size_t)i + k];
+                } else {
+                    const float4 q = reinterpret_cast<const float4*>(sc.rotations)[i];
+                    cov3d_from_scale_rot(sc.scales[3 * i + 0], sc.scales[3 * i + 1], sc.scales[3 * i + 2],
+                                         sc.scale_modifier, q, cov);
+                }
+                have_cov = true;
             }
-
             const float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
             const float txtz = tx / tz, tytz = ty / tz;
             tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
@@ -183,7 +230,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_kernel(PgrScene sc, cons
             const float c_xx = dot3_chain(U0[0], T0[0], U0[1], T0[1], U0[2], T0[2]) + LOWPASS;
             const float c_xy = dot3_chain(U0[0], T1[0], U0[1], T1[1], U0[2], T1[2]);
             const float c_yy = dot3_chain(U1[0], T1[0], U1[1], T1[1], U1[2], T1[2]) + LOWPASS;
-
             const float det = c_xx * c_yy - c_xy * c_xy;
             if (det != 0.0f) {
                 const float det_inv = 1.0f / det;
@@ -203,16 +249,14 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_kernel(PgrScene sc, cons
                         rgb = make_float3(sc.colors_precomp[3 * (size_t)i], sc.colors_precomp[3 * (size_t)i + 1],
                                           sc.colors_precomp[3 * (size_t)i + 2]);
                     } else {
+                        if (!have_sh) {
+                            load_sh<DEG>(sh, sc.shs + (size_t)i * sc.sh_stride * 3, vec4);
+                            have_sh = true;
+                        }
                         float dx = px - cam.campos[0], dy = py - cam.campos[1], dz = pz - cam.campos[2];
                         const float len = sqrtf(dx * dx + dy * dy + dz * dz);
                         dx = dx / len; dy = dy / len; dz = dz / len;
-                        const float* sh = sc.shs + (size_t)i * sc.sh_stride * 3;
-                        switch (sc.sh_degree) {
-                            case 0: rgb = sh_to_rgb<0>(sh, dx, dy, dz); break;
-                            case 1: rgb = sh_to_rgb<1>(sh, dx, dy, dz); break;
-                            case 2: rgb = sh_to_rgb<2>(sh, dx, dy, dz); break;
-                            default: rgb = sh_to_rgb<3>(sh, dx, dy, dz); break;
-                        }
+                        rgb = sh_regs_to_rgb<DEG>(sh, dx, dy, dz);
                     }
                     radius = rad;
                     rect = make_uint2((uint32_t)r.minx | ((uint32_t)r.miny << 16),
@@ -227,13 +271,13 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_kernel(PgrScene sc, cons
         o.radii[i] = radius;
         o.rects[i] = rect;
     }
-
 }
 
 // packs the caller's four device-side camera tensors + host scalars into one CameraDev
 __global__ void pack_camera_kernel(const float* __restrict__ view, const float* __restrict__ proj,
                                    const float* __restrict__ campos, const float* __restrict__ bg, float tanfovx,
                                    float tanfovy, int width, int height, CameraDev* out) {
+    // one launch per view: the four tensors come from the caller as separate device pointers
     const int t = threadIdx.x;
     if (t < 16) {
         out->view[t] = view[t];
