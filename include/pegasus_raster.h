@@ -144,6 +144,27 @@ int32_t pgr_forward_batch_profiled(const PgrScene *scene, int32_t n_views, const
 int32_t pgr_workspace_view(void *workspace, size_t workspace_bytes, int32_t n, int32_t width, int32_t height,
                            int64_t max_instances, int32_t n_views, int32_t view_index, PgrWorkspaceView *view);
 
+/* Rigid pose of one object, host struct (copied into the launch).  R row-major, q = R as a unit quaternion
+ * (w,x,y,z), D1/D2/D3 = real-SH band rotation matrices (row-major, c' = D c) for the rasterizer's basis. */
+typedef struct PgrObjectPose {
+    float R[9];
+    float t[3];
+    float center[3];
+    float q[4];
+    float D1[9], D2[25], D3[49];
+} PgrObjectPose;
+
+/* Scene composition (replaces GaussianModel.apply_transformation + merge_gaussians,
+ * /root/reference/src/gs/gaussian_model.py:482-546,584-591, called per frame at pegasus.py:255-264,387-390):
+ *   out_xyz[i]  = R (xyz[i] - center) + center + t
+ *   out_rot[i]  = q (x) normalise(rot[i])                    (skipped when rot or out_rot is NULL)
+ *   out_rest[i] = band-wise D_l * f_rest[i]                  (n_rest in {0,3,8,15} coefficients of 3 floats)
+ * Input rows of f_rest are in_rest_stride floats apart, output rows out_rest_stride floats apart, so the output can
+ * point INTO a merged [N,16,3] feature tensor (base + 3 floats, stride 48).  In-place operation is allowed. */
+int32_t pgr_compose_object(int32_t n, const float *xyz, const float *rot, const float *f_rest, int32_t n_rest,
+                           int32_t in_rest_stride, const PgrObjectPose *pose, float *out_xyz, float *out_rot,
+                           float *out_rest, int32_t out_rest_stride, void *stream);
+
 /* present[i] = 1 iff Gaussian i passes the near-plane test of `viewmatrix` (device [16]). */
 int32_t pgr_mark_visible(int32_t n, const float *means3d, const float *viewmatrix, uint8_t *present,
                          void *stream);

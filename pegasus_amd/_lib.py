@@ -40,6 +40,11 @@ class PgrOutputs(C.Structure):
                 ("n_contrib", C.c_void_p)]
 
 
+class PgrObjectPose(C.Structure):
+    _fields_ = [("R", C.c_float * 9), ("t", C.c_float * 3), ("center", C.c_float * 3), ("q", C.c_float * 4),
+                ("D1", C.c_float * 9), ("D2", C.c_float * 25), ("D3", C.c_float * 49)]
+
+
 class PgrWorkspaceView(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("xy", "depth", "conic_opacity", "rgb", "rects", "gauss_sorted", "ranges",
                                           "num_instances")]
@@ -62,6 +67,9 @@ SYMBOLS = {
                                                C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_float)]),
     "pgr_workspace_view": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                        C.c_int32, C.c_int32, C.POINTER(PgrWorkspaceView)]),
+    "pgr_compose_object": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                       C.POINTER(PgrObjectPose), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                       C.c_void_p]),
     "pgr_mark_visible": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgr_color_masks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
                                     C.c_void_p, C.c_void_p]),

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <vector>
 
+#include "compose.hip.h"
 #include "composite.hip.h"
 #include "pgr_common.h"
 #include "preprocess.hip.h"
@@ -365,6 +366,21 @@ int32_t pgr_forward_batch_profiled(const PgrScene* scene, int32_t n_views, const
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
     return rc;
+}
+
+int32_t pgr_compose_object(int32_t n, const float* xyz, const float* rot, const float* f_rest, int32_t n_rest,
+                           int32_t in_rest_stride, const PgrObjectPose* pose, float* out_xyz, float* out_rot,
+                           float* out_rest, int32_t out_rest_stride, void* stream_v) {
+    static_assert(sizeof(PgrObjectPose) == sizeof(ObjectPoseDev), "pose layout");
+    if (n < 0 || !pose || (n > 0 && (!xyz || !out_xyz)) || (n_rest != 0 && n_rest != 3 && n_rest != 8 && n_rest != 15) ||
+        (f_rest && n_rest > 0 && (in_rest_stride < 3 * n_rest || out_rest_stride < 3 * n_rest)))
+        return PGR_ERR_INVALID_ARGUMENT;
+    if (n == 0) return PGR_OK;
+    ObjectPoseDev P;
+    memcpy(&P, pose, sizeof(P));
+    compose_object_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream_v)>>>(
+        n, xyz, rot, f_rest, n_rest, in_rest_stride, P, out_xyz, out_rot, out_rest, out_rest_stride);
+    return hip_ok(hipGetLastError(), "compose_object launch") ? PGR_OK : PGR_ERR_LAUNCH_FAILURE;
 }
 
 int32_t pgr_mark_visible(int32_t n, const float* means3d, const float* viewmatrix, uint8_t* present, void* stream_v) {

@@ -1,0 +1,63 @@
+"""``gaussian_renderer.render`` counterpart: the facade every PEGASUS render path goes through
+(/root/reference/src/gs/render.py:16,57,86,118; /root/reference/pegasus.py:271;
+/root/reference/src/gs/gs_viewer.py:66; /root/reference/src/visualization/object_visualization.py:623).
+
+Contract fixed by its callers: returns a dict with "render" [3,H,W], "depth" [1,H,W],
+"viewspace_points", "visibility_filter" (radii > 0), "radii" (src/gs/render.py:16-17,
+src/gs/dev/gs_manipulation_static.py:311-315)."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from .sh_utils import eval_sh
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
+    """Render the scene ``pc`` (a GaussianModel) from ``viewpoint_camera``.  ``bg_color`` must be on the GPU."""
+    # kept for interface parity: upstream returns the (zero) screen-space points so training can read their grad
+    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, device=pc.get_xyz.device)
+
+    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height),
+        image_width=int(viewpoint_camera.image_width),
+        tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False,
+        debug=getattr(pipe, "debug", False))
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    means3D = pc.get_xyz
+    means2D = screenspace_points
+    opacity = pc.get_opacity
+
+    scales = rotations = cov3D_precomp = None
+    if getattr(pipe, "compute_cov3D_python", False):
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales = pc.get_scaling
+        rotations = pc.get_rotation
+
+    shs = colors_precomp = None
+    if override_color is None:
+        if getattr(pipe, "convert_SHs_python", False):
+            shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            dir_pp = pc.get_xyz - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
+            dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+            sh2rgb = eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized)
+            colors_precomp = torch.clamp_min(sh2rgb + 0.5, 0.0)
+        else:
+            shs = pc.get_features
+    else:
+        colors_precomp = override_color
+
+    rendered_image, radii, depth = rasterizer(
+        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
+        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+
+    return {"render": rendered_image, "depth": depth, "viewspace_points": screenspace_points,
+            "visibility_filter": radii > 0, "radii": radii}
