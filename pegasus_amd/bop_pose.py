@@ -1,0 +1,63 @@
+"""BOP ground-truth pose records on the batch path.
+
+Reference (the surviving copy of the writer): /root/reference/src/tools/pegasus_working.py:441-455,457-576.
+For every frame and object:  T_m2c = T_w2c @ T_m2w  with  T_w2c[:3,:3] = cam.R.T, T_w2c[:3,3] = cam.T
+(pegasus_working.py:464-466);  scene_gt entry = {"cam_R_m2c": 9 floats row-major, "cam_t_m2c": 3 floats,
+"obj_id"};  scene_camera entry = {"cam_K": 9 floats, "depth_scale"} with K from the FoV
+(fov2focal, pegasus_working.py:349-356).  Format: submodules/bop_toolkit/docs/bop_datasets_format.md:75-109.
+
+Quirk kept from the reference and flagged: translations stay in METRES while depth images are written in
+millimetres (pegasus.py:355); set ``translation_scale=1000.0`` for BOP-conformant millimetres.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .graphics import fov2focal
+
+
+def world_to_camera(R_c2w, t_w2c) -> np.ndarray:
+    T = np.eye(4)
+    T[:3, :3] = np.asarray(R_c2w, dtype=np.float64).T
+    T[:3, 3] = np.asarray(t_w2c, dtype=np.float64).reshape(3)
+    return T
+
+
+def camera_K(fovx, fovy, width, height) -> np.ndarray:
+    fx, fy = fov2focal(fovx, width), fov2focal(fovy, height)
+    return np.array([[fx, 0, width / 2.0], [0, fy, height / 2.0], [0, 0, 1.0]])
+
+
+def scene_gt_entry(R_c2w, t_w2c, object_poses_m2w: dict, translation_scale: float = 1.0) -> list:
+    """object_poses_m2w: {obj_id: 4x4 model-to-world}.  Returns the BOP scene_gt list for one image."""
+    T_w2c = world_to_camera(R_c2w, t_w2c)
+    out = []
+    for obj_id, T_m2w in object_poses_m2w.items():
+        T = T_w2c @ np.asarray(T_m2w, dtype=np.float64)
+        out.append({"cam_R_m2c": T[:3, :3].reshape(-1).tolist(),
+                    "cam_t_m2c": (T[:3, 3] * translation_scale).tolist(), "obj_id": int(obj_id)})
+    return out
+
+
+def scene_camera_entry(fovx, fovy, width, height, R_c2w=None, t_w2c=None, depth_scale: float = 1.0) -> dict:
+    e = {"cam_K": camera_K(fovx, fovy, width, height).reshape(-1).tolist(), "depth_scale": depth_scale}
+    if R_c2w is not None:
+        T = world_to_camera(R_c2w, t_w2c)
+        e["cam_R_w2c"] = T[:3, :3].reshape(-1).tolist()
+        e["cam_t_w2c"] = T[:3, 3].tolist()
+    return e
+
+
+def batch_pose_records(views, object_poses_per_frame, translation_scale: float = 1.0):
+    """views: sequence with R_c2w, t_w2c, fovx, fovy, width, height (pegasus_amd.scenes.View or Camera-like);
+    object_poses_per_frame: one {obj_id: 4x4} dict per view (or a single dict for a static scene)."""
+    gt, cam = {}, {}
+    for i, v in enumerate(views):
+        poses = object_poses_per_frame if isinstance(object_poses_per_frame, dict) else object_poses_per_frame[i]
+        R = getattr(v, "R_c2w", getattr(v, "R", None))
+        t = getattr(v, "t_w2c", getattr(v, "T", None))
+        fx, fy = getattr(v, "fovx", getattr(v, "FoVx", None)), getattr(v, "fovy", getattr(v, "FoVy", None))
+        w, h = getattr(v, "width", getattr(v, "image_width", None)), getattr(v, "height", getattr(v, "image_height", None))
+        gt[str(i)] = scene_gt_entry(R, t, poses, translation_scale)
+        cam[str(i)] = scene_camera_entry(fx, fy, w, h, R, t)
+    return gt, cam

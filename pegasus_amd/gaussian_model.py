@@ -1,0 +1,195 @@
+"""``GaussianModel`` for the render path: the parameter container PEGASUS composes scenes with
+(/root/reference/src/gs/gaussian_model.py).  Same attribute names, getters (activations), PLY layout,
+``merge_gaussians`` / ``mask_points`` and pose methods; training (optimizer, densification) is out of scope
+for this build and raises.
+
+The pose methods run on the device: ``apply_transformation`` is one pgr_compose_object launch instead of the
+reference's GPU -> CPU -> scipy/e3nn -> GPU round trip (gaussian_model.py:499-546)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import compose
+from .ply_io import read_ply_vertices, write_ply_vertices
+
+
+def strip_symmetric(L):
+    return torch.stack([L[:, 0, 0], L[:, 0, 1], L[:, 0, 2], L[:, 1, 1], L[:, 1, 2], L[:, 2, 2]], dim=1)
+
+
+def build_rotation(r):
+    q = r / torch.norm(r, dim=1, keepdim=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.zeros((q.size(0), 3, 3), device=r.device, dtype=r.dtype)
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z); R[:, 0, 1] = 2 * (x * y - w * z); R[:, 0, 2] = 2 * (x * z + w * y)
+    R[:, 1, 0] = 2 * (x * y + w * z); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - w * x)
+    R[:, 2, 0] = 2 * (x * z - w * y); R[:, 2, 1] = 2 * (y * z + w * x); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
+def build_scaling_rotation(s, r):
+    L = torch.zeros((s.shape[0], 3, 3), dtype=s.dtype, device=s.device)
+    L[:, 0, 0], L[:, 1, 1], L[:, 2, 2] = s[:, 0], s[:, 1], s[:, 2]
+    return build_rotation(r) @ L
+
+
+def inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+class GaussianModel:
+    def __init__(self, sh_degree: int, device="cuda"):
+        self.active_sh_degree = 0
+        self.max_sh_degree = sh_degree
+        self.device = torch.device(device)
+        e = torch.empty(0)
+        self._xyz = self._features_dc = self._features_rest = self._scaling = self._rotation = self._opacity = e
+        self.max_radii2D = self.xyz_gradient_accum = self.denom = e
+        self.optimizer = None
+        self.scaling_activation, self.scaling_inverse_activation = torch.exp, torch.log
+        self.opacity_activation, self.inverse_opacity_activation = torch.sigmoid, inverse_sigmoid
+        self.rotation_activation = torch.nn.functional.normalize
+
+    # ---- getters = what the rasterizer is fed (reference :105-128)
+    @property
+    def get_scaling(self):
+        return self.scaling_activation(self._scaling)
+
+    @property
+    def get_rotation(self):
+        return self.rotation_activation(self._rotation)
+
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    @property
+    def get_opacity(self):
+        return self.opacity_activation(self._opacity)
+
+    def get_covariance(self, scaling_modifier=1):
+        L = build_scaling_rotation(scaling_modifier * self.get_scaling, self._rotation)
+        return strip_symmetric(L @ L.transpose(1, 2))
+
+    def oneupSHdegree(self):
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+
+    # ---- construction
+    @classmethod
+    def from_arrays(cls, xyz, features_dc, features_rest, opacity, scaling, rotation, sh_degree=3, device="cuda"):
+        m = cls(sh_degree, device)
+        t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32).to(m.device).contiguous()
+        m._xyz, m._features_dc, m._features_rest = t(xyz), t(features_dc), t(features_rest)
+        m._opacity, m._scaling, m._rotation = t(opacity), t(scaling), t(rotation)
+        m.active_sh_degree = sh_degree
+        return m
+
+    def load_ply(self, path, clean_pcd: bool = False):
+        if clean_pcd:
+            raise NotImplementedError("clean_pcd needs open3d's radius-outlier filter (offline asset step)")
+        v = read_ply_vertices(path)
+        names = v.dtype.names
+        xyz = np.stack([v["x"], v["y"], v["z"]], axis=1)
+        f_dc = np.stack([v["f_dc_0"], v["f_dc_1"], v["f_dc_2"]], axis=1)[:, None, :]           # [N,1,3]
+        extra = sorted((n for n in names if n.startswith("f_rest_")), key=lambda s: int(s.split("_")[-1]))
+        assert len(extra) == 3 * (self.max_sh_degree + 1) ** 2 - 3
+        f_extra = np.stack([v[n] for n in extra], axis=1).reshape(len(v), 3, -1).transpose(0, 2, 1)   # [N,15,3]
+        scales = np.stack([v[n] for n in sorted((n for n in names if n.startswith("scale_")),
+                                                key=lambda s: int(s.split("_")[-1]))], axis=1)
+        rots = np.stack([v[n] for n in sorted((n for n in names if n.startswith("rot")),
+                                              key=lambda s: int(s.split("_")[-1]))], axis=1)
+        t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float, device=self.device)
+        self._xyz, self._features_dc, self._features_rest = t(xyz), t(f_dc), t(f_extra)
+        self._opacity, self._scaling, self._rotation = t(np.asarray(v["opacity"])[:, None]), t(scales), t(rots)
+        self.active_sh_degree = self.max_sh_degree
+
+    def save_ply(self, path):
+        c = lambda x: x.detach().cpu().numpy()
+        xyz, n = c(self._xyz), self._xyz.shape[0]
+        f_dc = c(self._features_dc).transpose(0, 2, 1).reshape(n, -1)
+        f_rest = c(self._features_rest).transpose(0, 2, 1).reshape(n, -1)
+        cols = {"x": xyz[:, 0], "y": xyz[:, 1], "z": xyz[:, 2], "nx": np.zeros(n), "ny": np.zeros(n), "nz": np.zeros(n)}
+        cols.update({f"f_dc_{i}": f_dc[:, i] for i in range(f_dc.shape[1])})
+        cols.update({f"f_rest_{i}": f_rest[:, i] for i in range(f_rest.shape[1])})
+        cols["opacity"] = c(self._opacity)[:, 0]
+        cols.update({f"scale_{i}": c(self._scaling)[:, i] for i in range(3)})
+        cols.update({f"rot_{i}": c(self._rotation)[:, i] for i in range(4)})
+        write_ply_vertices(path, cols)
+
+    # ---- scene composition (reference :482-623)
+    def apply_translation_on_xyz(self, t):
+        self._xyz = self._xyz + torch.as_tensor(t).to(self._xyz.device).type(torch.float32)
+
+    def apply_rotation_on_xyz(self, R, origin=False):
+        R = torch.as_tensor(R).to(self._xyz.device).type(torch.float32)
+        if not origin:
+            mean_xyz = torch.mean(self._xyz, 0)
+            self._xyz = (R @ (self._xyz - mean_xyz).T).T + mean_xyz
+        else:
+            self._xyz = (R @ self._xyz.T).T
+
+    def apply_transformation_on_xyz(self, T):
+        self.apply_rotation_on_xyz(R=T[:3, :3])
+        self.apply_translation_on_xyz(t=T[:3, 3])
+
+    def _pose(self, T, rotate_xyz):
+        T = np.asarray(torch.as_tensor(T).detach().cpu().numpy(), dtype=np.float64)
+        if not rotate_xyz:
+            T = T.copy(); T[:3, 3] = 0
+        center = self._xyz.double().mean(0).cpu().numpy()
+        return compose.make_pose(T, center)
+
+    def apply_rotation_on_splats(self, R):
+        T = np.eye(4); T[:3, :3] = np.asarray(torch.as_tensor(R).detach().cpu().numpy(), dtype=np.float64)
+        xyz_keep = self._xyz.clone()
+        out_rot = torch.empty_like(self._rotation)
+        compose.compose_object(self._xyz.contiguous(), self._rotation.contiguous(), None, self._pose(T, False),
+                               torch.empty_like(self._xyz), out_rot, None)
+        self._rotation, self._xyz = out_rot, xyz_keep
+
+    def apply_rotation_on_sh(self, R):
+        T = np.eye(4); T[:3, :3] = np.asarray(torch.as_tensor(R).detach().cpu().numpy(), dtype=np.float64)
+        out_rest = torch.empty_like(self._features_rest)
+        compose.compose_object(self._xyz.contiguous(), None, self._features_rest.contiguous(), self._pose(T, False),
+                               torch.empty_like(self._xyz), None, out_rest)
+        self._features_rest = out_rest
+
+    def apply_transformation(self, T):
+        """xyz, splat orientation and SH in ONE device pass (reference: three methods, two host round trips)."""
+        Tn = np.asarray(torch.as_tensor(T).detach().cpu().numpy(), dtype=np.float64)
+        pose = compose.make_pose(Tn, self._xyz.double().mean(0).cpu().numpy())
+        xyz, rot, rest = torch.empty_like(self._xyz), torch.empty_like(self._rotation), torch.empty_like(self._features_rest)
+        compose.compose_object(self._xyz.contiguous(), self._rotation.contiguous(), self._features_rest.contiguous(),
+                               pose, xyz, rot, rest)
+        self._xyz, self._rotation, self._features_rest = xyz, rot, rest
+
+    def merge_gaussians(self, gaussian):
+        for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+            setattr(self, k, torch.vstack((getattr(self, k), getattr(gaussian, k))))
+
+    def mask_points(self, mask):
+        if self.optimizer:
+            raise NotImplementedError("optimizer state pruning belongs to training (out of scope)")
+        for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+            setattr(self, k, getattr(self, k)[mask])
+        for k in ("xyz_gradient_accum", "denom", "max_radii2D"):
+            if len(getattr(self, k)) != 0:
+                setattr(self, k, getattr(self, k)[mask])
+
+    def translate_selected_points(self, mask, t):
+        translation = torch.zeros(self._xyz.shape, device=t.device)
+        translation[mask] = + t
+        self._xyz = self._xyz + translation
+
+    # ---- training: not part of this build
+    def training_setup(self, *a, **k):
+        raise NotImplementedError("training (optimizer, densification, backward) is out of scope: SURVEY.md section 8f row 4")
+
+    create_from_pcd = densify_and_prune = training_setup

@@ -1,0 +1,95 @@
+"""PEGASUS's render path through the compat module names: Camera -> render() -> the four wrappers of
+src/gs/render.py, on the GPU, against the oracle."""
+import math
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_render_facade_and_mask_wrappers(oracle, gpu_device):
+    sys.path.insert(0, str(ROOT / "compat"))
+    try:
+        import torch
+        from argparse import ArgumentParser
+        from arguments import PipelineParams                  # noqa: the names PEGASUS imports
+        from gaussian_renderer import render, GaussianModel
+        from scene.cameras import Camera
+        from utils.sh_utils import RGB2SH
+        from pegasus_amd import masks, render as prender, scenes
+        from helpers import assert_images_match
+
+        dev = gpu_device
+        rng = np.random.default_rng(2)
+        env_c = scenes.ground_plane(rng, 15000, 1.0, np.log(0.006), 0.4, 0.1, 0.005)
+        obj_c = [scenes.rigid_transform(scenes.box_object(rng, 5000, (0.1, 0.12, 0.16), np.log(0.004), 0.3, 0.2, k + 1),
+                                        np.eye(3), np.array([0.15 * k - 0.08, 0.05 * k, 0.09])) for k in range(2)]
+        mk = lambda c: GaussianModel.from_arrays(c.xyz, c.features_dc, c.features_rest, c.opacity, c.scaling,
+                                                 c.rotation, device=dev)
+        env, objs = mk(env_c), {k + 1: mk(c) for k, c in enumerate(obj_c)}
+        colors = torch.from_numpy(masks.generate_colors(len(objs))).to(dev)
+        prender.assign_semantic_colors(objs, colors)
+
+        v = scenes.scene_c3(scale=0.001, n_views=1, width=320, height=240)[1][0]
+        H, W = v.height, v.width
+        cam = Camera(colmap_id=0, R=v.R_c2w, T=v.t_w2c, FoVx=v.fovx, FoVy=v.fovy, image=torch.empty((3, H, W)),
+                     gt_alpha_mask=None, image_name="0", uid=0, data_device=str(dev))
+        np.testing.assert_allclose(cam.world_view_transform.cpu().numpy(), v.world_view_transform, atol=1e-6)
+        np.testing.assert_allclose(cam.full_proj_transform.cpu().numpy(), v.full_proj_transform, atol=1e-5)
+        pipe = PipelineParams(ArgumentParser())
+        bg = torch.zeros(3, device=dev)
+
+        # full scene = environment + objects in their own colours (pegasus.py:255-264)
+        import copy
+        scene = copy.deepcopy(env)
+        for o in objs.values():
+            scene.merge_gaussians(o)
+        pkg = render(cam, scene, pipe, bg)
+        assert set(pkg) == {"render", "depth", "viewspace_points", "visibility_filter", "radii"}
+        merged = scenes.SplatCloud.concat([env_c, *obj_c])
+        act = merged.activated()
+        # the facade applies torch's activations on the device; feed the oracle those exact values
+        act = dict(means3d=scene.get_xyz.cpu().numpy(), opacities=scene.get_opacity.cpu().numpy().reshape(-1),
+                   scales=scene.get_scaling.cpu().numpy(), rotations=scene.get_rotation.cpu().numpy(),
+                   shs=scene.get_features.cpu().numpy())
+        kw = dict(width=W, height=H, tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2),
+                  viewmatrix=cam.world_view_transform.cpu().numpy(), projmatrix=cam.full_proj_transform.cpu().numpy(),
+                  campos=cam.camera_center.cpu().numpy(), bg=np.zeros(3, np.float32))
+        o = oracle.forward(**act, sh_degree=3, num_threads=8, cull_mode=1, **kw)
+        amb = o["ambig"].astype(bool)
+        assert np.abs(pkg["render"].cpu().numpy() - o["color"])[:, ~amb].max() <= 1e-4
+        assert np.abs(pkg["depth"].cpu().numpy() - o["out_depth"])[:, ~amb].max() <= 1e-4
+        np.testing.assert_array_equal(pkg["radii"].cpu().numpy(), o["radii"])
+        np.testing.assert_array_equal(pkg["visibility_filter"].cpu().numpy(), o["radii"] > 0)
+
+        rgb, depth = prender.render_rgb_and_depth(cam, scene, pipe, bg)
+        assert tuple(rgb.shape) == (H, W, 3) and tuple(depth.shape) == (H, W, 1) and rgb.device.type == "cpu"
+
+        # masks: wrappers == oracle semantic render + colour-distance rule (render.py:68-97, 36-65)
+        vis, seg = prender.render_visib_mask(cam, env, objs, colors, H, W, pipe, bg)
+        assert vis.shape == (H, W, 2) and vis.dtype == np.float64 and tuple(seg.shape) == (H, W, 3)
+        n_env = env_c.n
+        sem_shs = np.zeros((merged.n - n_env, 16, 3), np.float32)
+        oid = merged.object_id[n_env:]
+        sem_shs[:, 0] = RGB2SH(colors.cpu().numpy()[oid - 1])
+        so = oracle.forward(act["means3d"][n_env:], act["opacities"][n_env:], scales=act["scales"][n_env:],
+                            rotations=act["rotations"][n_env:], shs=sem_shs, sh_degree=3, num_threads=8, **kw)
+        assert np.abs(seg.numpy().transpose(2, 0, 1) - so["color"])[:, ~so["ambig"].astype(bool)].max() <= 1e-4
+        ref_masks = oracle.color_masks(so["color"], colors.cpu().numpy(), 0.1)
+        dist = np.stack([np.linalg.norm(so["color"].transpose(1, 2, 0) - c, axis=2) for c in colors.cpu().numpy()])
+        decided = (np.abs(dist - 0.1) > 2e-4) & ~so["ambig"].astype(bool)[None]
+        np.testing.assert_array_equal(vis.transpose(2, 0, 1)[decided], ref_masks[decided].astype(np.float64))
+        assert vis.sum() > 100
+
+        sil = prender.render_silhouette_mask(cam, objs, env, W, H, colors, pipe, bg)
+        assert sil.shape == (H, W, 2)
+        assert (sil.sum(axis=(0, 1)) >= vis.sum(axis=(0, 1)) * 0.98).all()   # a silhouette covers the visible part
+        sem = prender.render_semanticsegmentation_mask(cam, env, objs, colors, H, W, pipe, bg, False)
+        assert sem.dtype == np.uint8 and sem.shape == (H, W, 3)
+        np.testing.assert_array_equal(sem, (np.ascontiguousarray(seg.numpy()) * 255).astype("uint8"))
+    finally:
+        sys.path.remove(str(ROOT / "compat"))

@@ -1,0 +1,72 @@
+"""Host-side modules either side of the render path: PLY I/O, BOP pose records, pose interpolation golden."""
+from pathlib import Path
+
+import numpy as np
+
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def test_ply_roundtrip(tmp_path):
+    from pegasus_amd.ply_io import read_ply_vertices, write_ply_vertices
+    rng = np.random.default_rng(0)
+    cols = {k: rng.normal(size=17).astype(np.float32) for k in ["x", "y", "z", "opacity", "f_dc_0", "rot_3"]}
+    write_ply_vertices(tmp_path / "a" / "pc.ply", cols)
+    v = read_ply_vertices(tmp_path / "a" / "pc.ply")
+    assert v.dtype.names == tuple(cols)
+    for k in cols:
+        np.testing.assert_array_equal(v[k], cols[k])
+    # ascii variant
+    txt = "ply\nformat ascii 1.0\nelement vertex 2\nproperty float x\nproperty uchar r\nend_header\n1.5 7\n-2 255\n"
+    (tmp_path / "b.ply").write_text(txt)
+    v = read_ply_vertices(tmp_path / "b.ply")
+    assert v["x"].tolist() == [1.5, -2.0] and v["r"].tolist() == [7, 255]
+
+
+def test_gaussian_model_ply_layout(tmp_path):
+    """f_rest is stored channel-major in the file and coefficient-major in memory (gaussian_model.py:252-268)."""
+    from pegasus_amd.gaussian_model import GaussianModel
+    rng = np.random.default_rng(1)
+    n = 11
+    m = GaussianModel.from_arrays(rng.normal(size=(n, 3)), rng.normal(size=(n, 1, 3)), rng.normal(size=(n, 15, 3)),
+                                  rng.normal(size=(n, 1)), rng.normal(size=(n, 3)), rng.normal(size=(n, 4)),
+                                  device="cpu")
+    m.save_ply(tmp_path / "pc.ply")
+    from pegasus_amd.ply_io import read_ply_vertices
+    v = read_ply_vertices(tmp_path / "pc.ply")
+    assert len(v.dtype.names) == 62
+    # f_rest_k = channel (k // 15), coefficient (k % 15)
+    np.testing.assert_array_equal(v["f_rest_16"], m._features_rest[:, 1, 1].numpy())
+    m2 = GaussianModel(3, device="cpu")
+    m2.load_ply(tmp_path / "pc.ply")
+    for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        np.testing.assert_array_equal(getattr(m2, k).numpy(), getattr(m, k).numpy())
+    assert m2.get_features.shape == (n, 16, 3) and m2.active_sh_degree == 3
+    np.testing.assert_allclose(m2.get_opacity.numpy(), 1 / (1 + np.exp(-m._opacity.numpy())), rtol=1e-6)
+    cov = m2.get_covariance().numpy()
+    assert cov.shape == (n, 6) and (cov[:, [0, 3, 5]] > 0).all()
+
+
+def test_bop_pose_record():
+    from pegasus_amd import bop_pose
+    from scipy.spatial.transform import Rotation as Rot
+    R_c2w = Rot.random(random_state=1).as_matrix()
+    t = np.array([0.1, -0.2, 1.5])
+    T_m2w = np.eye(4); T_m2w[:3, :3] = Rot.random(random_state=2).as_matrix(); T_m2w[:3, 3] = [0.3, 0.1, 0.05]
+    e = bop_pose.scene_gt_entry(R_c2w, t, {7: T_m2w})[0]
+    assert e["obj_id"] == 7
+    Rm2c = np.array(e["cam_R_m2c"]).reshape(3, 3)
+    np.testing.assert_allclose(Rm2c, R_c2w.T @ T_m2w[:3, :3], atol=1e-12)
+    np.testing.assert_allclose(e["cam_t_m2c"], R_c2w.T @ T_m2w[:3, 3] + t, atol=1e-12)
+    # a model point lands where the camera sees it
+    p = np.array([0.02, -0.03, 0.04])
+    np.testing.assert_allclose(Rm2c @ p + e["cam_t_m2c"], R_c2w.T @ (T_m2w[:3, :3] @ p + T_m2w[:3, 3]) + t, atol=1e-12)
+    K = np.array(bop_pose.scene_camera_entry(0.8, 0.6, 640, 480)["cam_K"]).reshape(3, 3)
+    assert K[0, 2] == 320 and K[1, 2] == 240 and abs(K[0, 0] - 320 / np.tan(0.4)) < 1e-9
+    assert bop_pose.scene_gt_entry(R_c2w, t, {7: T_m2w}, translation_scale=1000.0)[0]["cam_t_m2c"][2] == e["cam_t_m2c"][2] * 1000
+
+
+def test_pose_interpolation_matches_reference_golden():
+    from pegasus_amd.pose_interpolation import interpolate_pose
+    g = np.load(GOLD / "pose_interpolation.npz")
+    for p1, p2, t, out in zip(g["pose1"], g["pose2"], g["t"], g["out"]):
+        np.testing.assert_allclose(interpolate_pose(float(t), 0.0, p1, 1.0, p2), out, atol=1e-6)
