@@ -11,6 +11,8 @@
 
 namespace pgr {
 
+constexpr int NUM_XCD = 8;
+constexpr uint32_t INVALID_ITEM = 0xffffffffu;   // unused slot of the interleaved work order
 constexpr int COMP_THREADS = TILE * TILE;  // 256 = 4 waves; wave w owns pixel rows 4w..4w+3
 
 struct CompOut {
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(WAVE) void composite_wave_kernel(const ViewEntry* _
                                                               uint32_t items_per_view,
                                                               const uint32_t* __restrict__ work_order) {
     uint32_t item = work_order ? work_order[blockIdx.x] : blockIdx.x;
+    if (item == INVALID_ITEM) return;
     const uint32_t view = item / items_per_view;
     item -= view * items_per_view;
     const ViewEntry& ve = views[view];
@@ -286,62 +289,96 @@ finished:
 // Work ordering for the wave compositor: half-tile work items sorted by DESCENDING list length
 // (256 log-spaced length classes), so the long lists start first and the short ones back-fill the
 // SIMDs that finish early (longest-processing-time-first).  Order never affects results.
-// counters: [ORDER_CLASSES] zero-filled by the caller; grid = (ceil(tiles/256), n_views)
-__global__ __launch_bounds__(256) void order_count_kernel(const ViewEntry* __restrict__ views, int tiles,
-                                                          uint32_t* __restrict__ class_count) {
-    __shared__ uint32_t hist[ORDER_CLASSES];
-    hist[threadIdx.x] = 0;
+// ---- work order --------------------------------------------------------------------------------
+// The compositor's work items (view, tile, half) are laid out as NUM_XCD interleaved streams: position p
+// belongs to stream p % 8, and the hardware dispatcher is observed to place workgroup b on XCD b % 8
+// (MI355X_MICROARCH.md, a speed hint only -- any placement is correct).  Stream x owns every 8th row of
+// tiles of every view, so the two halves of a tile and its neighbours -- whose lists share most of their
+// Gaussians -- are gathered through the SAME XCD's L2 (measured before: 486 MB/view fetched from the fabric
+// for 161 MB of algorithmic bytes).  Inside a stream items are sorted by descending list length (256 log-spaced
+// classes) so long lists start first and short ones back-fill.  Unused slots hold INVALID_ITEM.
+
+// order_state layout (uint32): [NUM_XCD * ORDER_CLASSES] class counters -> cursors, then [1] number of long lists
+constexpr int ORDER_STATE_WORDS = NUM_XCD * ORDER_CLASSES + 1;
+
+// Tile ROWS are dealt to the streams round-robin (row y -> stream y % 8): a contiguous band per XCD would
+// share more vertically but leaves XCDs idle when the image's work is uneven (measured: 1.9x slower on C3);
+// striping keeps every XCD's share statistically equal and still keeps a tile's two halves and its
+// horizontal neighbours -- most of the sharing -- on one L2.
+__device__ __forceinline__ int xcd_of_tile(int tile, int grid_x, int grid_y) {
+    (void)grid_y;
+    return (tile / grid_x) % NUM_XCD;
+}
+
+__host__ __device__ inline int max_band_rows(int grid_y) { return (grid_y + NUM_XCD - 1) / NUM_XCD; }
+
+// grid = (ceil(tiles/256), n_views), 256 threads
+__global__ __launch_bounds__(256) void order_count_kernel(const ViewEntry* __restrict__ views, int tiles, int grid_x,
+                                                          int grid_y, uint32_t* __restrict__ state) {
+    __shared__ uint32_t hist[NUM_XCD * ORDER_CLASSES];
+    for (int k = threadIdx.x; k < NUM_XCD * ORDER_CLASSES; k += 256) hist[k] = 0;
     __syncthreads();
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < tiles) {
         const uint2 r = views[blockIdx.y].ranges[t];
-        const int c = min(length_class(r.y - r.x), ORDER_CLASSES - 1);
-        atomicAdd(&hist[ORDER_CLASSES - 1 - c], 2u);   // descending; two half tiles per tile
+        const int c = ORDER_CLASSES - 1 - min(length_class(r.y - r.x), ORDER_CLASSES - 1);   // descending
+        atomicAdd(&hist[xcd_of_tile(t, grid_x, grid_y) * ORDER_CLASSES + c], 2u);            // two halves per tile
     }
     __syncthreads();
-    if (hist[threadIdx.x]) atomicAdd(&class_count[threadIdx.x], hist[threadIdx.x]);
+    for (int k = threadIdx.x; k < NUM_XCD * ORDER_CLASSES; k += 256)
+        if (hist[k]) atomicAdd(&state[k], hist[k]);
 }
 
-// 1 block of ORDER_CLASSES threads.  class_count[ORDER_CLASSES] (one word past the classes) receives the
-// number of TILES whose class is >= long_class, i.e. the leading work_order pairs the long-list sort visits.
-__global__ void order_scan_kernel(uint32_t* __restrict__ class_count, int long_class) {
+// 1 block of ORDER_CLASSES threads: per stream, exclusive prefix over the classes = write cursors
+__global__ void order_scan_kernel(uint32_t* __restrict__ state) {
     __shared__ uint32_t s[ORDER_CLASSES];
     const int t = threadIdx.x;
-    s[t] = class_count[t];
-    __syncthreads();
-    uint32_t acc = 0;
-    for (int i = 0; i < t; ++i) acc += s[i];
-    class_count[t] = acc;   // exclusive prefix = running cursor of each class
-    if (t == ORDER_CLASSES - long_class) class_count[ORDER_CLASSES] = acc / 2u;   // classes stored descending
+    for (int x = 0; x < NUM_XCD; ++x) {
+        s[t] = state[x * ORDER_CLASSES + t];
+        __syncthreads();
+        uint32_t acc = 0;
+        for (int i = 0; i < t; ++i) acc += s[i];
+        state[x * ORDER_CLASSES + t] = acc;
+        __syncthreads();
+    }
 }
 
-// grid = (ceil(tiles/256), n_views), 256 threads.  Slots are claimed per workgroup: class histogram and local
-// ranks with LDS atomics, then ONE global atomic per (workgroup, non-empty class) -- per-tile global
-// atomics on 256 hot words measured 158 us per 40 k tiles on MI355X.
-__global__ __launch_bounds__(256) void order_scatter_kernel(const ViewEntry* __restrict__ views, int tiles,
-                                                            uint32_t* __restrict__ class_cursor,
-                                                            uint32_t* __restrict__ work_order) {
-    __shared__ uint32_t hist[ORDER_CLASSES];
-    __shared__ uint32_t base[ORDER_CLASSES];
-    hist[threadIdx.x] = 0;
+// grid = (ceil(tiles/256), n_views), 256 threads.  work_order is pre-filled with INVALID_ITEM.  Slots are claimed
+// per workgroup (LDS histogram + ranks, one global atomic per non-empty (stream, class)); tiles whose list
+// exceeds `long_threshold` are also appended to long_list for the large sort tier.
+__global__ __launch_bounds__(256) void order_scatter_kernel(const ViewEntry* __restrict__ views, int tiles, int grid_x,
+                                                            int grid_y, uint32_t* __restrict__ state,
+                                                            uint32_t* __restrict__ work_order, uint32_t long_threshold,
+                                                            uint32_t* __restrict__ long_list) {
+    __shared__ uint32_t hist[NUM_XCD * ORDER_CLASSES];
+    __shared__ uint32_t n_long_s, long_base_s;
+    for (int k = threadIdx.x; k < NUM_XCD * ORDER_CLASSES; k += 256) hist[k] = 0;
+    if (threadIdx.x == 0) n_long_s = 0;
     __syncthreads();
     const int t = blockIdx.x * 256 + threadIdx.x;
-    int c = 0;
-    uint32_t rank = 0;
+    int bin = 0, x = 0;
+    uint32_t rank = 0, long_rank = INVALID_ITEM;
     if (t < tiles) {
         const uint2 r = views[blockIdx.y].ranges[t];
-        c = ORDER_CLASSES - 1 - min(length_class(r.y - r.x), ORDER_CLASSES - 1);
-        rank = atomicAdd(&hist[c], 1u);
+        const uint32_t len = r.y - r.x;
+        x = xcd_of_tile(t, grid_x, grid_y);
+        bin = x * ORDER_CLASSES + ORDER_CLASSES - 1 - min(length_class(len), ORDER_CLASSES - 1);
+        rank = atomicAdd(&hist[bin], 1u);
+        if (len > long_threshold) long_rank = atomicAdd(&n_long_s, 1u);
     }
     __syncthreads();
-    const uint32_t mine = hist[threadIdx.x];
-    if (mine) base[threadIdx.x] = atomicAdd(&class_cursor[threadIdx.x], 2u * mine);
+    for (int k = threadIdx.x; k < NUM_XCD * ORDER_CLASSES; k += 256) {
+        const uint32_t mine = hist[k];
+        if (mine) hist[k] = atomicAdd(&state[k], 2u * mine);      // hist now holds this workgroup's base
+    }
+    if (threadIdx.x == 0 && n_long_s) long_base_s = atomicAdd(&state[NUM_XCD * ORDER_CLASSES], n_long_s);
     __syncthreads();
     if (t < tiles) {
-        const uint32_t pos = base[c] + 2u * rank;
+        const uint32_t r0 = hist[bin] + 2u * rank;                // position inside stream x
         const uint32_t item = (uint32_t)blockIdx.y * 2u * (uint32_t)tiles + 2u * (uint32_t)t;
-        work_order[pos] = item;
-        work_order[pos + 1] = item + 1u;
+        work_order[(size_t)r0 * NUM_XCD + x] = item;
+        work_order[(size_t)(r0 + 1) * NUM_XCD + x] = item + 1u;
+        if (long_rank != INVALID_ITEM) long_list[long_base_s + long_rank] = (uint32_t)blockIdx.y * (uint32_t)tiles + (uint32_t)t;
     }
 }
 

@@ -32,14 +32,14 @@ static bool hip_ok(hipError_t e, const char* what) {
 
 static size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
-// first length class that can hold a list longer than SORT_SMALL_MAX (4096 = 2^12 -> msb 12, frac 0)
-constexpr int LONG_LIST_CLASS = 12 * 8 + 0 + 1;
 
 static Layout make_layout(int32_t n, int32_t width, int32_t height, int64_t max_instances) {
     Layout L{};
     const size_t N = (size_t)(n > 0 ? n : 0), I = (size_t)(max_instances > 0 ? max_instances : 0);
     const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
     L.tiles = gx * gy;
+    L.grid_x = gx;
+    L.grid_y = gy;
     L.n_blocks = (int)((N + PRE_BLOCK - 1) / PRE_BLOCK);
     L.n_chunks = (int)((N + BIN_CHUNK - 1) / BIN_CHUNK);
     size_t off = 0;
@@ -112,7 +112,8 @@ static ViewWs carve(char* ws, const Layout& L) {
 
 // Batch header placed in front of the per-view slices.
 struct BatchLayout {
-    size_t view_table, bin_table, pre_table, cams, order_classes, work_order, views, total;
+    size_t view_table, bin_table, pre_table, cams, order_state, work_order, long_list, views, total;
+    size_t order_slots;
     size_t per_view;
 };
 
@@ -124,8 +125,11 @@ static BatchLayout make_batch_layout(const Layout& L, int n_views) {
     B.bin_table = take((size_t)n_views * sizeof(BinView));
     B.pre_table = take((size_t)n_views * sizeof(PreOut));
     B.cams = take((size_t)n_views * sizeof(CameraDev));
-    B.order_classes = take((ORDER_CLASSES + 1) * 4);
-    B.work_order = take((size_t)n_views * L.tiles * 2 * 4);
+    B.order_state = take(ORDER_STATE_WORDS * 4);
+    // NUM_XCD interleaved streams; each holds the items of its band of tile rows for every view
+    B.order_slots = (size_t)NUM_XCD * max_band_rows(L.grid_y) * L.grid_x * 2 * n_views;
+    B.work_order = take(B.order_slots * 4);
+    B.long_list = take((size_t)n_views * L.tiles * 4);
     B.views = off;
     B.per_view = align_up(L.total);
     B.total = off + (size_t)n_views * B.per_view;
@@ -187,7 +191,8 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     auto* bin_table = reinterpret_cast<BinView*>(ws + B.bin_table);
     auto* pre_table = reinterpret_cast<PreOut*>(ws + B.pre_table);
     auto* cams_dev = reinterpret_cast<CameraDev*>(ws + B.cams);
-    auto* classes = reinterpret_cast<uint32_t*>(ws + B.order_classes);
+    auto* order_state = reinterpret_cast<uint32_t*>(ws + B.order_state);
+    auto* long_list = reinterpret_cast<uint32_t*>(ws + B.long_list);
     auto* work_order = reinterpret_cast<uint32_t*>(ws + B.work_order);
     std::vector<ViewWs> vw((size_t)n_views);
     std::vector<ViewEntry> table((size_t)n_views);
@@ -245,24 +250,26 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     // ---- stage 2: scatter (depth bits, index) into the tiles' slices
     bin_kernel<true><<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(bin_table, N, grid_x, L.tiles, W, H);
     mark(3);
-    // ---- stage 3: work order (longest lists first) + per-tile (depth, index) sort
-    if (!hip_ok(hipMemsetAsync(classes, 0, (ORDER_CLASSES + 1) * 4, stream), "memset classes"))
+    // ---- stage 3: work order (XCD streams, longest lists first) + per-tile (depth, index) sort
+    if (!hip_ok(hipMemsetAsync(order_state, 0, ORDER_STATE_WORDS * 4, stream), "memset order state") ||
+        !hip_ok(hipMemsetAsync(work_order, 0xff, B.order_slots * 4, stream), "memset work order"))
         return PGR_ERR_LAUNCH_FAILURE;
     const dim3 og((L.tiles + 255) / 256, n_views);
-    order_count_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, classes);
-    order_scan_kernel<<<1, ORDER_CLASSES, 0, stream>>>(classes, LONG_LIST_CLASS);
-    order_scatter_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, classes, work_order);
+    order_count_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, L.grid_x, L.grid_y, order_state);
+    order_scan_kernel<<<1, ORDER_CLASSES, 0, stream>>>(order_state);
+    order_scatter_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, L.grid_x, L.grid_y, order_state, work_order,
+                                                 (uint32_t)SORT_SMALL_MAX, long_list);
     tile_sort_large_kernel<<<std::min(n_views * L.tiles, 1024), SORT_LARGE_THREADS, 0, stream>>>(
-        bin_table, L.tiles, work_order, classes + ORDER_CLASSES);
-    tile_sort_kernel<<<n_views * L.tiles, SORT_THREADS, 0, stream>>>(bin_table, L.tiles, work_order);
+        bin_table, L.tiles, long_list, order_state + NUM_XCD * ORDER_CLASSES);
+    tile_sort_kernel<<<n_views * L.tiles, SORT_THREADS, 0, stream>>>(bin_table, L.tiles);
     mark(4);
-    // ---- stage 4: compositing of every (view, tile, half) work item in ONE launch, longest lists first
+    // ---- stage 4: compositing of every (view, tile, half) work item in ONE launch
     const uint32_t items_per_view = 2u * (uint32_t)L.tiles;
-    const uint32_t items = items_per_view * (uint32_t)n_views;
+    const uint32_t slots = (uint32_t)B.order_slots;
     if (want_aux)
-        composite_wave_kernel<true><<<items, WAVE, 0, stream>>>(view_table, items_per_view, work_order);
+        composite_wave_kernel<true><<<slots, WAVE, 0, stream>>>(view_table, items_per_view, work_order);
     else
-        composite_wave_kernel<false><<<items, WAVE, 0, stream>>>(view_table, items_per_view, work_order);
+        composite_wave_kernel<false><<<slots, WAVE, 0, stream>>>(view_table, items_per_view, work_order);
     mark(5);
     if (!hip_ok(hipGetLastError(), "kernel launch")) return PGR_ERR_LAUNCH_FAILURE;
 

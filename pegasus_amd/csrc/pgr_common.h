@@ -36,13 +36,12 @@ static_assert(sizeof(CameraDev) == 256, "CameraDev must be 256 B");
 struct Layout {
     size_t cam, counters, xy, depth, conic_opacity, rgb, radii, rects, tile_count, rel, ranges, bucket, alt,
         gauss_sorted, total;
-    int32_t tiles;
+    int32_t tiles, grid_x, grid_y;
     int32_t n_blocks;
     int32_t n_chunks;
 };
 
-// Work ordering: half-tile work items sorted by DESCENDING list length in 256 log-spaced classes, so long
-// lists start first and short ones back-fill the SIMDs that finish early.  Order never affects results.
+// Work ordering: list-length classes (256, log-spaced); see composite.hip.h "work order".
 constexpr int ORDER_CLASSES = 256;
 
 __device__ __forceinline__ int length_class(uint32_t len) {

@@ -310,11 +310,9 @@ constexpr int SORT_SMALL_MAX = SORT_THREADS * 16;      // 4096 keys, 32 KiB LDS
 constexpr int SORT_LARGE_THREADS = 1024;
 constexpr int SORT_LARGE_MAX = SORT_LARGE_THREADS * 16; // 16384 keys, 136 KiB LDS with padding
 
-__device__ __forceinline__ bool sort_item(const BinView* __restrict__ views, int tiles,
-                                          const uint32_t* __restrict__ work_order, uint32_t index,
-                                          const uint2*& bucket, uint32_t*& out, int& n,
-                                          uint64_t** alt = nullptr) {
-    const uint32_t item = work_order[2 * index] >> 1;   // work items come in (half 0, half 1) pairs
+// item = view * tiles + tile
+__device__ __forceinline__ bool sort_item(const BinView* __restrict__ views, int tiles, uint32_t item,
+                                          const uint2*& bucket, uint32_t*& out, int& n, uint64_t** alt = nullptr) {
     const uint32_t view = item / (uint32_t)tiles;
     const uint32_t tile = item - view * (uint32_t)tiles;
     const BinView& bv = views[view];
@@ -328,11 +326,10 @@ __device__ __forceinline__ bool sort_item(const BinView* __restrict__ views, int
 }
 
 // grid = n_views * tiles workgroups of 256; lists of 1..4096 entries
-__global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* __restrict__ views, int tiles,
-                                                                 const uint32_t* __restrict__ work_order) {
+__global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* __restrict__ views, int tiles) {
     __shared__ uint64_t skeys[SORT_THREADS * 17];
     const uint2* bucket; uint32_t* out; int n;
-    if (!sort_item(views, tiles, work_order, blockIdx.x, bucket, out, n)) return;
+    if (!sort_item(views, tiles, blockIdx.x, bucket, out, n)) return;
     if (n > SORT_SMALL_MAX) return;                      // tile_sort_large_kernel's
     if (n <= SORT_THREADS * 2) merge_sort_tile<SORT_THREADS, 2>(skeys, bucket, out, n);
     else if (n <= SORT_THREADS * 4) merge_sort_tile<SORT_THREADS, 4>(skeys, bucket, out, n);
@@ -340,16 +337,16 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* 
     else merge_sort_tile<SORT_THREADS, 16>(skeys, bucket, out, n);
 }
 
-// Lists longer than 4096: work_order is sorted by descending length class, so they are its first
-// n_candidates entries (device counter written by order_scan_kernel); workgroups stride over them.
+// Lists longer than 4096: order_scatter_kernel appends them to long_list (device counter n_long);
+// workgroups stride over the list.
 __global__ __launch_bounds__(SORT_LARGE_THREADS) void tile_sort_large_kernel(const BinView* __restrict__ views, int tiles,
-                                                                             const uint32_t* __restrict__ work_order,
-                                                                             const uint32_t* __restrict__ n_candidates) {
+                                                                             const uint32_t* __restrict__ long_list,
+                                                                             const uint32_t* __restrict__ n_long) {
     __shared__ uint64_t skeys[SORT_LARGE_THREADS * 17];   // 136 KiB of the CU's 160 KiB
-    const uint32_t cand = *n_candidates;
+    const uint32_t cand = *n_long;
     for (uint32_t k = blockIdx.x; k < cand; k += gridDim.x) {
         const uint2* bucket; uint32_t* out; int n; uint64_t* alt;
-        const bool ok = sort_item(views, tiles, work_order, k, bucket, out, n, &alt);
+        const bool ok = sort_item(views, tiles, long_list[k], bucket, out, n, &alt);
         if (ok && n > SORT_SMALL_MAX) {
             if (n <= SORT_LARGE_MAX) {
                 merge_sort_tile<SORT_LARGE_THREADS, 16>(skeys, bucket, out, n);
