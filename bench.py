@@ -199,6 +199,17 @@ def main():
         "N": N, "V": round(V), "I": round(I), "P": P,
     }
 
+    # HBM-side traffic of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+    # (separate passes, gfx950 unit = KiB; see profiles/README.md), committed as profiles/pmc_traffic.json
+    try:
+        pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+        k = pmc["kernels"].get(dom_name)
+        if k and pmc.get("workload") == args.workload and pmc.get("batch") == B:
+            roofline["traffic"] = int(k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"])
+            roofline["traffic_source"] = pmc["source"]
+    except (OSError, ValueError, KeyError):
+        pass
+
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         import oracle
@@ -224,8 +235,8 @@ def main():
                          f"({cores} threads), reference-style lists; no reference CPU rasterizer exists"}
 
     line = {
-        "metric": "rendered views/sec (RGB+depth+mask) on 2M-Gaussian scene @800x800" if with_masks else
-                  "rendered views/sec (RGB+depth, raster only) on 2M-Gaussian scene @800x800",
+        "metric": (f"rendered views/sec (RGB+depth+mask) on {N / 1e6:.2g}M-Gaussian scene @{W}x{H}" if with_masks else
+                   f"rendered views/sec (RGB+depth, raster only) on {N / 1e6:.2g}M-Gaussian scene @{W}x{H}"),
         "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
