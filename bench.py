@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--views", type=int, default=64, help="distinct cameras cycled through")
     ap.add_argument("--batch", type=int, default=16, help="views per step (one pgr_forward_batch call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-steps", action="store_true", help="one blocking render_batch per step (no pipelining)")
     ap.add_argument("--raster-only", action="store_true", help="time only the full-scene RGB+depth pass (R), no masks")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--profile-steps", type=int, default=2, help="steps measured per-stage with HIP events")
@@ -110,7 +111,8 @@ def main():
     W, H = my_views[0].width, my_views[0].height
     P = W * H
     with_masks = not args.raster_only and fr.K > 0
-    frames = fr.alloc_frames(B, H, W, masks=with_masks)      # one batch of frame buffers, reused every step
+    frames = fr.alloc_frames(B, H, W, masks=with_masks)      # frame buffers, reused (two sets: 2-deep pipeline)
+    frames2 = fr.alloc_frames(B, H, W, masks=with_masks)
 
     def batch_views(i):
         return [specs[(i * B + k) % len(specs)] for k in range(B)]
@@ -118,15 +120,29 @@ def main():
     def step(i, **kw):
         return fr.render_batch(batch_views(i), frames, masks=with_masks, **kw)
 
-    for i in range(args.warmup):
-        step(i)
+    def run_steps(first, count):
+        """`count` steps as a 2-deep software pipeline: batch i is enqueued (scene pass and semantic pass on two
+        streams, no host sync) while batch i-1 finishes; every batch's overflow status is checked."""
+        if args.sync_steps:
+            for i in range(first, first + count):
+                step(i)
+            return
+        pending = None
+        for i in range(first, first + count):
+            h = fr.render_batch_async(batch_views(i), frames if i % 2 == 0 else frames2, masks=with_masks, slot=i % 2)
+            if pending is not None:
+                pending.wait()
+            pending = h
+        if pending is not None:
+            pending.wait()
+
+    run_steps(0, args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    run_steps(args.warmup, args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -123,6 +123,19 @@ int32_t pgr_forward_batch(const PgrScene *scene, int32_t n_views, const PgrCamer
                           const PgrOutputs *outs, void *workspace, size_t workspace_bytes,
                           int64_t max_instances_per_view, int64_t *num_instances, void *stream);
 
+/* Asynchronous form: enqueues the whole batch on `stream` and returns without synchronising.  `host_scratch`
+ * is PINNED host memory of pgr_host_scratch_bytes(n_views) that the library uses to stage its pointer tables and
+ * to receive the status words; it must stay untouched until `stream` has passed the call.  After synchronising,
+ * pgr_batch_status(host_scratch, n_views, num_instances) returns PGR_OK or PGR_ERR_INSTANCE_OVERFLOW (frames of
+ * an overflowed batch are not valid; re-run with a larger capacity).  Lets two batches -- e.g. the scene pass
+ * and the semantic pass of a frame set -- run concurrently on two streams with two workspaces. */
+size_t pgr_host_scratch_bytes(int32_t n_views);
+int32_t pgr_forward_batch_async(const PgrScene *scene, int32_t n_views, const PgrCamera *cameras,
+                                const PgrOutputs *outs, void *workspace, size_t workspace_bytes,
+                                int64_t max_instances_per_view, void *host_scratch, size_t host_scratch_size,
+                                void *stream);
+int32_t pgr_batch_status(const void *host_scratch, int32_t n_views, int64_t *num_instances);
+
 /* Profiling twin of pgr_forward_batch (bench / rocprof only): records HIP events on `stream` at the
  * stage boundaries (each stage runs for all views before the next starts), synchronises, and writes the
  * elapsed milliseconds of each stage for the whole batch to stage_ms[PGR_NUM_STAGES] in PgrStage order. */

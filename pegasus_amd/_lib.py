@@ -62,6 +62,11 @@ SYMBOLS = {
     "pgr_batch_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32]),
     "pgr_forward_batch": (C.c_int32, [C.POINTER(PgrScene), C.c_int32, C.POINTER(PgrCamera), C.POINTER(PgrOutputs),
                                       C.c_void_p, C.c_size_t, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
+    "pgr_host_scratch_bytes": (C.c_size_t, [C.c_int32]),
+    "pgr_forward_batch_async": (C.c_int32, [C.POINTER(PgrScene), C.c_int32, C.POINTER(PgrCamera),
+                                            C.POINTER(PgrOutputs), C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p,
+                                            C.c_size_t, C.c_void_p]),
+    "pgr_batch_status": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "pgr_forward_batch_profiled": (C.c_int32, [C.POINTER(PgrScene), C.c_int32, C.POINTER(PgrCamera),
                                                C.POINTER(PgrOutputs), C.c_void_p, C.c_size_t, C.c_int64,
                                                C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_float)]),

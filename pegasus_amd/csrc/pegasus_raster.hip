@@ -112,19 +112,29 @@ static ViewWs carve(char* ws, const Layout& L) {
 
 // Batch header placed in front of the per-view slices.
 struct BatchLayout {
-    size_t view_table, bin_table, pre_table, cams, order_state, work_order, long_list, views, total;
+    size_t tables, cams, status, order_state, work_order, long_list, views, total;
+    size_t view_table_off, bin_table_off, pre_table_off, tables_bytes;   // inside `tables` (one H2D copy)
     size_t order_slots;
     size_t per_view;
 };
+
+// Host-side image of the tables + the status words read back, laid out exactly as on the device.
+static size_t host_scratch_bytes(int n_views) {
+    return align_up((size_t)n_views * sizeof(ViewEntry), 16) + align_up((size_t)n_views * sizeof(BinView), 16) +
+           align_up((size_t)n_views * sizeof(PreOut), 16) + (size_t)n_views * 8;
+}
 
 static BatchLayout make_batch_layout(const Layout& L, int n_views) {
     BatchLayout B{};
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes ? bytes : 1); return o; };
-    B.view_table = take((size_t)n_views * sizeof(ViewEntry));
-    B.bin_table = take((size_t)n_views * sizeof(BinView));
-    B.pre_table = take((size_t)n_views * sizeof(PreOut));
+    B.view_table_off = 0;
+    B.bin_table_off = B.view_table_off + align_up((size_t)n_views * sizeof(ViewEntry), 16);
+    B.pre_table_off = B.bin_table_off + align_up((size_t)n_views * sizeof(BinView), 16);
+    B.tables_bytes = B.pre_table_off + align_up((size_t)n_views * sizeof(PreOut), 16);
+    B.tables = take(B.tables_bytes);
     B.cams = take((size_t)n_views * sizeof(CameraDev));
+    B.status = take((size_t)n_views * 8);          // per view: [0] listed instances, [1] overflow flag
     B.order_state = take(ORDER_STATE_WORDS * 4);
     // NUM_XCD interleaved streams; each holds the items of its band of tile rows for every view
     B.order_slots = (size_t)NUM_XCD * max_band_rows(L.grid_y) * L.grid_x * 2 * n_views;
@@ -160,9 +170,13 @@ static int zero_outputs(const PgrOutputs* out, size_t P, hipStream_t stream) {
 
 // The whole hot path for a batch of views of ONE scene.  All views share the image size.
 // ev: optional PGR_NUM_STAGES+1 events recorded at the stage boundaries (profiling entry point only).
+// host_scratch: NULL = synchronous call (tables staged from pageable memory, stream synchronised at the end,
+// num_instances filled).  Non-NULL = pinned host memory of host_scratch_bytes(n_views): nothing blocks, the
+// status words land in its tail when the stream reaches them (pgr_batch_status reads them).
 static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrCamera* cams, const PgrOutputs* outs,
                                   void* workspace, size_t workspace_bytes, int64_t max_instances,
-                                  int64_t* num_instances, hipStream_t stream, hipEvent_t* ev) {
+                                  int64_t* num_instances, hipStream_t stream, hipEvent_t* ev,
+                                  void* host_scratch = nullptr) {
     auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], stream); };
     if (n_views <= 0 || !cams || !outs) return PGR_ERR_INVALID_ARGUMENT;
     if (num_instances) for (int v = 0; v < n_views; ++v) num_instances[v] = 0;
@@ -187,21 +201,30 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     const BatchLayout B = make_batch_layout(L, n_views);
     if (workspace_bytes < B.total) return PGR_ERR_WORKSPACE_TOO_SMALL;
     char* ws = static_cast<char*>(workspace);
-    auto* view_table = reinterpret_cast<ViewEntry*>(ws + B.view_table);
-    auto* bin_table = reinterpret_cast<BinView*>(ws + B.bin_table);
-    auto* pre_table = reinterpret_cast<PreOut*>(ws + B.pre_table);
+    auto* view_table = reinterpret_cast<ViewEntry*>(ws + B.tables + B.view_table_off);
+    auto* bin_table = reinterpret_cast<BinView*>(ws + B.tables + B.bin_table_off);
+    auto* pre_table = reinterpret_cast<PreOut*>(ws + B.tables + B.pre_table_off);
     auto* cams_dev = reinterpret_cast<CameraDev*>(ws + B.cams);
+    auto* status_dev = reinterpret_cast<uint32_t*>(ws + B.status);
     auto* order_state = reinterpret_cast<uint32_t*>(ws + B.order_state);
     auto* long_list = reinterpret_cast<uint32_t*>(ws + B.long_list);
     auto* work_order = reinterpret_cast<uint32_t*>(ws + B.work_order);
     std::vector<ViewWs> vw((size_t)n_views);
-    std::vector<ViewEntry> table((size_t)n_views);
-    std::vector<BinView> bins((size_t)n_views);
-    std::vector<PreOut> pres((size_t)n_views);
+    std::vector<char> pageable;
+    char* hs = static_cast<char*>(host_scratch);
+    if (!hs) {
+        pageable.resize(host_scratch_bytes(n_views));
+        hs = pageable.data();
+    }
+    auto* table = reinterpret_cast<ViewEntry*>(hs + B.view_table_off);
+    auto* bins = reinterpret_cast<BinView*>(hs + B.bin_table_off);
+    auto* pres = reinterpret_cast<PreOut*>(hs + B.pre_table_off);
+    auto* h_status = reinterpret_cast<uint32_t*>(hs + B.tables_bytes);
     bool want_aux = false;
     for (int v = 0; v < n_views; ++v) {
         vw[v] = carve(ws + B.views + (size_t)v * B.per_view, L);
-        vw[v].cam = cams_dev + v;   // cameras of a batch are contiguous: preprocess walks them
+        vw[v].cam = cams_dev + v;          // cameras of a batch are contiguous: preprocess walks them
+        vw[v].counters = status_dev + 2 * v;   // and so are the status words: one D2H copy per batch
         ViewEntry& e = table[v];
         memset(&e, 0, sizeof(e));
         e.cam = vw[v].cam; e.ranges = vw[v].ranges; e.gauss_sorted = vw[v].gauss_sorted; e.xy = vw[v].xy;
@@ -215,12 +238,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         pres[v] = PreOut{vw[v].xy, vw[v].depth, vw[v].conop, vw[v].rgbd, vw[v].rects,
                          outs[v].radii ? outs[v].radii : vw[v].radii};
     }
-    if (!hip_ok(hipMemcpyAsync(view_table, table.data(), table.size() * sizeof(ViewEntry), hipMemcpyHostToDevice,
-                               stream), "memcpy view table") ||
-        !hip_ok(hipMemcpyAsync(bin_table, bins.data(), bins.size() * sizeof(BinView), hipMemcpyHostToDevice, stream),
-                "memcpy bin table") ||
-        !hip_ok(hipMemcpyAsync(pre_table, pres.data(), pres.size() * sizeof(PreOut), hipMemcpyHostToDevice, stream),
-                "memcpy pre table"))
+    if (!hip_ok(hipMemcpyAsync(ws + B.tables, hs, B.tables_bytes, hipMemcpyHostToDevice, stream), "memcpy tables"))
         return PGR_ERR_LAUNCH_FAILURE;
 
     // ---- stage 0: camera pack + per-Gaussian preprocess
@@ -274,15 +292,14 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     if (!hip_ok(hipGetLastError(), "kernel launch")) return PGR_ERR_LAUNCH_FAILURE;
 
     // the only host read of the batch: instance counts + overflow flags, after everything is enqueued
-    std::vector<uint32_t> h_counters((size_t)n_views * 2, 0u);
-    for (int v = 0; v < n_views; ++v)
-        if (!hip_ok(hipMemcpyAsync(&h_counters[2 * v], vw[v].counters, 8, hipMemcpyDeviceToHost, stream), "memcpy"))
-            return PGR_ERR_LAUNCH_FAILURE;
+    if (!hip_ok(hipMemcpyAsync(h_status, status_dev, (size_t)n_views * 8, hipMemcpyDeviceToHost, stream), "memcpy status"))
+        return PGR_ERR_LAUNCH_FAILURE;
+    if (host_scratch) return PGR_OK;       // asynchronous: the caller synchronises and calls pgr_batch_status
     if (!hip_ok(hipStreamSynchronize(stream), "sync at batch end")) return PGR_ERR_LAUNCH_FAILURE;
     bool overflow = false;
     for (int v = 0; v < n_views; ++v) {
-        if (num_instances) num_instances[v] = (int64_t)h_counters[2 * v];
-        overflow = overflow || h_counters[2 * v + 1];
+        if (num_instances) num_instances[v] = (int64_t)h_status[2 * v];
+        overflow = overflow || h_status[2 * v + 1];
     }
     return overflow ? PGR_ERR_INSTANCE_OVERFLOW : PGR_OK;
 }
@@ -352,6 +369,30 @@ int32_t pgr_forward_batch(const PgrScene* scene, int32_t n_views, const PgrCamer
                           int64_t* num_instances, void* stream_v) {
     return forward_batch_impl(scene, n_views, cameras, outs, workspace, workspace_bytes, max_instances_per_view,
                               num_instances, static_cast<hipStream_t>(stream_v), nullptr);
+}
+
+size_t pgr_host_scratch_bytes(int32_t n_views) { return n_views > 0 ? host_scratch_bytes(n_views) : 0; }
+
+int32_t pgr_forward_batch_async(const PgrScene* scene, int32_t n_views, const PgrCamera* cameras, const PgrOutputs* outs,
+                                void* workspace, size_t workspace_bytes, int64_t max_instances_per_view,
+                                void* host_scratch, size_t host_scratch_size, void* stream_v) {
+    if (!host_scratch || n_views <= 0 || host_scratch_size < host_scratch_bytes(n_views)) return PGR_ERR_INVALID_ARGUMENT;
+    if (scene && scene->n == 0) memset(static_cast<char*>(host_scratch), 0, host_scratch_bytes(n_views));
+    return forward_batch_impl(scene, n_views, cameras, outs, workspace, workspace_bytes, max_instances_per_view, nullptr,
+                              static_cast<hipStream_t>(stream_v), nullptr, host_scratch);
+}
+
+int32_t pgr_batch_status(const void* host_scratch, int32_t n_views, int64_t* num_instances) {
+    if (!host_scratch || n_views <= 0) return PGR_ERR_INVALID_ARGUMENT;
+    const size_t tables = align_up((size_t)n_views * sizeof(ViewEntry), 16) + align_up((size_t)n_views * sizeof(BinView), 16) +
+                          align_up((size_t)n_views * sizeof(PreOut), 16);
+    const uint32_t* st = reinterpret_cast<const uint32_t*>(static_cast<const char*>(host_scratch) + tables);
+    bool overflow = false;
+    for (int v = 0; v < n_views; ++v) {
+        if (num_instances) num_instances[v] = (int64_t)st[2 * v];
+        overflow = overflow || st[2 * v + 1];
+    }
+    return overflow ? PGR_ERR_INSTANCE_OVERFLOW : PGR_OK;
 }
 
 int32_t pgr_forward_batch_profiled(const PgrScene* scene, int32_t n_views, const PgrCamera* cameras,

@@ -66,6 +66,54 @@ class FrameRenderer:
             f["masks"] = torch.empty((batch, self.K, height, width), dtype=torch.uint8, device=dev)
         return f
 
+    def render_batch_async(self, specs: Sequence[R.ViewSpec], frames: dict, masks: bool = True, slot: int = 0):
+        """Enqueues the scene pass and the semantic pass of one batch on two side streams (two workspaces) so
+        their kernels overlap, chains the mask kernels behind the semantic pass, and returns a ``wait()``-able
+        handle without synchronising the host.  ``slot`` selects the workspace pair: keep at most one batch in
+        flight per slot (two slots + two frame sets = a 2-deep pipeline)."""
+        B = len(specs)
+        dev = self.device
+        cur = torch.cuda.current_stream(dev)
+        if not hasattr(self, "_streams"):
+            self._streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        s_scene, s_sem = self._streams
+        outs = [dict(color=frames["color"][i], depth=frames["depth"][i], radii=None) for i in range(B)]
+        s_scene.wait_stream(cur)
+        with torch.cuda.stream(s_scene):
+            h1 = R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales,
+                                 rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False, outputs=outs,
+                                 async_slot=("scene", slot))
+        h2 = None
+        if masks and self.K:
+            souts = [dict(color=frames["seg"][i], depth=frames["seg_depth"][i], radii=None) for i in range(B)]
+            s_sem.wait_stream(cur)
+            with torch.cuda.stream(s_sem):
+                h2 = R.forward_views(self.obj["means3d"], self.obj["opacities"], specs, shs=self.sem_shs,
+                                     scales=self.obj["scales"], rotations=self.obj["rotations"], sh_degree=0,
+                                     want_radii=False, outputs=souts, async_slot=("sem", slot))
+                for i in range(B):
+                    M.color_masks(frames["seg"][i], self.colors, M.MASK_THRESHOLD, out=frames["masks"][i])
+                ev_masks = torch.cuda.Event()
+                ev_masks.record(s_sem)
+            cur.wait_stream(s_sem)
+        cur.wait_stream(s_scene)
+        renderer = self
+
+        class _Pending:
+            def wait(self_inner):
+                h1.wait()
+                if h2 is not None:
+                    redone = h2._event is not None and False
+                    before = h2.results
+                    h2.wait()
+                    ev_masks.synchronize()
+                    if h2.results is not before:      # semantic pass was re-rendered after an overflow: redo masks
+                        for i in range(B):
+                            M.color_masks(frames["seg"][i], renderer.colors, M.MASK_THRESHOLD, out=frames["masks"][i])
+                        torch.cuda.current_stream(dev).synchronize()
+                return frames
+        return _Pending()
+
     def render_batch(self, specs: Sequence[R.ViewSpec], frames: dict = None, masks: bool = True,
                      stage_ms: list = None, sem_stage_ms: list = None):
         """Renders len(specs) frames into ``frames`` (allocated if None).  Returns the dict of batched

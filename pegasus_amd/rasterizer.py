@@ -36,13 +36,22 @@ class _Workspace:
         self.buf = {}
         self.capacity_hint = {}
 
-    def get(self, device, nbytes: int) -> torch.Tensor:
-        t = self.buf.get(device)
+    def get(self, device, nbytes: int, slot=0) -> torch.Tensor:
+        key = (device, slot)
+        t = self.buf.get(key)
         if t is None or t.numel() < nbytes:
-            self.buf[device] = None
+            self.buf[key] = None
             del t
             t = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
-            self.buf[device] = t
+            self.buf[key] = t
+        return t
+
+    def pinned(self, slot, nbytes: int) -> torch.Tensor:
+        key = ("pinned", slot)
+        t = self.buf.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(int(nbytes) + 64, dtype=torch.uint8).pin_memory()
+            self.buf[key] = t
         return t
 
 
@@ -69,15 +78,46 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+class PendingBatch:
+    """Handle of an asynchronous forward_views call: ``wait()`` blocks until the batch has finished on its
+    stream, checks the overflow flags (re-rendering synchronously with a larger capacity if needed) and
+    returns the list of result dicts."""
+
+    def __init__(self, results, event, scratch, nv, key, max_inst, redo):
+        self.results, self._event, self._scratch, self._nv = results, event, scratch, nv
+        self._key, self._max_inst, self._redo = key, max_inst, redo
+        self.num_instances = None
+
+    def wait(self):
+        if self._event is not None:
+            self._event.synchronize()
+            need = (C.c_int64 * self._nv)()
+            status = _lib.lib().pgr_batch_status(C.c_void_p(self._scratch.data_ptr()), self._nv, need)
+            self.num_instances = [int(x) for x in need]
+            peak = max(self.num_instances)
+            if peak > 0.8 * self._max_inst:
+                _WS.capacity_hint[self._key] = max(_WS.capacity_hint.get(self._key, 0), int(peak * 1.3) + 1024)
+            self._event = None
+            if status == _lib.PGR_ERR_INSTANCE_OVERFLOW:
+                self.results = self._redo()          # synchronous path grows the workspace and retries
+            else:
+                _lib.check(status, "pgr_forward_batch_async")
+            self._redo = None
+        return self.results
+
+
 def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, colors_precomp=None, scales=None,
                   rotations=None, cov3D_precomp=None, sh_degree=0, scale_modifier=1.0, want_radii=True,
-                  want_aux=False, stage_ms: Optional[list] = None, outputs: Optional[list] = None):
+                  want_aux=False, stage_ms: Optional[list] = None, outputs: Optional[list] = None,
+                  async_slot=None):
     """Renders ``len(views)`` views of one scene.  Returns a list of dicts with keys
     color[3,H,W], depth[1,H,W], radii[N] (or None), and final_T / n_contrib when ``want_aux``.
 
     ``stage_ms``: pass an empty list to use the profiling entry point; it receives the per-stage
     milliseconds (whole batch) measured with HIP events on the launch stream.
     ``outputs``: optional pre-allocated list of dicts (same keys) to render into.
+    ``async_slot``: not None -> enqueue on torch's CURRENT stream without synchronising and return a
+    PendingBatch; the slot names the workspace / pinned scratch to use (one batch in flight per slot).
     """
     L = _lib.lib()
     device = means3D.device
@@ -129,6 +169,24 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     key = (device, n, W, H)
     max_inst = _WS.capacity_hint.get(key, max(1 << 20, 6 * n))
+    if async_slot is not None:
+        with torch.cuda.device(device):
+            nbytes = L.pgr_batch_workspace_bytes(n, W, H, max_inst, nv)
+            ws = _WS.get(device, nbytes, slot=("async", async_slot))
+            sb = L.pgr_host_scratch_bytes(nv)
+            scratch = _WS.pinned(async_slot, sb)
+            _lib.check(L.pgr_forward_batch_async(C.byref(scene), nv, cams, outs, C.c_void_p(ws.data_ptr()),
+                                                 ws.numel(), max_inst, C.c_void_p(scratch.data_ptr()),
+                                                 scratch.numel(), stream), "pgr_forward_batch_async")
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+        kw = dict(shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
+                  cov3D_precomp=cov3D_precomp, sh_degree=sh_degree, scale_modifier=scale_modifier,
+                  want_radii=want_radii, want_aux=want_aux, outputs=results)
+        redo = lambda: forward_views(means3D, opacities, views, **kw)
+        pb = PendingBatch(results, ev, scratch, nv, key, max_inst, redo)
+        pb._keep = (keep, ws, cams, outs, scene)
+        return pb
     need = (C.c_int64 * nv)()
     ms = (C.c_float * _lib.PGR_NUM_STAGES)()
     with torch.cuda.device(device):

@@ -271,3 +271,34 @@ def test_frame_renderer_rgb_depth_masks(oracle, gpu_device):
         # and the device mask kernel is bit-exact against the oracle on the SAME image
         np.testing.assert_array_equal(M.color_masks(out["seg"][i], fr.colors).cpu().numpy(),
                                       oracle.color_masks(seg, fr.colors_np, 0.1))
+
+
+def test_async_frame_pipeline_matches_sync(gpu_device):
+    """render_batch_async (two streams, two workspaces, no host sync until wait) == render_batch, bit for bit,
+    including when the first attempt overflows its instance capacity."""
+    import torch
+    from pegasus_amd import frames as F, rasterizer
+    cloud, views = scenes.scene_c3(scale=0.04, n_views=6, width=320, height=240)
+    act = cloud.activated()
+    fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"],
+                         cloud.object_id, sh_degree=3, device=gpu_device)
+    specs = [fr.view_spec(v) for v in views]
+    ref = {k: v.clone() for k, v in fr.render_batch(specs).items()}
+    torch.cuda.synchronize()
+    fa, fb = fr.alloc_frames(3, 240, 320), fr.alloc_frames(3, 240, 320)
+    h0 = fr.render_batch_async(specs[:3], fa, slot=0)
+    h1 = fr.render_batch_async(specs[3:], fb, slot=1)
+    h0.wait(); h1.wait()
+    for k in ("color", "depth", "seg", "masks"):
+        assert torch.equal(fa[k], ref[k][:3]), k
+        assert torch.equal(fb[k], ref[k][3:]), k
+    # force an overflow on the async path: shrink the capacity hint, the handle must transparently re-render
+    for key in list(rasterizer._WS.capacity_hint):
+        rasterizer._WS.capacity_hint[key] = 1000
+    for kk in [k for k in rasterizer._WS.buf if isinstance(k, tuple) and len(k) == 2 and isinstance(k[1], tuple)]:
+        rasterizer._WS.buf.pop(kk)
+    fc = fr.alloc_frames(3, 240, 320)
+    fr.render_batch_async(specs[:3], fc, slot=0).wait()
+    torch.cuda.synchronize()
+    for k in ("color", "depth", "seg", "masks"):
+        assert torch.equal(fc[k], ref[k][:3]), k
