@@ -52,6 +52,7 @@ static Layout make_layout(int32_t n, int32_t width, int32_t height, int64_t max_
     L.rgb = take(N * 16);
     L.radii = take(N * 4);
     L.rects = take(N * 8);
+    L.crects = take(N * 8);
     L.tile_count = take((size_t)L.tiles * 4);
     L.rel = take((size_t)L.n_chunks * L.tiles * 4);
     L.ranges = take((size_t)L.tiles * 8);
@@ -83,7 +84,7 @@ struct ViewWs {
     float4* conop;
     float4* rgbd;
     int32_t* radii;   // per-view home of radii when the caller passes no radii output
-    uint2* rects;
+    uint2 *rects, *crects;
     uint32_t *tile_count, *rel;
     uint2* ranges;
     uint2* bucket;
@@ -101,6 +102,7 @@ static ViewWs carve(char* ws, const Layout& L) {
     v.rgbd = reinterpret_cast<float4*>(ws + L.rgb);
     v.radii = reinterpret_cast<int32_t*>(ws + L.radii);
     v.rects = reinterpret_cast<uint2*>(ws + L.rects);
+    v.crects = reinterpret_cast<uint2*>(ws + L.crects);
     v.tile_count = reinterpret_cast<uint32_t*>(ws + L.tile_count);
     v.rel = reinterpret_cast<uint32_t*>(ws + L.rel);
     v.ranges = reinterpret_cast<uint2*>(ws + L.ranges);
@@ -232,10 +234,10 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         e.out = CompOut{outs[v].color, outs[v].depth, outs[v].final_T, outs[v].n_contrib};
         e.counters = vw[v].counters;
         want_aux = want_aux || outs[v].final_T || outs[v].n_contrib;
-        bins[v] = BinView{vw[v].rects, vw[v].depth, vw[v].xy, vw[v].conop, vw[v].tile_count, vw[v].rel, vw[v].ranges,
+        bins[v] = BinView{vw[v].crects, vw[v].depth, vw[v].xy, vw[v].conop, vw[v].tile_count, vw[v].rel, vw[v].ranges,
                           vw[v].counters, vw[v].bucket, vw[v].gauss_sorted, vw[v].alt};
         // radii is part of the per-view contract; when the caller does not want it, it lands in the workspace
-        pres[v] = PreOut{vw[v].xy, vw[v].depth, vw[v].conop, vw[v].rgbd, vw[v].rects,
+        pres[v] = PreOut{vw[v].xy, vw[v].depth, vw[v].conop, vw[v].rgbd, vw[v].rects, vw[v].crects,
                          outs[v].radii ? outs[v].radii : vw[v].radii};
     }
     if (!hip_ok(hipMemcpyAsync(ws + B.tables, hs, B.tables_bytes, hipMemcpyHostToDevice, stream), "memcpy tables"))

@@ -119,12 +119,41 @@ __device__ __forceinline__ float3 sh_to_rgb(const float* __restrict__ sh, float 
     return make_float3(fmaxf(acc[0] + 0.5f, 0.0f), fmaxf(acc[1] + 0.5f, 0.0f), fmaxf(acc[2] + 0.5f, 0.0f));
 }
 
+// Candidate rectangle for the binning walk: the 3-sigma rectangle clipped to the axis-aligned box of the
+// ellipse {q <= tau''} where tau'' bounds from above every threshold the tight-list predicate
+// (cull.hip.h) can apply to a tile of this splat; tiles outside it are rejected by the predicate anyway, so the
+// lists are unchanged -- there are just fewer candidates to test (anisotropic and faint splats shrink most).
+__device__ __forceinline__ uint2 candidate_rect(const TileRect& r, float mx, float my, float c_xx, float c_yy,
+                                                float con_x, float con_y, float con_z, float opacity, int radius) {
+    if (opacity < ALPHA_MIN) return make_uint2(0u, 0u);                 // never listed
+    const uint2 full = make_uint2((uint32_t)r.minx | ((uint32_t)r.miny << 16), (uint32_t)r.maxx | ((uint32_t)r.maxy << 16));
+    if (!(con_x > 0.0f) || !(con_z > 0.0f)) return full;                // degenerate conic: the predicate keeps all
+    const float t = 255.0f * opacity;
+    const uint32_t bits = __float_as_uint(t);
+    const float e = (float)((int)((bits >> 23) & 0xffu) - 127);
+    const float m = __uint_as_float((bits & 0x007fffffu) | 0x3f800000u);
+    const float tau = 1.3862944f * (e + (m - 1.0f) + 0.0861f);
+    const float D = (float)radius + 2.0f * (float)TILE;                  // no pixel of the rectangle is farther than this
+    const float M = (con_x + 2.0f * fabsf(con_y) + con_z) * D * D;
+    const float tau2 = 1.001f * (tau + 0.00001f * M + 0.01f) + 0.001f;
+    const float ex = sqrtf(tau2 * c_xx) * 1.001f + 1.0f, ey = sqrtf(tau2 * c_yy) * 1.001f + 1.0f;
+    if (!(ex < 1.0e9f) || !(ey < 1.0e9f)) return full;
+    // tiles whose pixel-centre span [16t, 16t+15] meets [m - e, m + e]
+    const int minx = max(r.minx, (int)floorf((mx - ex - (float)(TILE - 1)) / (float)TILE) + 0);
+    const int miny = max(r.miny, (int)floorf((my - ey - (float)(TILE - 1)) / (float)TILE) + 0);
+    const int maxx = min(r.maxx, (int)floorf((mx + ex) / (float)TILE) + 1);
+    const int maxy = min(r.maxy, (int)floorf((my + ey) / (float)TILE) + 1);
+    if (maxx <= minx || maxy <= miny) return make_uint2(0u, 0u);
+    return make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)maxx | ((uint32_t)maxy << 16));
+}
+
 struct PreOut {
     float2* xy;
     float* depth;
     float4* conic_opacity;
     float4* rgb;             // (r,g,b,depth)
     uint2* rects;            // packed tile rectangle (4 x uint16: minx,miny,maxx,maxy), all zero when culled
+    uint2* crects;           // candidate rectangle for binning: rects clipped to the alpha >= 1/255 ellipse's box
     int32_t* radii;
 };
 
@@ -183,7 +212,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_batch_kernel(PgrScene sc
         const CameraDev& cam = cams[v];
         const PreOut& o = outs[v];
         int radius = 0;
-        uint2 rect = make_uint2(0u, 0u);
+        uint2 rect = make_uint2(0u, 0u), crect = make_uint2(0u, 0u);
         const float* vm = cam.view;
         const float* pm = cam.proj;
         float tx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
@@ -261,15 +290,18 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_batch_kernel(PgrScene sc
                     radius = rad;
                     rect = make_uint2((uint32_t)r.minx | ((uint32_t)r.miny << 16),
                                       (uint32_t)r.maxx | ((uint32_t)r.maxy << 16));
+                    const float op = sc.opacities[i];
+                    crect = candidate_rect(r, pix_x, pix_y, c_xx, c_yy, con_x, con_y, con_z, op, rad);
                     o.xy[i] = make_float2(pix_x, pix_y);
                     o.depth[i] = tz;
-                    o.conic_opacity[i] = make_float4(con_x, con_y, con_z, sc.opacities[i]);
+                    o.conic_opacity[i] = make_float4(con_x, con_y, con_z, op);
                     o.rgb[i] = make_float4(rgb.x, rgb.y, rgb.z, tz);
                 }
             }
         }
         o.radii[i] = radius;
         o.rects[i] = rect;
+        o.crects[i] = crect;
     }
 }
 

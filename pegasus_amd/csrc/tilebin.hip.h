@@ -37,7 +37,7 @@ __device__ __forceinline__ uint2 pack_rect(int minx, int miny, int maxx, int max
 }
 
 struct BinView {                 // per-view pointers used by the binning kernels (device table)
-    const uint2* rects;          // [n] packed tile rectangles
+    const uint2* rects;          // [n] packed CANDIDATE tile rectangles (preprocess.hip.h candidate_rect)
     const float* depth;          // [n]
     const float2* xy;            // [n]
     const float4* conic_opacity; // [n]
