@@ -279,8 +279,11 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     order_scan_kernel<<<1, ORDER_CLASSES, 0, stream>>>(order_state);
     order_scatter_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, L.grid_x, L.grid_y, order_state, work_order,
                                                  (uint32_t)SORT_SMALL_MAX, long_list);
-    tile_sort_large_kernel<<<std::min(n_views * L.tiles, 1024), SORT_LARGE_THREADS, 0, stream>>>(
-        bin_table, L.tiles, long_list, order_state + NUM_XCD * ORDER_CLASSES);
+    const uint32_t* n_long = order_state + NUM_XCD * ORDER_CLASSES;
+    tile_sort_long_kernel<SORT_LARGE_THREADS><<<std::min(n_views * L.tiles, 512), SORT_LARGE_THREADS, 0, stream>>>(
+        bin_table, L.tiles, long_list, n_long);
+    tile_sort_long_kernel<SORT_MEDIUM_THREADS><<<std::min(n_views * L.tiles, 1024), SORT_MEDIUM_THREADS, 0, stream>>>(
+        bin_table, L.tiles, long_list, n_long);
     tile_sort_kernel<<<n_views * L.tiles, SORT_THREADS, 0, stream>>>(bin_table, L.tiles);
     mark(4);
     // ---- stage 4: compositing of every (view, tile, half) work item in ONE launch

@@ -307,8 +307,6 @@ __device__ __forceinline__ void merge_round_global(const uint64_t* __restrict__ 
 }
 
 constexpr int SORT_SMALL_MAX = SORT_THREADS * 16;      // 4096 keys, 32 KiB LDS
-constexpr int SORT_LARGE_THREADS = 1024;
-constexpr int SORT_LARGE_MAX = SORT_LARGE_THREADS * 16; // 16384 keys, 136 KiB LDS with padding
 
 // item = view * tiles + tile
 __device__ __forceinline__ bool sort_item(const BinView* __restrict__ views, int tiles, uint32_t item,
@@ -337,35 +335,42 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* 
     else merge_sort_tile<SORT_THREADS, 16>(skeys, bucket, out, n);
 }
 
-// Lists longer than 4096: order_scatter_kernel appends them to long_list (device counter n_long);
-// workgroups stride over the list.
-__global__ __launch_bounds__(SORT_LARGE_THREADS) void tile_sort_large_kernel(const BinView* __restrict__ views, int tiles,
-                                                                             const uint32_t* __restrict__ long_list,
-                                                                             const uint32_t* __restrict__ n_long) {
-    __shared__ uint64_t skeys[SORT_LARGE_THREADS * 17];   // 136 KiB of the CU's 160 KiB
+// Lists longer than 4096: order_scatter_kernel appends them to long_list (device counter n_long); workgroups
+// stride over the list.  Two launches share the queue: THREADS = 512 takes 4097..8192 keys (68 KiB of LDS, two
+// workgroups per CU), THREADS = 1024 takes 8193..16384 in LDS (136 KiB of the CU's 160 KiB) and anything longer
+// as LDS-sorted 16384-key chunks merged through L2 between the list and its alt buffer.
+constexpr int SORT_MEDIUM_THREADS = 512;
+constexpr int SORT_MEDIUM_MAX = SORT_MEDIUM_THREADS * 16;   // 8192
+constexpr int SORT_LARGE_THREADS = 1024;
+constexpr int SORT_LARGE_MAX = SORT_LARGE_THREADS * 16;     // 16384
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void tile_sort_long_kernel(const BinView* __restrict__ views, int tiles,
+                                                                 const uint32_t* __restrict__ long_list,
+                                                                 const uint32_t* __restrict__ n_long) {
+    __shared__ uint64_t skeys[THREADS * 17];
+    constexpr int CAP = THREADS * 16;
     const uint32_t cand = *n_long;
     for (uint32_t k = blockIdx.x; k < cand; k += gridDim.x) {
         const uint2* bucket; uint32_t* out; int n; uint64_t* alt;
         const bool ok = sort_item(views, tiles, long_list[k], bucket, out, n, &alt);
-        if (ok && n > SORT_SMALL_MAX) {
-            if (n <= SORT_LARGE_MAX) {
-                merge_sort_tile<SORT_LARGE_THREADS, 16>(skeys, bucket, out, n);
+        const bool mine = THREADS == SORT_MEDIUM_THREADS ? (n > SORT_SMALL_MAX && n <= SORT_MEDIUM_MAX) : n > SORT_MEDIUM_MAX;
+        if (ok && mine) {
+            if (n <= CAP) {
+                merge_sort_tile<THREADS, 16>(skeys, bucket, out, n);
             } else {
-                // Longer than the LDS holds: sort 16384-key chunks in LDS into 64-bit keys (in place over the
-                // (depth,index) pairs), then merge the runs through L2 between the list and its alt buffer.
                 uint64_t* gk = reinterpret_cast<uint64_t*>(const_cast<uint2*>(bucket));
-                for (int c0 = 0; c0 < n; c0 += SORT_LARGE_MAX) {
-                    merge_sort_tile<SORT_LARGE_THREADS, 16>(skeys, bucket + c0, nullptr, min(SORT_LARGE_MAX, n - c0),
-                                                            gk + c0);
+                for (int c0 = 0; c0 < n; c0 += CAP) {
+                    merge_sort_tile<THREADS, 16>(skeys, bucket + c0, nullptr, min(CAP, n - c0), gk + c0);
                     __syncthreads();
                 }
                 uint64_t *src = gk, *dst = alt;
-                for (int run = SORT_LARGE_MAX; run < n; run <<= 1) {
-                    merge_round_global<SORT_LARGE_THREADS, 16>(src, dst, n, run);
+                for (int run = CAP; run < n; run <<= 1) {
+                    merge_round_global<THREADS, 16>(src, dst, n, run);
                     __syncthreads();
                     uint64_t* tmp = src; src = dst; dst = tmp;
                 }
-                for (int i = threadIdx.x; i < n; i += SORT_LARGE_THREADS) out[i] = (uint32_t)src[i];
+                for (int i = threadIdx.x; i < n; i += THREADS) out[i] = (uint32_t)src[i];
             }
         }
         __syncthreads();   // skeys reuse across loop iterations
