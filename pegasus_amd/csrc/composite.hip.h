@@ -292,89 +292,100 @@ finished:
 // ---- work order --------------------------------------------------------------------------------
 // The compositor's work items (view, tile, half) are laid out as NUM_XCD interleaved streams: position p
 // belongs to stream p % 8, and the hardware dispatcher is observed to place workgroup b on XCD b % 8
-// (MI355X_MICROARCH.md, a speed hint only -- any placement is correct).  Stream x owns every 8th row of
-// tiles of every view, so the two halves of a tile and its neighbours -- whose lists share most of their
-// Gaussians -- are gathered through the SAME XCD's L2 (measured before: 486 MB/view fetched from the fabric
-// for 161 MB of algorithmic bytes).  Inside a stream items are sorted by descending list length (256 log-spaced
-// classes) so long lists start first and short ones back-fill.  Unused slots hold INVALID_ITEM.
+// (MI355X_MICROARCH.md, a speed hint only -- any placement is correct).  Stream x owns every 8th band of
+// ORDER_BAND_ROWS tile rows of every view, and inside a stream the items keep their row-major order, so a tile's
+// two halves and its horizontal neighbours -- whose lists share most of their Gaussians -- run back to back on
+// the SAME XCD and find each other's gathers in its L2 (PMC before: 486 MB/view fetched from the fabric for
+// 161 MB of algorithmic bytes).  Only a coarse longest-first split is kept (ORDER_CLASSES_USED length classes:
+// the long lists of every stream start first, short ones back-fill).  Unused slots hold INVALID_ITEM.
+// Contiguous bands per XCD share more vertically but leave XCDs idle when the image's work is uneven
+// (measured 1.9x slower on C3); striping keeps every XCD's share statistically equal.
+constexpr int ORDER_BAND_ROWS = 1;
+constexpr int ORDER_CLASSES_USED = 3;            // > 4096, > 1024, rest
+constexpr int ORDER_BINS = NUM_XCD * ORDER_CLASSES_USED;
 
-// order_state layout (uint32): [NUM_XCD * ORDER_CLASSES] class counters -> cursors, then [1] number of long lists
-constexpr int ORDER_STATE_WORDS = NUM_XCD * ORDER_CLASSES + 1;
+// order_state layout (uint32): [ORDER_BINS] counters -> cursors, then [1] number of long lists
+constexpr int ORDER_STATE_WORDS = ORDER_BINS + 1;
 
-// Tile ROWS are dealt to the streams round-robin (row y -> stream y % 8): a contiguous band per XCD would
-// share more vertically but leaves XCDs idle when the image's work is uneven (measured: 1.9x slower on C3);
-// striping keeps every XCD's share statistically equal and still keeps a tile's two halves and its
-// horizontal neighbours -- most of the sharing -- on one L2.
-__device__ __forceinline__ int xcd_of_tile(int tile, int grid_x, int grid_y) {
-    (void)grid_y;
-    return (tile / grid_x) % NUM_XCD;
+__device__ __forceinline__ int xcd_of_tile(int tile, int grid_x) { return (tile / grid_x / ORDER_BAND_ROWS) % NUM_XCD; }
+
+__device__ __forceinline__ int coarse_class(uint32_t len) { return len > 4096u ? 0 : (len > 1024u ? 1 : 2); }
+
+__host__ __device__ inline int max_band_rows(int grid_y) {
+    const int bands = (grid_y + ORDER_BAND_ROWS - 1) / ORDER_BAND_ROWS;
+    return (bands + NUM_XCD - 1) / NUM_XCD * ORDER_BAND_ROWS;
 }
-
-__host__ __device__ inline int max_band_rows(int grid_y) { return (grid_y + NUM_XCD - 1) / NUM_XCD; }
 
 // grid = (ceil(tiles/256), n_views), 256 threads
 __global__ __launch_bounds__(256) void order_count_kernel(const ViewEntry* __restrict__ views, int tiles, int grid_x,
-                                                          int grid_y, uint32_t* __restrict__ state) {
-    __shared__ uint32_t hist[NUM_XCD * ORDER_CLASSES];
-    for (int k = threadIdx.x; k < NUM_XCD * ORDER_CLASSES; k += 256) hist[k] = 0;
+                                                          uint32_t* __restrict__ state) {
+    __shared__ uint32_t hist[ORDER_BINS];
+    if (threadIdx.x < ORDER_BINS) hist[threadIdx.x] = 0;
     __syncthreads();
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < tiles) {
         const uint2 r = views[blockIdx.y].ranges[t];
-        const int c = ORDER_CLASSES - 1 - min(length_class(r.y - r.x), ORDER_CLASSES - 1);   // descending
-        atomicAdd(&hist[xcd_of_tile(t, grid_x, grid_y) * ORDER_CLASSES + c], 2u);            // two halves per tile
+        atomicAdd(&hist[xcd_of_tile(t, grid_x) * ORDER_CLASSES_USED + coarse_class(r.y - r.x)], 2u);   // two halves
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < NUM_XCD * ORDER_CLASSES; k += 256)
-        if (hist[k]) atomicAdd(&state[k], hist[k]);
+    if (threadIdx.x < ORDER_BINS && hist[threadIdx.x]) atomicAdd(&state[threadIdx.x], hist[threadIdx.x]);
 }
 
-// 1 block of ORDER_CLASSES threads: per stream, exclusive prefix over the classes = write cursors
+// 1 thread per stream: exclusive prefix over the classes = write cursors
 __global__ void order_scan_kernel(uint32_t* __restrict__ state) {
-    __shared__ uint32_t s[ORDER_CLASSES];
-    const int t = threadIdx.x;
-    for (int x = 0; x < NUM_XCD; ++x) {
-        s[t] = state[x * ORDER_CLASSES + t];
-        __syncthreads();
-        uint32_t acc = 0;
-        for (int i = 0; i < t; ++i) acc += s[i];
-        state[x * ORDER_CLASSES + t] = acc;
-        __syncthreads();
+    const int x = threadIdx.x;
+    if (x >= NUM_XCD) return;
+    uint32_t acc = 0;
+    for (int c = 0; c < ORDER_CLASSES_USED; ++c) {
+        const uint32_t v = state[x * ORDER_CLASSES_USED + c];
+        state[x * ORDER_CLASSES_USED + c] = acc;
+        acc += v;
     }
 }
 
-// grid = (ceil(tiles/256), n_views), 256 threads.  work_order is pre-filled with INVALID_ITEM.  Slots are claimed
-// per workgroup (LDS histogram + ranks, one global atomic per non-empty (stream, class)); tiles whose list
-// exceeds `long_threshold` are also appended to long_list for the large sort tier.
+// grid = (ceil(tiles/256), n_views), 256 threads.  work_order is pre-filled with INVALID_ITEM.  Ranks inside a
+// workgroup follow the tile order (ballot prefix per bin), so row-major neighbours stay adjacent in their
+// stream; one global atomic per non-empty (workgroup, bin) claims the slots.  Tiles whose list exceeds
+// `long_threshold` are also appended to long_list for the long sort tiers.
 __global__ __launch_bounds__(256) void order_scatter_kernel(const ViewEntry* __restrict__ views, int tiles, int grid_x,
-                                                            int grid_y, uint32_t* __restrict__ state,
+                                                            uint32_t* __restrict__ state,
                                                             uint32_t* __restrict__ work_order, uint32_t long_threshold,
                                                             uint32_t* __restrict__ long_list) {
-    __shared__ uint32_t hist[NUM_XCD * ORDER_CLASSES];
+    __shared__ uint32_t wave_cnt[4][ORDER_BINS];
+    __shared__ uint32_t base[ORDER_BINS];
     __shared__ uint32_t n_long_s, long_base_s;
-    for (int k = threadIdx.x; k < NUM_XCD * ORDER_CLASSES; k += 256) hist[k] = 0;
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
     if (threadIdx.x == 0) n_long_s = 0;
     __syncthreads();
     const int t = blockIdx.x * 256 + threadIdx.x;
-    int bin = 0, x = 0;
-    uint32_t rank = 0, long_rank = INVALID_ITEM;
+    int bin = -1, x = 0;
+    uint32_t long_rank = INVALID_ITEM;
     if (t < tiles) {
         const uint2 r = views[blockIdx.y].ranges[t];
         const uint32_t len = r.y - r.x;
-        x = xcd_of_tile(t, grid_x, grid_y);
-        bin = x * ORDER_CLASSES + ORDER_CLASSES - 1 - min(length_class(len), ORDER_CLASSES - 1);
-        rank = atomicAdd(&hist[bin], 1u);
+        x = xcd_of_tile(t, grid_x);
+        bin = x * ORDER_CLASSES_USED + coarse_class(len);
         if (len > long_threshold) long_rank = atomicAdd(&n_long_s, 1u);
     }
-    __syncthreads();
-    for (int k = threadIdx.x; k < NUM_XCD * ORDER_CLASSES; k += 256) {
-        const uint32_t mine = hist[k];
-        if (mine) hist[k] = atomicAdd(&state[k], 2u * mine);      // hist now holds this workgroup's base
+    // ordered rank inside the wave, per bin
+    uint32_t rank = 0;
+    for (int b = 0; b < ORDER_BINS; ++b) {
+        const unsigned long long m = __ballot(bin == b);
+        if (bin == b) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave][b] = (uint32_t)__popcll(m);
     }
-    if (threadIdx.x == 0 && n_long_s) long_base_s = atomicAdd(&state[NUM_XCD * ORDER_CLASSES], n_long_s);
+    __syncthreads();
+    if (threadIdx.x < ORDER_BINS) {
+        const uint32_t tot = wave_cnt[0][threadIdx.x] + wave_cnt[1][threadIdx.x] + wave_cnt[2][threadIdx.x] +
+                             wave_cnt[3][threadIdx.x];
+        base[threadIdx.x] = tot ? atomicAdd(&state[threadIdx.x], 2u * tot) : 0u;
+    }
+    if (threadIdx.x == 0 && n_long_s) long_base_s = atomicAdd(&state[ORDER_BINS], n_long_s);
     __syncthreads();
     if (t < tiles) {
-        const uint32_t r0 = hist[bin] + 2u * rank;                // position inside stream x
+        uint32_t before = 0;
+        for (int w = 0; w < wave; ++w) before += wave_cnt[w][bin];
+        const uint32_t r0 = base[bin] + 2u * (before + rank);     // position inside stream x
         const uint32_t item = (uint32_t)blockIdx.y * 2u * (uint32_t)tiles + 2u * (uint32_t)t;
         work_order[(size_t)r0 * NUM_XCD + x] = item;
         work_order[(size_t)(r0 + 1) * NUM_XCD + x] = item + 1u;

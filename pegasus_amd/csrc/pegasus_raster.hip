@@ -275,11 +275,11 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         !hip_ok(hipMemsetAsync(work_order, 0xff, B.order_slots * 4, stream), "memset work order"))
         return PGR_ERR_LAUNCH_FAILURE;
     const dim3 og((L.tiles + 255) / 256, n_views);
-    order_count_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, L.grid_x, L.grid_y, order_state);
-    order_scan_kernel<<<1, ORDER_CLASSES, 0, stream>>>(order_state);
-    order_scatter_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, L.grid_x, L.grid_y, order_state, work_order,
+    order_count_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, L.grid_x, order_state);
+    order_scan_kernel<<<1, 64, 0, stream>>>(order_state);
+    order_scatter_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, L.grid_x, order_state, work_order,
                                                  (uint32_t)SORT_SMALL_MAX, long_list);
-    const uint32_t* n_long = order_state + NUM_XCD * ORDER_CLASSES;
+    const uint32_t* n_long = order_state + ORDER_BINS;
     tile_sort_long_kernel<SORT_LARGE_THREADS><<<std::min(n_views * L.tiles, 512), SORT_LARGE_THREADS, 0, stream>>>(
         bin_table, L.tiles, long_list, n_long);
     tile_sort_long_kernel<SORT_MEDIUM_THREADS><<<std::min(n_views * L.tiles, 1024), SORT_MEDIUM_THREADS, 0, stream>>>(
