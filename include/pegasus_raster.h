@@ -82,10 +82,8 @@ typedef struct PgrOutputs {
 
 /* Device pointers into one view's slice of a workspace, for stage-level parity tests and for backward. */
 typedef struct PgrWorkspaceView {
-    const float *xy;             /* [n,2] pixel centre */
-    const float *depth;          /* [n]   view-space z */
-    const float *conic_opacity;  /* [n,4] */
-    const float *rgb;            /* [n,4] (r,g,b,depth) */
+    const float *splats;         /* [n,12] per-Gaussian record: x, y, conic A, B, C, opacity, r, g, b, depth, 0, 0
+                                    (defined only for Gaussians with a non-empty rectangle) */
     const uint16_t *rects;       /* [n,4] tile rectangle minx,miny,maxx,maxy (max exclusive); zeros = culled */
     const uint32_t *gauss_sorted;/* [num_instances] Gaussian index, tile-major, (depth, index) ascending per tile */
     const uint32_t *ranges;      /* [tiles,2] start,end into gauss_sorted */

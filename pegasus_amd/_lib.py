@@ -46,8 +46,7 @@ class PgrObjectPose(C.Structure):
 
 
 class PgrWorkspaceView(C.Structure):
-    _fields_ = [(k, C.c_void_p) for k in ("xy", "depth", "conic_opacity", "rgb", "rects", "gauss_sorted", "ranges",
-                                          "num_instances")]
+    _fields_ = [(k, C.c_void_p) for k in ("splats", "rects", "gauss_sorted", "ranges", "num_instances")]
 
 
 # every symbol include/pegasus_raster.h declares: name -> (restype, argtypes)

@@ -13,7 +13,6 @@ namespace pgr {
 
 constexpr int NUM_XCD = 8;
 constexpr uint32_t INVALID_ITEM = 0xffffffffu;   // unused slot of the interleaved work order
-constexpr int COMP_THREADS = TILE * TILE;  // 256 = 4 waves; wave w owns pixel rows 4w..4w+3
 
 struct CompOut {
     float* color;        // [3,H,W]
@@ -27,92 +26,12 @@ struct alignas(16) ViewEntry {
     const CameraDev* cam;
     const uint2* ranges;
     const uint32_t* gauss_sorted;
-    const float2* xy;
-    const float4* conic_opacity;
-    const float4* rgbd;
+    const float4* splats;        // [n, 3] records: q0 = (x,y,A,B), q1 = (C,op,r,g), q2 = (b,depth,..)
     CompOut out;
     const uint32_t* counters;    // [1] != 0: instance overflow, the view must not be composited
-    uint64_t pad[1];
+    uint64_t pad[3];
 };
 static_assert(sizeof(ViewEntry) == 96, "ViewEntry layout");
-
-__global__ __launch_bounds__(COMP_THREADS) void composite_kernel(const CameraDev* __restrict__ camp,
-                                                                 const uint2* __restrict__ ranges,
-                                                                 const uint32_t* __restrict__ gauss_sorted,
-                                                                 const float2* __restrict__ xy,
-                                                                 const float4* __restrict__ conic_opacity,
-                                                                 const float4* __restrict__ rgbd, CompOut o) {
-    const CameraDev& cam = *camp;
-    const int W = cam.width, H = cam.height;
-    const int tile = blockIdx.x;
-    const int tile_x = tile % cam.grid_x, tile_y = tile / cam.grid_x;
-    const int lx = threadIdx.x & (TILE - 1), ly = threadIdx.x / TILE;
-    const int px = tile_x * TILE + lx, py = tile_y * TILE + ly;
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
-
-    const uint2 range = ranges[tile];
-    const int rounds = (int)((range.y - range.x + COMP_THREADS - 1) / COMP_THREADS);
-    int todo = (int)(range.y - range.x);
-
-    __shared__ float4 s_a[COMP_THREADS];  // x, y, hx, ny
-    __shared__ float4 s_b[COMP_THREADS];  // hz, opacity, r, g
-    __shared__ float2 s_c[COMP_THREADS];  // b, depth
-
-    bool done = !inside;
-    float T = 1.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f, D = 0.0f;
-    uint32_t contributor = 0, last = 0;
-
-    for (int r = 0; r < rounds; ++r, todo -= COMP_THREADS) {
-        if (__syncthreads_and(done)) break;
-        const int progress = r * COMP_THREADS + threadIdx.x;
-        if (range.x + progress < range.y) {
-            const uint32_t g = gauss_sorted[range.x + progress];
-            const float2 p = xy[g];
-            const float4 co = conic_opacity[g];
-            const float4 cd = rgbd[g];
-            s_a[threadIdx.x] = make_float4(p.x, p.y, -0.5f * co.x, -co.y);
-            s_b[threadIdx.x] = make_float4(-0.5f * co.z, co.w, cd.x, cd.y);
-            s_c[threadIdx.x] = make_float2(cd.z, cd.w);
-        }
-        __syncthreads();
-        const int cnt = todo < COMP_THREADS ? todo : COMP_THREADS;
-        for (int j = 0; !done && j < cnt; ++j) {
-            ++contributor;
-            const float4 a = s_a[j];
-            const float dx = a.x - pxf, dy = a.y - pyf;
-            const float4 b = s_b[j];
-            const float power = fmaf(dx, fmaf(a.z, dx, a.w * dy), (b.x * dy) * dy);
-            if (power > 0.0f) continue;
-            const float e = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
-            const float alpha = fminf(ALPHA_MAX, b.y * e);
-            if (alpha < ALPHA_MIN) continue;
-            const float test_T = fmaf(-alpha, T, T);
-            if (test_T < T_EPS) {
-                done = true;
-                continue;
-            }
-            const float2 c = s_c[j];
-            const float w = alpha * T;
-            Cr = fmaf(b.z, w, Cr);
-            Cg = fmaf(b.w, w, Cg);
-            Cb = fmaf(c.x, w, Cb);
-            D = fmaf(c.y, w, D);
-            T = test_T;
-            last = contributor;
-        }
-    }
-
-    if (inside) {
-        const size_t P = (size_t)W * H, pix = (size_t)py * W + px;
-        o.color[0 * P + pix] = fmaf(T, cam.bg[0], Cr);
-        o.color[1 * P + pix] = fmaf(T, cam.bg[1], Cg);
-        o.color[2 * P + pix] = fmaf(T, cam.bg[2], Cb);
-        o.depth[pix] = D;
-        if (o.final_T) o.final_T[pix] = T;
-        if (o.n_contrib) o.n_contrib[pix] = last;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // composite_wave_kernel: ONE WAVE per half tile (16 x 8 pixels), two pixels per lane.
@@ -142,9 +61,7 @@ __global__ __launch_bounds__(WAVE) void composite_wave_kernel(const ViewEntry* _
     const CameraDev& cam = *ve.cam;
     const uint2* __restrict__ ranges = ve.ranges;
     const uint32_t* __restrict__ gauss_sorted = ve.gauss_sorted;
-    const float2* __restrict__ xy = ve.xy;
-    const float4* __restrict__ conic_opacity = ve.conic_opacity;
-    const float4* __restrict__ rgbd = ve.rgbd;
+    const float4* __restrict__ splats = ve.splats;
     const CompOut o = ve.out;
     const int W = cam.width, H = cam.height;
     const int tile = (int)(item >> 1), half = (int)(item & 1);
@@ -174,10 +91,11 @@ __global__ __launch_bounds__(WAVE) void composite_wave_kernel(const ViewEntry* _
     float2 p = make_float2(0.f, 0.f);
     float4 co = make_float4(0.f, 0.f, 0.f, 0.f), cd = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lane < n) {
-        const uint32_t g = gauss_sorted[range.x + lane];
-        p = xy[g];
-        co = conic_opacity[g];
-        cd = rgbd[g];
+        const float4* rec = splats + (size_t)gauss_sorted[range.x + lane] * 3;
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+        p = make_float2(q0.x, q0.y);
+        co = make_float4(q0.z, q0.w, q1.x, q1.y);
+        cd = make_float4(q1.z, q1.w, q2.x, q2.y);
     }
 
     // the wave's pixel-centre rectangle (clipped to the image), for the per-entry skip test
@@ -214,10 +132,11 @@ __global__ __launch_bounds__(WAVE) void composite_wave_kernel(const ViewEntry* _
         co = make_float4(0.f, 0.f, 0.f, 0.f);
         cd = make_float4(0.f, 0.f, 0.f, 0.f);
         if (base + WAVE_BATCH + lane < n) {
-            const uint32_t g = gauss_sorted[range.x + base + WAVE_BATCH + lane];
-            p = xy[g];
-            co = conic_opacity[g];
-            cd = rgbd[g];
+            const float4* rec = splats + (size_t)gauss_sorted[range.x + base + WAVE_BATCH + lane] * 3;
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+            p = make_float2(q0.x, q0.y);
+            co = make_float4(q0.z, q0.w, q1.x, q1.y);
+            cd = make_float4(q1.z, q1.w, q2.x, q2.y);
         }
         for (int j0 = 0; j0 < cnt; j0 += 8) {
 #pragma unroll

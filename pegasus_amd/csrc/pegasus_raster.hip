@@ -46,10 +46,7 @@ static Layout make_layout(int32_t n, int32_t width, int32_t height, int64_t max_
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes ? bytes : 1); return o; };
     L.cam = take(sizeof(CameraDev));
     L.counters = take(64);
-    L.xy = take(N * 8);
-    L.depth = take(N * 4);
-    L.conic_opacity = take(N * 16);
-    L.rgb = take(N * 16);
+    L.splats = take(N * 48);
     L.radii = take(N * 4);
     L.rects = take(N * 8);
     L.crects = take(N * 8);
@@ -79,10 +76,7 @@ static int check_scene(const PgrScene* s) {
 struct ViewWs {
     CameraDev* cam;
     uint32_t* counters;
-    float2* xy;
-    float* depth;
-    float4* conop;
-    float4* rgbd;
+    float4* splats;   // [n,3] per-Gaussian records
     int32_t* radii;   // per-view home of radii when the caller passes no radii output
     uint2 *rects, *crects;
     uint32_t *tile_count, *rel;
@@ -96,10 +90,7 @@ static ViewWs carve(char* ws, const Layout& L) {
     ViewWs v;
     v.cam = reinterpret_cast<CameraDev*>(ws + L.cam);
     v.counters = reinterpret_cast<uint32_t*>(ws + L.counters);
-    v.xy = reinterpret_cast<float2*>(ws + L.xy);
-    v.depth = reinterpret_cast<float*>(ws + L.depth);
-    v.conop = reinterpret_cast<float4*>(ws + L.conic_opacity);
-    v.rgbd = reinterpret_cast<float4*>(ws + L.rgb);
+    v.splats = reinterpret_cast<float4*>(ws + L.splats);
     v.radii = reinterpret_cast<int32_t*>(ws + L.radii);
     v.rects = reinterpret_cast<uint2*>(ws + L.rects);
     v.crects = reinterpret_cast<uint2*>(ws + L.crects);
@@ -229,15 +220,14 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         vw[v].counters = status_dev + 2 * v;   // and so are the status words: one D2H copy per batch
         ViewEntry& e = table[v];
         memset(&e, 0, sizeof(e));
-        e.cam = vw[v].cam; e.ranges = vw[v].ranges; e.gauss_sorted = vw[v].gauss_sorted; e.xy = vw[v].xy;
-        e.conic_opacity = vw[v].conop; e.rgbd = vw[v].rgbd;
+        e.cam = vw[v].cam; e.ranges = vw[v].ranges; e.gauss_sorted = vw[v].gauss_sorted; e.splats = vw[v].splats;
         e.out = CompOut{outs[v].color, outs[v].depth, outs[v].final_T, outs[v].n_contrib};
         e.counters = vw[v].counters;
         want_aux = want_aux || outs[v].final_T || outs[v].n_contrib;
-        bins[v] = BinView{vw[v].crects, vw[v].depth, vw[v].xy, vw[v].conop, vw[v].tile_count, vw[v].rel, vw[v].ranges,
+        bins[v] = BinView{vw[v].crects, vw[v].splats, vw[v].tile_count, vw[v].rel, vw[v].ranges,
                           vw[v].counters, vw[v].bucket, vw[v].gauss_sorted, vw[v].alt};
         // radii is part of the per-view contract; when the caller does not want it, it lands in the workspace
-        pres[v] = PreOut{vw[v].xy, vw[v].depth, vw[v].conop, vw[v].rgbd, vw[v].rects, vw[v].crects,
+        pres[v] = PreOut{vw[v].splats, vw[v].rects, vw[v].crects,
                          outs[v].radii ? outs[v].radii : vw[v].radii};
     }
     if (!hip_ok(hipMemcpyAsync(ws + B.tables, hs, B.tables_bytes, hipMemcpyHostToDevice, stream), "memcpy tables"))
@@ -351,10 +341,7 @@ int32_t pgr_workspace_view(void* workspace, size_t workspace_bytes, int32_t n, i
     const BatchLayout B = make_batch_layout(L, n_views);
     if (workspace_bytes < B.total) return PGR_ERR_WORKSPACE_TOO_SMALL;
     const ViewWs w = carve(static_cast<char*>(workspace) + B.views + (size_t)view_index * B.per_view, L);
-    v->xy = reinterpret_cast<const float*>(w.xy);
-    v->depth = w.depth;
-    v->conic_opacity = reinterpret_cast<const float*>(w.conop);
-    v->rgb = reinterpret_cast<const float*>(w.rgbd);
+    v->splats = reinterpret_cast<const float*>(w.splats);
     v->rects = reinterpret_cast<const uint16_t*>(w.rects);
     v->gauss_sorted = w.gauss_sorted;
     v->ranges = reinterpret_cast<const uint32_t*>(w.ranges);

@@ -38,9 +38,7 @@ __device__ __forceinline__ uint2 pack_rect(int minx, int miny, int maxx, int max
 
 struct BinView {                 // per-view pointers used by the binning kernels (device table)
     const uint2* rects;          // [n] packed CANDIDATE tile rectangles (preprocess.hip.h candidate_rect)
-    const float* depth;          // [n]
-    const float2* xy;            // [n]
-    const float4* conic_opacity; // [n]
+    const float4* splats;        // [n, 3] records (preprocess.hip.h): q0 = (x,y,A,B), q1 = (C,op,r,g), q2 = (b,depth,..)
     uint32_t* tile_count;        // [tiles] zero-filled before bin_count
     uint32_t* rel;               // [chunks, tiles]
     uint2* ranges;               // [tiles]
@@ -84,8 +82,9 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restr
                 const int w = (int)(r.y & 0xffff) - (int)(r.x & 0xffff), h = (int)(r.y >> 16) - (int)(r.x >> 16);
                 if (w > 0 && h > 0) {
                     area = w * h;
-                    cs = make_cull_splat(bv.xy[i], bv.conic_opacity[i]);
-                    if (SCATTER) dbits = __float_as_uint(bv.depth[i]);
+                    const float4 q0 = bv.splats[(size_t)i * 3], q1 = bv.splats[(size_t)i * 3 + 1];
+                    cs = make_cull_splat(make_float2(q0.x, q0.y), make_float4(q0.z, q0.w, q1.x, q1.y));
+                    if (SCATTER) dbits = __float_as_uint(bv.splats[(size_t)i * 3 + 2].y);
                 }
             }
             int incl = area;

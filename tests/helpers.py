@@ -52,10 +52,11 @@ def fetch_workspace(view_index, n, width, height):
         off = ptr - base
         return ws[off:off + nbytes].cpu().numpy().view(dtype).copy()
     r = {}
-    r["xy"] = grab(v["xy"], 2 * n, np.float32).reshape(n, 2)
-    r["depth"] = grab(v["depth"], n, np.float32)
-    r["conic_opacity"] = grab(v["conic_opacity"], 4 * n, np.float32).reshape(n, 4)
-    r["rgb4"] = grab(v["rgb"], 4 * n, np.float32).reshape(n, 4)
+    rec = grab(v["splats"], 12 * n, np.float32).reshape(n, 12)
+    r["xy"] = np.ascontiguousarray(rec[:, 0:2])
+    r["conic_opacity"] = np.ascontiguousarray(rec[:, 2:6])
+    r["rgb4"] = np.ascontiguousarray(rec[:, 6:10])
+    r["depth"] = np.ascontiguousarray(rec[:, 9])
     rects = grab(v["rects"], 4 * n, np.uint16).reshape(n, 4).astype(np.int32)
     r["rects"] = rects
     r["tiles_touched"] = (rects[:, 2] - rects[:, 0]) * (rects[:, 3] - rects[:, 1])
