@@ -180,9 +180,10 @@ int32_t pgr_compose_object(int32_t n, const float *xyz, const float *rot, const 
 int32_t pgr_mark_visible(int32_t n, const float *means3d, const float *viewmatrix, uint8_t *present,
                          void *stream);
 
-/* masks[k,y,x] = || img[:,y,x] - colors[k,:] ||_2 <= threshold   (uint8 0/1), img is CHW fp32. */
-int32_t pgr_color_masks(const float *img_chw, int32_t width, int32_t height, const float *colors_k3,
-                        int32_t k, float threshold, uint8_t *masks_khw, void *stream);
+/* masks[b,k,y,x] = || img[b,:,y,x] - colors[k,:] ||_2 <= threshold   (uint8 0/1); img is a contiguous batch of
+ * n_images CHW fp32 images, masks the matching [n_images,k,H,W] batch. */
+int32_t pgr_color_masks(const float *img_chw, int32_t n_images, int32_t width, int32_t height,
+                        const float *colors_k3, int32_t k, float threshold, uint8_t *masks_khw, void *stream);
 
 /* rgb_hwc = uint8(img*255) (wraps, no clamp), depth_mm = uint16(depth*1000). Either pair may be NULL. */
 int32_t pgr_quantize_frame(const float *img_chw, const float *depth_hw, int32_t width, int32_t height,

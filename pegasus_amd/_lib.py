@@ -75,7 +75,7 @@ SYMBOLS = {
                                        C.POINTER(PgrObjectPose), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                        C.c_void_p]),
     "pgr_mark_visible": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "pgr_color_masks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
+    "pgr_color_masks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
                                     C.c_void_p, C.c_void_p]),
     "pgr_quantize_frame": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),

@@ -315,10 +315,13 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const ViewEntry* __r
 // ---- frame post-processing ---------------------------------------
 
 // masks[k,p] = || img[:,p] - colors[k] ||_2 <= thr   (reference: src/gs/render.py:60-63,89-93)
+// grid.y = image index of a contiguous batch: img [B,3,P], masks [B,k,P]
 __global__ void color_masks_kernel(const float* __restrict__ img, size_t P, const float* __restrict__ colors, int k,
                                    float thr, uint8_t* __restrict__ masks) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
+    img += (size_t)blockIdx.y * 3 * P;
+    masks += (size_t)blockIdx.y * (size_t)k * P;
     const float r = img[p], g = img[P + p], b = img[2 * P + p];
     for (int c = 0; c < k; ++c) {
         const float d0 = r - colors[3 * c], d1 = g - colors[3 * c + 1], d2 = b - colors[3 * c + 2];

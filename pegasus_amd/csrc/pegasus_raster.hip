@@ -50,7 +50,6 @@ static Layout make_layout(int32_t n, int32_t width, int32_t height, int64_t max_
     L.radii = take(N * 4);
     L.rects = take(N * 8);
     L.crects = take(N * 8);
-    L.tile_count = take((size_t)L.tiles * 4);
     L.rel = take((size_t)L.n_chunks * L.tiles * 4);
     L.ranges = take((size_t)L.tiles * 8);
     L.bucket = take(I * 8);
@@ -94,7 +93,7 @@ static ViewWs carve(char* ws, const Layout& L) {
     v.radii = reinterpret_cast<int32_t*>(ws + L.radii);
     v.rects = reinterpret_cast<uint2*>(ws + L.rects);
     v.crects = reinterpret_cast<uint2*>(ws + L.crects);
-    v.tile_count = reinterpret_cast<uint32_t*>(ws + L.tile_count);
+    v.tile_count = nullptr;   // lives in the batch header (BatchLayout::tile_counts)
     v.rel = reinterpret_cast<uint32_t*>(ws + L.rel);
     v.ranges = reinterpret_cast<uint2*>(ws + L.ranges);
     v.bucket = reinterpret_cast<uint2*>(ws + L.bucket);
@@ -105,7 +104,7 @@ static ViewWs carve(char* ws, const Layout& L) {
 
 // Batch header placed in front of the per-view slices.
 struct BatchLayout {
-    size_t tables, cams, status, order_state, work_order, long_list, views, total;
+    size_t tables, cams, status, tile_counts, order_state, work_order, long_list, views, total;
     size_t view_table_off, bin_table_off, pre_table_off, tables_bytes;   // inside `tables` (one H2D copy)
     size_t order_slots;
     size_t per_view;
@@ -128,6 +127,7 @@ static BatchLayout make_batch_layout(const Layout& L, int n_views) {
     B.tables = take(B.tables_bytes);
     B.cams = take((size_t)n_views * sizeof(CameraDev));
     B.status = take((size_t)n_views * 8);          // per view: [0] listed instances, [1] overflow flag
+    B.tile_counts = take((size_t)n_views * L.tiles * 4);   // contiguous across views: one memset per batch
     B.order_state = take(ORDER_STATE_WORDS * 4);
     // NUM_XCD interleaved streams; each holds the items of its band of tile rows for every view
     B.order_slots = (size_t)NUM_XCD * max_band_rows(L.grid_y) * L.grid_x * 2 * n_views;
@@ -218,6 +218,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         vw[v] = carve(ws + B.views + (size_t)v * B.per_view, L);
         vw[v].cam = cams_dev + v;          // cameras of a batch are contiguous: preprocess walks them
         vw[v].counters = status_dev + 2 * v;   // and so are the status words: one D2H copy per batch
+        vw[v].tile_count = reinterpret_cast<uint32_t*>(ws + B.tile_counts) + (size_t)v * L.tiles;
         ViewEntry& e = table[v];
         memset(&e, 0, sizeof(e));
         e.cam = vw[v].cam; e.ranges = vw[v].ranges; e.gauss_sorted = vw[v].gauss_sorted; e.splats = vw[v].splats;
@@ -235,10 +236,15 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
 
     // ---- stage 0: camera pack + per-Gaussian preprocess
     mark(0);
-    for (int v = 0; v < n_views; ++v) {
-        const PgrCamera& c = cams[v];
-        pack_camera_kernel<<<1, 64, 0, stream>>>(c.viewmatrix, c.projmatrix, c.campos, c.bg, c.tanfovx, c.tanfovy, W, H,
-                                                 vw[v].cam);
+    for (int v0 = 0; v0 < n_views; v0 += CAM_PACK_MAX) {
+        CamPack cp;
+        const int cnt = std::min(CAM_PACK_MAX, n_views - v0);
+        for (int k = 0; k < cnt; ++k) {
+            const PgrCamera& c = cams[v0 + k];
+            cp.view[k] = c.viewmatrix; cp.proj[k] = c.projmatrix; cp.campos[k] = c.campos; cp.bg[k] = c.bg;
+            cp.tanfovx[k] = c.tanfovx; cp.tanfovy[k] = c.tanfovy;
+        }
+        pack_camera_kernel<<<cnt, 64, 0, stream>>>(cp, W, H, cams_dev + v0);
     }
     // one pass over the Gaussians for the whole batch (scene data read once, per-view outputs written)
     switch (scene->shs ? scene->sh_degree : 0) {
@@ -251,9 +257,8 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     // ---- stage 1: per-chunk LDS tile histograms + slice reservation, then the tile scan (device only)
     const int grid_x = (W + TILE - 1) / TILE;
     const size_t lds = (size_t)std::min(L.tiles, BIN_LDS_TILES) * 4;
-    for (int v = 0; v < n_views; ++v)
-        if (!hip_ok(hipMemsetAsync(vw[v].tile_count, 0, (size_t)L.tiles * 4, stream), "memset tile_count"))
-            return PGR_ERR_LAUNCH_FAILURE;
+    if (!hip_ok(hipMemsetAsync(ws + B.tile_counts, 0, (size_t)n_views * L.tiles * 4, stream), "memset tile counts"))
+        return PGR_ERR_LAUNCH_FAILURE;
     bin_kernel<false><<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(bin_table, N, grid_x, L.tiles, W, H);
     tile_scan_kernel<<<n_views, 1024, 0, stream>>>(bin_table, L.tiles, (uint32_t)max_instances);
     mark(2);
@@ -431,13 +436,14 @@ int32_t pgr_mark_visible(int32_t n, const float* means3d, const float* viewmatri
     return hip_ok(hipGetLastError(), "mark_visible launch") ? PGR_OK : PGR_ERR_LAUNCH_FAILURE;
 }
 
-int32_t pgr_color_masks(const float* img_chw, int32_t width, int32_t height, const float* colors_k3, int32_t k,
-                        float threshold, uint8_t* masks_khw, void* stream_v) {
-    if (!img_chw || width <= 0 || height <= 0 || k < 0 || (k > 0 && (!colors_k3 || !masks_khw)))
+int32_t pgr_color_masks(const float* img_chw, int32_t n_images, int32_t width, int32_t height, const float* colors_k3,
+                        int32_t k, float threshold, uint8_t* masks_khw, void* stream_v) {
+    if (!img_chw || n_images < 0 || n_images > 65535 || width <= 0 || height <= 0 || k < 0 ||
+        (k > 0 && (!colors_k3 || !masks_khw)))
         return PGR_ERR_INVALID_ARGUMENT;
-    if (k == 0) return PGR_OK;
+    if (k == 0 || n_images == 0) return PGR_OK;
     const size_t P = (size_t)width * height;
-    color_masks_kernel<<<(unsigned)((P + 255) / 256), 256, 0, static_cast<hipStream_t>(stream_v)>>>(
+    color_masks_kernel<<<dim3((unsigned)((P + 255) / 256), n_images), 256, 0, static_cast<hipStream_t>(stream_v)>>>(
         img_chw, P, colors_k3, k, threshold, masks_khw);
     return hip_ok(hipGetLastError(), "color_masks launch") ? PGR_OK : PGR_ERR_LAUNCH_FAILURE;
 }

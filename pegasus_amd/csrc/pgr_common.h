@@ -34,7 +34,7 @@ static_assert(sizeof(CameraDev) == 256, "CameraDev must be 256 B");
 
 // Workspace carve-up (all offsets multiples of 256 B).
 struct Layout {
-    size_t cam, counters, splats, radii, rects, crects, tile_count, rel, ranges, bucket, alt,
+    size_t cam, counters, splats, radii, rects, crects, rel, ranges, bucket, alt,
         gauss_sorted, total;
     int32_t tiles, grid_x, grid_y;
     int32_t n_blocks;

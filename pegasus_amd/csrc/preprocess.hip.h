@@ -307,21 +307,30 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_batch_kernel(PgrScene sc
     }
 }
 
-// packs the caller's four device-side camera tensors + host scalars into one CameraDev
-__global__ void pack_camera_kernel(const float* __restrict__ view, const float* __restrict__ proj,
-                                   const float* __restrict__ campos, const float* __restrict__ bg, float tanfovx,
-                                   float tanfovy, int width, int height, CameraDev* out) {
-    // one launch per view: the four tensors come from the caller as separate device pointers
-    const int t = threadIdx.x;
+// packs the callers' four device-side camera tensors + host scalars into CameraDev records, one workgroup per
+// view (up to CAM_PACK_MAX views per launch; the pointers travel in the launch arguments)
+constexpr int CAM_PACK_MAX = 32;
+struct CamPack {
+    const float* view[CAM_PACK_MAX];
+    const float* proj[CAM_PACK_MAX];
+    const float* campos[CAM_PACK_MAX];
+    const float* bg[CAM_PACK_MAX];
+    float tanfovx[CAM_PACK_MAX], tanfovy[CAM_PACK_MAX];
+};
+
+__global__ void pack_camera_kernel(CamPack p, int width, int height, CameraDev* __restrict__ outs) {
+    const int v = blockIdx.x, t = threadIdx.x;
+    CameraDev* out = outs + v;
     if (t < 16) {
-        out->view[t] = view[t];
-        out->proj[t] = proj[t];
+        out->view[t] = p.view[v][t];
+        out->proj[t] = p.proj[v][t];
     }
     if (t < 3) {
-        out->campos[t] = campos[t];
-        out->bg[t] = bg[t];
+        out->campos[t] = p.campos[v][t];
+        out->bg[t] = p.bg[v][t];
     }
     if (t == 0) {
+        const float tanfovx = p.tanfovx[v], tanfovy = p.tanfovy[v];
         out->tanfovx = tanfovx;
         out->tanfovy = tanfovy;
         out->focal_x = (float)width / (2.0f * tanfovx);

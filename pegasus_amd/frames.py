@@ -91,8 +91,7 @@ class FrameRenderer:
                 h2 = R.forward_views(self.obj["means3d"], self.obj["opacities"], specs, shs=self.sem_shs,
                                      scales=self.obj["scales"], rotations=self.obj["rotations"], sh_degree=0,
                                      want_radii=False, outputs=souts, async_slot=("sem", slot))
-                for i in range(B):
-                    M.color_masks(frames["seg"][i], self.colors, M.MASK_THRESHOLD, out=frames["masks"][i])
+                M.color_masks(frames["seg"][:B], self.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])
                 ev_masks = torch.cuda.Event()
                 ev_masks.record(s_sem)
             cur.wait_stream(s_sem)
@@ -108,8 +107,7 @@ class FrameRenderer:
                     h2.wait()
                     ev_masks.synchronize()
                     if h2.results is not before:      # semantic pass was re-rendered after an overflow: redo masks
-                        for i in range(B):
-                            M.color_masks(frames["seg"][i], renderer.colors, M.MASK_THRESHOLD, out=frames["masks"][i])
+                        M.color_masks(frames["seg"][:B], renderer.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])
                         torch.cuda.current_stream(dev).synchronize()
                 return frames
         return _Pending()
@@ -131,6 +129,5 @@ class FrameRenderer:
             R.forward_views(self.obj["means3d"], self.obj["opacities"], specs, shs=self.sem_shs,
                             scales=self.obj["scales"], rotations=self.obj["rotations"], sh_degree=0,
                             want_radii=False, outputs=souts, stage_ms=sem_stage_ms)
-            for i in range(B):
-                M.color_masks(frames["seg"][i], self.colors, M.MASK_THRESHOLD, out=frames["masks"][i])
+            M.color_masks(frames["seg"][:B], self.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])
         return frames

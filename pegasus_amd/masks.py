@@ -39,18 +39,21 @@ def _stream(device):
 
 def color_masks(img_chw: torch.Tensor, colors: torch.Tensor, threshold: float = MASK_THRESHOLD,
                 out: torch.Tensor = None) -> torch.Tensor:
-    """uint8 [K,H,W]: 1 where the rendered colour is within ``threshold`` (L2) of semantic colour k."""
+    """uint8 [K,H,W] (or [B,K,H,W] for a [B,3,H,W] batch, one launch): 1 where the rendered colour is within
+    ``threshold`` (L2) of semantic colour k."""
     L = _lib.lib()
     if img_chw.device.type != "cuda":
         raise RuntimeError("color_masks needs a HIP device tensor; there is no CPU path")
     img = img_chw.contiguous().float()
     colors = colors.to(img.device).contiguous().float().reshape(-1, 3)
-    _, H, W = img.shape
+    batched = img.dim() == 4
+    nb = img.shape[0] if batched else 1
+    H, W = img.shape[-2:]
     K = colors.shape[0]
     if out is None:
-        out = torch.empty((K, H, W), dtype=torch.uint8, device=img.device)
+        out = torch.empty(((nb, K, H, W) if batched else (K, H, W)), dtype=torch.uint8, device=img.device)
     with torch.cuda.device(img.device):
-        _lib.check(L.pgr_color_masks(C.c_void_p(img.data_ptr()), W, H, C.c_void_p(colors.data_ptr()), K,
+        _lib.check(L.pgr_color_masks(C.c_void_p(img.data_ptr()), nb, W, H, C.c_void_p(colors.data_ptr()), K,
                                      float(threshold), C.c_void_p(out.data_ptr()), _stream(img.device)),
                    "pgr_color_masks")
     return out

@@ -59,7 +59,7 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     with pytest.raises(ValueError):
         _lib.check(rc, "pgr_forward")
     assert lib.pgr_mark_visible(-1, None, None, None, None) == _lib.PGR_ERR_INVALID_ARGUMENT
-    assert lib.pgr_color_masks(None, 8, 8, None, 1, 0.1, None, None) == _lib.PGR_ERR_INVALID_ARGUMENT
+    assert lib.pgr_color_masks(None, 1, 8, 8, None, 1, 0.1, None, None) == _lib.PGR_ERR_INVALID_ARGUMENT
 
 
 def test_rasterizer_refuses_cpu_tensors():

@@ -163,7 +163,7 @@ def test_masks_and_quantisation(oracle, gpu_device):
     mm = torch.zeros((H, W), dtype=torch.int16, device=dev)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: C.c_void_p(t.data_ptr())
-    _lib.check(L.pgr_color_masks(P(timg), W, H, P(tcol), K, 0.1, P(masks), st))
+    _lib.check(L.pgr_color_masks(P(timg), 1, W, H, P(tcol), K, 0.1, P(masks), st))
     _lib.check(L.pgr_quantize_frame(P(timg), P(tdepth), W, H, P(rgb8), P(mm), st))
     torch.cuda.synchronize()
     np.testing.assert_array_equal(masks.cpu().numpy(), oracle.color_masks(img, colors, 0.1))
