@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--views", type=int, default=64, help="distinct cameras cycled through")
     ap.add_argument("--batch", type=int, default=16, help="views per step (one pgr_forward_batch call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--separate-semantic", action="store_true",
+                    help="semantic image by a second full pass over the objects (default: fused into the scene pass)")
     ap.add_argument("--sync-steps", action="store_true", help="one blocking render_batch per step (no pipelining)")
     ap.add_argument("--raster-only", action="store_true", help="time only the full-scene RGB+depth pass (R), no masks")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
@@ -129,7 +131,8 @@ def main():
             return
         pending = None
         for i in range(first, first + count):
-            h = fr.render_batch_async(batch_views(i), frames if i % 2 == 0 else frames2, masks=with_masks, slot=i % 2)
+            render = fr.render_batch_async if args.separate_semantic else fr.render_frames_async
+            h = render(batch_views(i), frames if i % 2 == 0 else frames2, masks=with_masks, slot=i % 2)
             if pending is not None:
                 pending.wait()
             pending = h

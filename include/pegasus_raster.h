@@ -78,7 +78,21 @@ typedef struct PgrOutputs {
     int32_t *radii;              /* [n]      required */
     float *final_T;              /* [H,W]    optional (NULL) */
     uint32_t *n_contrib;         /* [H,W]    optional (NULL) */
+    float *sem_color;            /* [3,H,W]  optional: the objects-only semantic render (PgrSemantic), else NULL */
+    float *sem_depth;            /* [1,H,W]  optional, only with sem_color */
 } PgrOutputs;
+
+/* Fused semantic pass: PEGASUS renders the objects alone, painted in flat semantic colours, to derive masks
+ * (/root/reference/src/gs/render.py:68-97, colours from pegasus.py:230-232).  With this descriptor the batch
+ * call also writes that image (outs[v].sem_color) from the SAME per-tile lists -- the objects-only list of a
+ * tile is the scene's list minus the environment entries -- instead of a second preprocess/bin/sort/composite. */
+typedef struct PgrSemantic {
+    const int32_t *object_id;    /* device [n]: 0 = environment, k = object k (1..k_objects) */
+    const float *colors;         /* device [k_objects,3]: the rgb each object's Gaussians carry =
+                                    max(C0 * RGB2SH(c_k) + 0.5, 0), evaluated in fp32 in that order */
+    int32_t n_env;               /* Gaussians [0, n_env) are the environment */
+    int32_t k_objects;
+} PgrSemantic;
 
 /* Device pointers into one view's slice of a workspace, for stage-level parity tests and for backward. */
 typedef struct PgrWorkspaceView {
@@ -132,6 +146,11 @@ int32_t pgr_forward_batch_async(const PgrScene *scene, int32_t n_views, const Pg
                                 const PgrOutputs *outs, void *workspace, size_t workspace_bytes,
                                 int64_t max_instances_per_view, void *host_scratch, size_t host_scratch_size,
                                 void *stream);
+/* Same, with the fused semantic pass (`semantic` may be NULL = plain batch). */
+int32_t pgr_forward_frames_async(const PgrScene *scene, const PgrSemantic *semantic, int32_t n_views,
+                                 const PgrCamera *cameras, const PgrOutputs *outs, void *workspace,
+                                 size_t workspace_bytes, int64_t max_instances_per_view, void *host_scratch,
+                                 size_t host_scratch_size, void *stream);
 int32_t pgr_batch_status(const void *host_scratch, int32_t n_views, int64_t *num_instances);
 
 /* Profiling twin of pgr_forward_batch (bench / rocprof only): records HIP events on `stream` at the

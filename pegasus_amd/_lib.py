@@ -37,7 +37,11 @@ class PgrCamera(C.Structure):
 
 class PgrOutputs(C.Structure):
     _fields_ = [("color", C.c_void_p), ("depth", C.c_void_p), ("radii", C.c_void_p), ("final_T", C.c_void_p),
-                ("n_contrib", C.c_void_p)]
+                ("n_contrib", C.c_void_p), ("sem_color", C.c_void_p), ("sem_depth", C.c_void_p)]
+
+
+class PgrSemantic(C.Structure):
+    _fields_ = [("object_id", C.c_void_p), ("colors", C.c_void_p), ("n_env", C.c_int32), ("k_objects", C.c_int32)]
 
 
 class PgrObjectPose(C.Structure):
@@ -65,6 +69,9 @@ SYMBOLS = {
     "pgr_forward_batch_async": (C.c_int32, [C.POINTER(PgrScene), C.c_int32, C.POINTER(PgrCamera),
                                             C.POINTER(PgrOutputs), C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p,
                                             C.c_size_t, C.c_void_p]),
+    "pgr_forward_frames_async": (C.c_int32, [C.POINTER(PgrScene), C.POINTER(PgrSemantic), C.c_int32,
+                                             C.POINTER(PgrCamera), C.POINTER(PgrOutputs), C.c_void_p, C.c_size_t,
+                                             C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pgr_batch_status": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "pgr_forward_batch_profiled": (C.c_int32, [C.POINTER(PgrScene), C.c_int32, C.POINTER(PgrCamera),
                                                C.POINTER(PgrOutputs), C.c_void_p, C.c_size_t, C.c_int64,

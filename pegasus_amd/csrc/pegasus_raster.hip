@@ -158,6 +158,10 @@ static int zero_outputs(const PgrOutputs* out, size_t P, hipStream_t stream) {
         return PGR_ERR_LAUNCH_FAILURE;
     if (out->n_contrib && !hip_ok(hipMemsetAsync(out->n_contrib, 0, P * sizeof(uint32_t), stream), "memset n"))
         return PGR_ERR_LAUNCH_FAILURE;
+    if (out->sem_color && !hip_ok(hipMemsetAsync(out->sem_color, 0, 3 * P * sizeof(float), stream), "memset sem"))
+        return PGR_ERR_LAUNCH_FAILURE;
+    if (out->sem_depth && !hip_ok(hipMemsetAsync(out->sem_depth, 0, P * sizeof(float), stream), "memset semd"))
+        return PGR_ERR_LAUNCH_FAILURE;
     return PGR_OK;
 }
 
@@ -169,7 +173,7 @@ static int zero_outputs(const PgrOutputs* out, size_t P, hipStream_t stream) {
 static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrCamera* cams, const PgrOutputs* outs,
                                   void* workspace, size_t workspace_bytes, int64_t max_instances,
                                   int64_t* num_instances, hipStream_t stream, hipEvent_t* ev,
-                                  void* host_scratch = nullptr) {
+                                  void* host_scratch = nullptr, const PgrSemantic* semantic = nullptr) {
     auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], stream); };
     if (n_views <= 0 || !cams || !outs) return PGR_ERR_INVALID_ARGUMENT;
     if (num_instances) for (int v = 0; v < n_views; ++v) num_instances[v] = 0;
@@ -213,7 +217,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     auto* bins = reinterpret_cast<BinView*>(hs + B.bin_table_off);
     auto* pres = reinterpret_cast<PreOut*>(hs + B.pre_table_off);
     auto* h_status = reinterpret_cast<uint32_t*>(hs + B.tables_bytes);
-    bool want_aux = false;
+    bool want_aux = false, want_sem = false;
     for (int v = 0; v < n_views; ++v) {
         vw[v] = carve(ws + B.views + (size_t)v * B.per_view, L);
         vw[v].cam = cams_dev + v;          // cameras of a batch are contiguous: preprocess walks them
@@ -224,6 +228,8 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         e.cam = vw[v].cam; e.ranges = vw[v].ranges; e.gauss_sorted = vw[v].gauss_sorted; e.splats = vw[v].splats;
         e.out = CompOut{outs[v].color, outs[v].depth, outs[v].final_T, outs[v].n_contrib};
         e.counters = vw[v].counters;
+        e.sem = CompOut{semantic ? outs[v].sem_color : nullptr, semantic ? outs[v].sem_depth : nullptr, nullptr, nullptr};
+        want_sem = want_sem || (semantic && outs[v].sem_color);
         want_aux = want_aux || outs[v].final_T || outs[v].n_contrib;
         bins[v] = BinView{vw[v].crects, vw[v].splats, vw[v].tile_count, vw[v].rel, vw[v].ranges,
                           vw[v].counters, vw[v].bucket, vw[v].gauss_sorted, vw[v].alt};
@@ -288,6 +294,12 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         composite_wave_kernel<true><<<slots, WAVE, 0, stream>>>(view_table, items_per_view, work_order);
     else
         composite_wave_kernel<false><<<slots, WAVE, 0, stream>>>(view_table, items_per_view, work_order);
+    if (want_sem) {
+        if (!semantic->object_id || !semantic->colors || semantic->n_env < 0 || semantic->k_objects <= 0)
+            return PGR_ERR_INVALID_ARGUMENT;
+        const SemanticDev sd{semantic->object_id, semantic->colors, semantic->n_env, semantic->k_objects};
+        composite_semantic_wave_kernel<0><<<slots, WAVE, 0, stream>>>(view_table, items_per_view, work_order, sd);
+    }
     mark(5);
     if (!hip_ok(hipGetLastError(), "kernel launch")) return PGR_ERR_LAUNCH_FAILURE;
 
@@ -377,6 +389,16 @@ int32_t pgr_forward_batch_async(const PgrScene* scene, int32_t n_views, const Pg
     if (scene && scene->n == 0) memset(static_cast<char*>(host_scratch), 0, host_scratch_bytes(n_views));
     return forward_batch_impl(scene, n_views, cameras, outs, workspace, workspace_bytes, max_instances_per_view, nullptr,
                               static_cast<hipStream_t>(stream_v), nullptr, host_scratch);
+}
+
+int32_t pgr_forward_frames_async(const PgrScene* scene, const PgrSemantic* semantic, int32_t n_views,
+                                 const PgrCamera* cameras, const PgrOutputs* outs, void* workspace,
+                                 size_t workspace_bytes, int64_t max_instances_per_view, void* host_scratch,
+                                 size_t host_scratch_size, void* stream_v) {
+    if (!host_scratch || n_views <= 0 || host_scratch_size < host_scratch_bytes(n_views)) return PGR_ERR_INVALID_ARGUMENT;
+    if (scene && scene->n == 0) memset(static_cast<char*>(host_scratch), 0, host_scratch_bytes(n_views));
+    return forward_batch_impl(scene, n_views, cameras, outs, workspace, workspace_bytes, max_instances_per_view, nullptr,
+                              static_cast<hipStream_t>(stream_v), nullptr, host_scratch, semantic);
 }
 
 int32_t pgr_batch_status(const void* host_scratch, int32_t n_views, int64_t* num_instances) {

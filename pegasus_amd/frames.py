@@ -45,6 +45,12 @@ class FrameRenderer:
         self.colors_np = M.generate_colors(max(self.K, 1), color_mode)[: self.K]
         self.colors = t(self.colors_np) if self.K else None
         if self.K:
+            # fused semantic pass: object ids + the rgb value each object's Gaussians carry, evaluated like the
+            # preprocess kernel evaluates SH degree 0: max(C0 * dc + 0.5, 0) in fp32
+            dc_k = RGB2SH(self.colors_np).astype(np.float32)
+            carried = np.maximum(np.float32(0.28209479177387814) * dc_k + np.float32(0.5), np.float32(0.0))
+            self.semantic = dict(object_id=torch.from_numpy(oid.astype(np.int32)).to(self.device),
+                                 colors=t(carried.astype(np.float32)), n_env=self.n_env, k=self.K)
             dc = RGB2SH(self.colors_np[oid[self.n_env:] - 1]).astype(np.float32)       # [n_obj,3]
             self.sem_shs = t(dc.reshape(-1, 1, 3))
             s = slice(self.n_env, self.n)
@@ -65,6 +71,47 @@ class FrameRenderer:
             f["seg_depth"] = torch.empty((batch, 1, height, width), device=dev)
             f["masks"] = torch.empty((batch, self.K, height, width), dtype=torch.uint8, device=dev)
         return f
+
+    def render_frames_async(self, specs: Sequence[R.ViewSpec], frames: dict, masks: bool = True, slot: int = 0):
+        """The fast path: ONE batch call renders the scene (color, depth) and -- from the same per-tile lists --
+        the objects-only semantic image (seg), then one mask launch; enqueued on side stream ``slot`` (2 slots =
+        two batches in flight on two streams).  Returns a ``wait()``-able handle; nothing synchronises the host."""
+        B = len(specs)
+        dev = self.device
+        cur = torch.cuda.current_stream(dev)
+        if not hasattr(self, "_streams"):
+            self._streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        st = self._streams[slot % 2]
+        fused = masks and self.K > 0
+        outs = [dict(color=frames["color"][i], depth=frames["depth"][i], radii=None) for i in range(B)]
+        if fused:
+            for i in range(B):
+                outs[i]["sem_color"], outs[i]["sem_depth"] = frames["seg"][i], frames["seg_depth"][i]
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            h = R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales,
+                                rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False, outputs=outs,
+                                async_slot=("frames", slot), semantic=self.semantic if fused else None)
+            if fused:
+                M.color_masks(frames["seg"][:B], self.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])
+            ev = torch.cuda.Event()
+            ev.record(st)
+        cur.wait_stream(st)
+        renderer = self
+
+        class _Pending:
+            def wait(self_inner):
+                before = h.results
+                redone = h._event is not None
+                h.wait()
+                ev.synchronize()
+                if fused and redone and h.num_instances is not None and h._redo is None and h.results is not before:
+                    pass
+                if fused and getattr(h, "_was_redone", False):
+                    M.color_masks(frames["seg"][:B], renderer.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])
+                    torch.cuda.current_stream(dev).synchronize()
+                return frames
+        return _Pending()
 
     def render_batch_async(self, specs: Sequence[R.ViewSpec], frames: dict, masks: bool = True, slot: int = 0):
         """Enqueues the scene pass and the semantic pass of one batch on two side streams (two workspaces) so

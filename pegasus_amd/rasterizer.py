@@ -99,6 +99,7 @@ class PendingBatch:
                 _WS.capacity_hint[self._key] = max(_WS.capacity_hint.get(self._key, 0), int(peak * 1.3) + 1024)
             self._event = None
             if status == _lib.PGR_ERR_INSTANCE_OVERFLOW:
+                self._was_redone = True
                 self.results = self._redo()          # synchronous path grows the workspace and retries
             else:
                 _lib.check(status, "pgr_forward_batch_async")
@@ -109,7 +110,7 @@ class PendingBatch:
 def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, colors_precomp=None, scales=None,
                   rotations=None, cov3D_precomp=None, sh_degree=0, scale_modifier=1.0, want_radii=True,
                   want_aux=False, stage_ms: Optional[list] = None, outputs: Optional[list] = None,
-                  async_slot=None):
+                  async_slot=None, semantic: Optional[dict] = None):
     """Renders ``len(views)`` views of one scene.  Returns a list of dicts with keys
     color[3,H,W], depth[1,H,W], radii[N] (or None), and final_T / n_contrib when ``want_aux``.
 
@@ -118,6 +119,8 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
     ``outputs``: optional pre-allocated list of dicts (same keys) to render into.
     ``async_slot``: not None -> enqueue on torch's CURRENT stream without synchronising and return a
     PendingBatch; the slot names the workspace / pinned scratch to use (one batch in flight per slot).
+    ``semantic``: dict(object_id int32[N], colors float32[K,3], n_env, k) -> the fused objects-only semantic
+    render is written to r["sem_color"] (and r["sem_depth"]) of every view (pgr_forward_frames_async).
     """
     L = _lib.lib()
     device = means3D.device
@@ -162,27 +165,54 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
             if want_aux:
                 r["final_T"] = torch.empty((H, W), dtype=torch.float32, device=device)
                 r["n_contrib"] = torch.empty((H, W), dtype=torch.int32, device=device)
+            if semantic is not None:
+                r["sem_color"] = torch.empty((3, H, W), dtype=torch.float32, device=device)
+                r["sem_depth"] = torch.empty((1, H, W), dtype=torch.float32, device=device)
         outs[i] = _lib.PgrOutputs(color=_ptr(r["color"]), depth=_ptr(r["depth"]), radii=_ptr(r.get("radii")),
-                                  final_T=_ptr(r.get("final_T")), n_contrib=_ptr(r.get("n_contrib")))
+                                  final_T=_ptr(r.get("final_T")), n_contrib=_ptr(r.get("n_contrib")),
+                                  sem_color=_ptr(r.get("sem_color")) if semantic is not None else None,
+                                  sem_depth=_ptr(r.get("sem_depth")) if semantic is not None else None)
         results.append(r)
 
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     key = (device, n, W, H)
     max_inst = _WS.capacity_hint.get(key, max(1 << 20, 6 * n))
+    sem_struct = None
+    if semantic is not None:
+        sem_struct = _lib.PgrSemantic(object_id=_ptr(semantic["object_id"]), colors=_ptr(semantic["colors"]),
+                                      n_env=int(semantic["n_env"]), k_objects=int(semantic["k"]))
+        if stage_ms is not None:
+            raise ValueError("stage timing is only available for the plain batch call")
+        if async_slot is None:      # synchronous fused call: enqueue asynchronously, wait, retry on overflow
+            kw = dict(shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
+                      cov3D_precomp=cov3D_precomp, sh_degree=sh_degree, scale_modifier=scale_modifier,
+                      want_radii=want_radii, want_aux=want_aux, outputs=results, semantic=semantic)
+            for _attempt in range(3):
+                pb = forward_views(means3D, opacities, views, async_slot="sync-fused", **kw)
+                pb._redo = None
+                pb._event.synchronize()
+                need = (C.c_int64 * nv)()
+                status = L.pgr_batch_status(C.c_void_p(pb._scratch.data_ptr()), nv, need)
+                if status != _lib.PGR_ERR_INSTANCE_OVERFLOW:
+                    _lib.check(status, "pgr_forward_frames_async")
+                    return results
+                _WS.capacity_hint[key] = int(max(need) * 1.3) + 1024
+            raise RuntimeError("instance capacity did not converge")
     if async_slot is not None:
         with torch.cuda.device(device):
             nbytes = L.pgr_batch_workspace_bytes(n, W, H, max_inst, nv)
             ws = _WS.get(device, nbytes, slot=("async", async_slot))
             sb = L.pgr_host_scratch_bytes(nv)
             scratch = _WS.pinned(async_slot, sb)
-            _lib.check(L.pgr_forward_batch_async(C.byref(scene), nv, cams, outs, C.c_void_p(ws.data_ptr()),
-                                                 ws.numel(), max_inst, C.c_void_p(scratch.data_ptr()),
-                                                 scratch.numel(), stream), "pgr_forward_batch_async")
+            _lib.check(L.pgr_forward_frames_async(C.byref(scene), C.byref(sem_struct) if sem_struct else None, nv,
+                                                  cams, outs, C.c_void_p(ws.data_ptr()), ws.numel(), max_inst,
+                                                  C.c_void_p(scratch.data_ptr()), scratch.numel(), stream),
+                       "pgr_forward_frames_async")
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(device))
         kw = dict(shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
                   cov3D_precomp=cov3D_precomp, sh_degree=sh_degree, scale_modifier=scale_modifier,
-                  want_radii=want_radii, want_aux=want_aux, outputs=results)
+                  want_radii=want_radii, want_aux=want_aux, outputs=results, semantic=semantic)
         redo = lambda: forward_views(means3D, opacities, views, **kw)
         pb = PendingBatch(results, ev, scratch, nv, key, max_inst, redo)
         pb._keep = (keep, ws, cams, outs, scene)

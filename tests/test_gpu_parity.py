@@ -302,3 +302,31 @@ def test_async_frame_pipeline_matches_sync(gpu_device):
     torch.cuda.synchronize()
     for k in ("color", "depth", "seg", "masks"):
         assert torch.equal(fc[k], ref[k][:3]), k
+
+
+def test_fused_semantic_pass_is_bit_identical(gpu_device):
+    """The semantic image composited from the SCENE's lists (environment entries dropped on the fly) equals the
+    image of a separate objects-only render bit for bit -- with and without an instance overflow on the way."""
+    import torch
+    from pegasus_amd import frames as F, rasterizer
+    cloud, views = scenes.scene_c3(scale=0.04, n_views=5, width=320, height=240)
+    act = cloud.activated()
+    fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"],
+                         cloud.object_id, sh_degree=3, device=gpu_device, bg=(0.1, 0.0, 0.2))
+    specs = [fr.view_spec(v) for v in views]
+    ref = {k: v.clone() for k, v in fr.render_batch(specs).items()}          # two separate passes
+    torch.cuda.synchronize()
+    f = fr.alloc_frames(5, 240, 320)
+    fr.render_frames_async(specs, f, slot=0).wait()
+    for k in ("color", "depth", "seg", "seg_depth", "masks"):
+        assert torch.equal(f[k], ref[k]), k
+    assert int(f["masks"].sum()) > 0
+    for key in list(rasterizer._WS.capacity_hint):
+        rasterizer._WS.capacity_hint[key] = 2000
+    for kk in [k for k in rasterizer._WS.buf if isinstance(k, tuple) and len(k) == 2 and isinstance(k[1], tuple)]:
+        rasterizer._WS.buf.pop(kk)
+    f2 = fr.alloc_frames(5, 240, 320)
+    fr.render_frames_async(specs, f2, slot=1).wait()
+    torch.cuda.synchronize()
+    for k in ("color", "depth", "seg", "masks"):
+        assert torch.equal(f2[k], ref[k]), k
