@@ -78,6 +78,7 @@ def algorithmic_bytes(N, V, I, P):
         "bin_scatter": 12 * I,
         "tile_sort": 24 * I + 8 * I,
         "composite": 44 * I + 16 * P,
+        "composite_semantic": 4 * I + 16 * P,   # walks the same lists (indices only) + the objects' records
     }
     return 16 * N + 272 * V + 88 * I + 16 * P, per_stage
 
@@ -120,7 +121,10 @@ def main():
         return [specs[(i * B + k) % len(specs)] for k in range(B)]
 
     def step(i, **kw):
-        return fr.render_batch(batch_views(i), frames, masks=with_masks, **kw)
+        if args.separate_semantic:
+            return fr.render_batch(batch_views(i), frames, masks=with_masks, **kw)
+        kw.pop("sem_stage_ms", None)
+        return fr.render_frames(batch_views(i), frames, masks=with_masks, **kw)
 
     def run_steps(first, count):
         """`count` steps as a 2-deep software pipeline: batch i is enqueued (scene pass and semantic pass on two
@@ -213,7 +217,8 @@ def main():
         "whole_path": {"bytes_per_view": int(B_view), "achieved": round(B_view * value / world / 1e9, 2),
                        "frac": round(B_view * value / world / 1e9 / HBM_PEAK_GBS, 5)},
         "composite_evals_per_s": round(evals * B / (mean_ms[4] * 1e-3), 1) if mean_ms[4] > 0 else None,
-        "semantic_pass_ms_per_view": {k: round(float(m) / B, 4) for k, m in zip(_lib.STAGE_NAMES, sem_ms.mean(axis=0))},
+        "semantic": "separate objects-only pass" if args.separate_semantic else
+                    "fused: composited from the scene's per-tile lists (stage composite_semantic)",
         "raster_only_views_per_s": round(raster_only_fps, 2) if raster_only_fps else None,
         "N": N, "V": round(V), "I": round(I), "P": P,
     }

@@ -156,18 +156,19 @@ int32_t pgr_batch_status(const void *host_scratch, int32_t n_views, int64_t *num
 /* Profiling twin of pgr_forward_batch (bench / rocprof only): records HIP events on `stream` at the
  * stage boundaries (each stage runs for all views before the next starts), synchronises, and writes the
  * elapsed milliseconds of each stage for the whole batch to stage_ms[PGR_NUM_STAGES] in PgrStage order. */
-#define PGR_NUM_STAGES 5
+#define PGR_NUM_STAGES 6
 typedef enum PgrStage {
     PGR_STAGE_PREPROCESS = 0,  /* camera pack + per-Gaussian projection / EWA / SH */
     PGR_STAGE_BIN_COUNT = 1,   /* per-chunk tile histograms, slice reservation, tile scan */
     PGR_STAGE_BIN_SCATTER = 2, /* (depth, index) pairs into the tiles' slices */
     PGR_STAGE_TILE_SORT = 3,   /* work order + per-tile (depth, index) sort */
-    PGR_STAGE_COMPOSITE = 4    /* front-to-back alpha compositing of all views */
+    PGR_STAGE_COMPOSITE = 4,   /* front-to-back alpha compositing of all views */
+    PGR_STAGE_SEMANTIC = 5     /* fused objects-only semantic compositing (0 when not requested) */
 } PgrStage;
-int32_t pgr_forward_batch_profiled(const PgrScene *scene, int32_t n_views, const PgrCamera *cameras,
-                                   const PgrOutputs *outs, void *workspace, size_t workspace_bytes,
-                                   int64_t max_instances_per_view, int64_t *num_instances, void *stream,
-                                   float *stage_ms);
+int32_t pgr_forward_batch_profiled(const PgrScene *scene, const PgrSemantic *semantic, int32_t n_views,
+                                   const PgrCamera *cameras, const PgrOutputs *outs, void *workspace,
+                                   size_t workspace_bytes, int64_t max_instances_per_view,
+                                   int64_t *num_instances, void *stream, float *stage_ms);
 
 /* Fill `view` with device pointers into view `view_index` of a workspace laid out for
  * (n,width,height,max_instances,n_views). */

@@ -15,8 +15,8 @@ PGR_ERR_INVALID_ARGUMENT = -1
 PGR_ERR_WORKSPACE_TOO_SMALL = -2
 PGR_ERR_INSTANCE_OVERFLOW = -3
 PGR_ERR_LAUNCH_FAILURE = -4
-PGR_NUM_STAGES = 5
-STAGE_NAMES = ("preprocess", "bin_count", "bin_scatter", "tile_sort", "composite")
+PGR_NUM_STAGES = 6
+STAGE_NAMES = ("preprocess", "bin_count", "bin_scatter", "tile_sort", "composite", "composite_semantic")
 
 
 class PgrScene(C.Structure):
@@ -73,7 +73,8 @@ SYMBOLS = {
                                              C.POINTER(PgrCamera), C.POINTER(PgrOutputs), C.c_void_p, C.c_size_t,
                                              C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pgr_batch_status": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
-    "pgr_forward_batch_profiled": (C.c_int32, [C.POINTER(PgrScene), C.c_int32, C.POINTER(PgrCamera),
+    "pgr_forward_batch_profiled": (C.c_int32, [C.POINTER(PgrScene), C.POINTER(PgrSemantic), C.c_int32,
+                                               C.POINTER(PgrCamera),
                                                C.POINTER(PgrOutputs), C.c_void_p, C.c_size_t, C.c_int64,
                                                C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_float)]),
     "pgr_workspace_view": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int64,

@@ -294,13 +294,14 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         composite_wave_kernel<true><<<slots, WAVE, 0, stream>>>(view_table, items_per_view, work_order);
     else
         composite_wave_kernel<false><<<slots, WAVE, 0, stream>>>(view_table, items_per_view, work_order);
+    mark(5);
     if (want_sem) {
         if (!semantic->object_id || !semantic->colors || semantic->n_env < 0 || semantic->k_objects <= 0)
             return PGR_ERR_INVALID_ARGUMENT;
         const SemanticDev sd{semantic->object_id, semantic->colors, semantic->n_env, semantic->k_objects};
         composite_semantic_wave_kernel<0><<<slots, WAVE, 0, stream>>>(view_table, items_per_view, work_order, sd);
     }
-    mark(5);
+    mark(6);
     if (!hip_ok(hipGetLastError(), "kernel launch")) return PGR_ERR_LAUNCH_FAILURE;
 
     // the only host read of the batch: instance counts + overflow flags, after everything is enqueued
@@ -414,10 +415,10 @@ int32_t pgr_batch_status(const void* host_scratch, int32_t n_views, int64_t* num
     return overflow ? PGR_ERR_INSTANCE_OVERFLOW : PGR_OK;
 }
 
-int32_t pgr_forward_batch_profiled(const PgrScene* scene, int32_t n_views, const PgrCamera* cameras,
-                                   const PgrOutputs* outs, void* workspace, size_t workspace_bytes,
-                                   int64_t max_instances_per_view, int64_t* num_instances, void* stream_v,
-                                   float* stage_ms) {
+int32_t pgr_forward_batch_profiled(const PgrScene* scene, const PgrSemantic* semantic, int32_t n_views,
+                                   const PgrCamera* cameras, const PgrOutputs* outs, void* workspace,
+                                   size_t workspace_bytes, int64_t max_instances_per_view, int64_t* num_instances,
+                                   void* stream_v, float* stage_ms) {
     if (!stage_ms) return PGR_ERR_INVALID_ARGUMENT;
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     hipEvent_t ev[PGR_NUM_STAGES + 1];
@@ -425,7 +426,7 @@ int32_t pgr_forward_batch_profiled(const PgrScene* scene, int32_t n_views, const
         if (!hip_ok(hipEventCreate(&e), "hipEventCreate")) return PGR_ERR_LAUNCH_FAILURE;
     for (int k = 0; k < PGR_NUM_STAGES; ++k) stage_ms[k] = 0.f;
     int32_t rc = forward_batch_impl(scene, n_views, cameras, outs, workspace, workspace_bytes, max_instances_per_view,
-                                    num_instances, stream, ev);
+                                    num_instances, stream, ev, nullptr, semantic);
     if (rc == PGR_OK && scene->n > 0) {
         for (int k = 0; rc == PGR_OK && k < PGR_NUM_STAGES; ++k)
             if (!hip_ok(hipEventElapsedTime(&stage_ms[k], ev[k], ev[k + 1]), "hipEventElapsedTime"))

@@ -159,6 +159,26 @@ class FrameRenderer:
                 return frames
         return _Pending()
 
+    def render_frames(self, specs: Sequence[R.ViewSpec], frames: dict = None, masks: bool = True,
+                      stage_ms: list = None):
+        """Blocking form of render_frames_async on the current stream (fused semantic pass); ``stage_ms``
+        receives the HIP-event stage times of the whole batch."""
+        B = len(specs)
+        H, W = int(specs[0].image_height), int(specs[0].image_width)
+        if frames is None:
+            frames = self.alloc_frames(B, H, W, masks)
+        fused = masks and self.K > 0
+        outs = [dict(color=frames["color"][i], depth=frames["depth"][i], radii=None) for i in range(B)]
+        if fused:
+            for i in range(B):
+                outs[i]["sem_color"], outs[i]["sem_depth"] = frames["seg"][i], frames["seg_depth"][i]
+        R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales,
+                        rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False, outputs=outs,
+                        stage_ms=stage_ms, semantic=self.semantic if fused else None)
+        if fused:
+            M.color_masks(frames["seg"][:B], self.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])
+        return frames
+
     def render_batch(self, specs: Sequence[R.ViewSpec], frames: dict = None, masks: bool = True,
                      stage_ms: list = None, sem_stage_ms: list = None):
         """Renders len(specs) frames into ``frames`` (allocated if None).  Returns the dict of batched

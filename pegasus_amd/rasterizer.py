@@ -181,9 +181,7 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
     if semantic is not None:
         sem_struct = _lib.PgrSemantic(object_id=_ptr(semantic["object_id"]), colors=_ptr(semantic["colors"]),
                                       n_env=int(semantic["n_env"]), k_objects=int(semantic["k"]))
-        if stage_ms is not None:
-            raise ValueError("stage timing is only available for the plain batch call")
-        if async_slot is None:      # synchronous fused call: enqueue asynchronously, wait, retry on overflow
+        if async_slot is None and stage_ms is None:      # synchronous fused call: enqueue asynchronously, wait, retry on overflow
             kw = dict(shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
                       cov3D_precomp=cov3D_precomp, sh_degree=sh_degree, scale_modifier=scale_modifier,
                       want_radii=want_radii, want_aux=want_aux, outputs=results, semantic=semantic)
@@ -226,8 +224,9 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
                 raise ValueError("pgr_batch_workspace_bytes: invalid sizes")
             ws = _WS.get(device, nbytes)
             if stage_ms is not None:
-                status = L.pgr_forward_batch_profiled(C.byref(scene), nv, cams, outs, C.c_void_p(ws.data_ptr()),
-                                                      ws.numel(), max_inst, need, stream, ms)
+                status = L.pgr_forward_batch_profiled(C.byref(scene), C.byref(sem_struct) if sem_struct else None,
+                                                      nv, cams, outs, C.c_void_p(ws.data_ptr()), ws.numel(),
+                                                      max_inst, need, stream, ms)
             else:
                 status = L.pgr_forward_batch(C.byref(scene), nv, cams, outs, C.c_void_p(ws.data_ptr()), ws.numel(),
                                              max_inst, need, stream)
