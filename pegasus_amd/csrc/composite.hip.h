@@ -29,10 +29,9 @@ struct alignas(16) ViewEntry {
     const float4* splats;        // [n, 3] records: q0 = (x,y,A,B), q1 = (C,op,r,g), q2 = (b,depth,..)
     CompOut out;
     const uint32_t* counters;    // [1] != 0: instance overflow, the view must not be composited
-    CompOut sem;                 // outputs of the fused semantic pass (objects only, flat colours); color may be NULL
     uint64_t pad[3];
 };
-static_assert(sizeof(ViewEntry) == 128, "ViewEntry layout");
+static_assert(sizeof(ViewEntry) == 96, "ViewEntry layout");
 
 // Fused semantic pass (same for every view of a batch): which Gaussians are objects and what colour they carry.
 struct SemanticDev {
@@ -57,16 +56,23 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int HALF_ROWS = 8;     // rows per half tile
 constexpr int WAVE_BATCH = 64;   // list entries staged per round
 
-template <bool AUX>
+// SEM = true: PEGASUS's object-only semantic render (/root/reference/src/gs/render.py:68-97: all objects in their
+// semantic colours, environment REMOVED) from the scene's own data: `views` then points at the tiles'
+// OBJECT lists (tile_sort writes them as a by-product: the scene's sorted list minus the environment entries,
+// which is exactly the list an objects-only cloud would produce) and every entry takes its object's flat colour
+// instead of its SH colour.  No second preprocess / binning / sort; pixel arithmetic is the sequence a separate
+// pass would execute, so the image is bit-identical (tests/test_gpu_parity.py).
+template <bool AUX, bool SEM>
 __global__ __launch_bounds__(WAVE) void composite_wave_kernel(const ViewEntry* __restrict__ views,
                                                               uint32_t items_per_view,
-                                                              const uint32_t* __restrict__ work_order) {
+                                                              const uint32_t* __restrict__ work_order,
+                                                              SemanticDev sem) {
     uint32_t item = work_order ? work_order[blockIdx.x] : blockIdx.x;
     if (item == INVALID_ITEM) return;
     const uint32_t view = item / items_per_view;
     item -= view * items_per_view;
     const ViewEntry& ve = views[view];
-    if (ve.counters[1]) return;
+    if (ve.counters[1] || !ve.out.color) return;
     const CameraDev& cam = *ve.cam;
     const uint2* __restrict__ ranges = ve.ranges;
     const uint32_t* __restrict__ gauss_sorted = ve.gauss_sorted;
@@ -100,11 +106,16 @@ __global__ __launch_bounds__(WAVE) void composite_wave_kernel(const ViewEntry* _
     float2 p = make_float2(0.f, 0.f);
     float4 co = make_float4(0.f, 0.f, 0.f, 0.f), cd = make_float4(0.f, 0.f, 0.f, 0.f);
     if (lane < n) {
-        const float4* rec = splats + (size_t)gauss_sorted[range.x + lane] * 3;
+        const uint32_t g = gauss_sorted[range.x + lane];
+        const float4* rec = splats + (size_t)g * 3;
         const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
         p = make_float2(q0.x, q0.y);
         co = make_float4(q0.z, q0.w, q1.x, q1.y);
         cd = make_float4(q1.z, q1.w, q2.x, q2.y);
+        if (SEM) {
+            const float* col = sem.colors + 3 * (size_t)(sem.object_id[g] - 1);
+            cd = make_float4(col[0], col[1], col[2], q2.y);
+        }
     }
 
     // the wave's pixel-centre rectangle (clipped to the image), for the per-entry skip test
@@ -141,11 +152,16 @@ __global__ __launch_bounds__(WAVE) void composite_wave_kernel(const ViewEntry* _
         co = make_float4(0.f, 0.f, 0.f, 0.f);
         cd = make_float4(0.f, 0.f, 0.f, 0.f);
         if (base + WAVE_BATCH + lane < n) {
-            const float4* rec = splats + (size_t)gauss_sorted[range.x + base + WAVE_BATCH + lane] * 3;
+            const uint32_t g = gauss_sorted[range.x + base + WAVE_BATCH + lane];
+            const float4* rec = splats + (size_t)g * 3;
             const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
             p = make_float2(q0.x, q0.y);
             co = make_float4(q0.z, q0.w, q1.x, q1.y);
             cd = make_float4(q1.z, q1.w, q2.x, q2.y);
+            if (SEM) {
+                const float* col = sem.colors + 3 * (size_t)(sem.object_id[g] - 1);
+                cd = make_float4(col[0], col[1], col[2], q2.y);
+            }
         }
         for (int j0 = 0; j0 < cnt; j0 += 8) {
 #pragma unroll
@@ -195,7 +211,7 @@ finished:
         o.color[0 * P + pix] = fmaf(T.x, cam.bg[0], Cr.x);
         o.color[1 * P + pix] = fmaf(T.x, cam.bg[1], Cg.x);
         o.color[2 * P + pix] = fmaf(T.x, cam.bg[2], Cb.x);
-        o.depth[pix] = D.x;
+        if (o.depth) o.depth[pix] = D.x;
         if (AUX) {
             if (o.final_T) o.final_T[pix] = T.x;
             if (o.n_contrib) o.n_contrib[pix] = last0;
@@ -206,7 +222,7 @@ finished:
         o.color[0 * P + pix] = fmaf(T.y, cam.bg[0], Cr.y);
         o.color[1 * P + pix] = fmaf(T.y, cam.bg[1], Cg.y);
         o.color[2 * P + pix] = fmaf(T.y, cam.bg[2], Cb.y);
-        o.depth[pix] = D.y;
+        if (o.depth) o.depth[pix] = D.y;
         if (AUX) {
             if (o.final_T) o.final_T[pix] = T.y;
             if (o.n_contrib) o.n_contrib[pix] = last1;
@@ -217,167 +233,6 @@ finished:
 // Work ordering for the wave compositor: half-tile work items sorted by DESCENDING list length
 // (256 log-spaced length classes), so the long lists start first and the short ones back-fill the
 // SIMDs that finish early (longest-processing-time-first).  Order never affects results.
-// ---------------------------------------------------------------------------------------------
-// composite_semantic_wave_kernel: PEGASUS's object-only semantic render
-// (/root/reference/src/gs/render.py:68-97: all objects in their semantic colours, environment REMOVED) without
-// a second preprocess / binning / sort.  The per-tile list of an objects-only cloud is exactly the scene's
-// sorted list with the environment entries deleted -- same Gaussians, same geometry, same opacity, same
-// (depth, index) order -- so this kernel walks the SCENE's lists, drops every index < n_env before it is even
-// gathered, and blends the rest with the object's flat colour.  Pixel arithmetic is the same sequence the
-// separate pass would execute: bit-identical images (tests/test_gpu_parity.py).  Live entries are collected
-// across scan batches (CAP) so the unrolled loop runs on full buffers although objects are a small
-// fraction of most lists.
-template <int DUMMY>
-__global__ __launch_bounds__(WAVE) void composite_semantic_wave_kernel(const ViewEntry* __restrict__ views,
-                                                                       uint32_t items_per_view,
-                                                                       const uint32_t* __restrict__ work_order,
-                                                                       SemanticDev sem) {
-    uint32_t item = work_order ? work_order[blockIdx.x] : blockIdx.x;
-    if (item == INVALID_ITEM) return;
-    const uint32_t view = item / items_per_view;
-    item -= view * items_per_view;
-    const ViewEntry& ve = views[view];
-    if (ve.counters[1] || !ve.sem.color) return;
-    const CameraDev& cam = *ve.cam;
-    const uint32_t* __restrict__ gauss_sorted = ve.gauss_sorted;
-    const float4* __restrict__ splats = ve.splats;
-    const CompOut o = ve.sem;
-    const int W = cam.width, H = cam.height;
-    const int tile = (int)(item >> 1), half = (int)(item & 1);
-    const int tile_x = tile % cam.grid_x, tile_y = tile / cam.grid_x;
-    const int lane = threadIdx.x;
-    const int px = tile_x * TILE + (lane & (TILE - 1));
-    const int py0 = tile_y * TILE + half * HALF_ROWS + (lane >> 4);
-    const int py1 = py0 + 4;
-    const bool in0 = px < W && py0 < H, in1 = px < W && py1 < H;
-    const float pxf = (float)px;
-    const f32x2 pyf = {(float)py0, (float)py1};
-    const uint2 range = ve.ranges[tile];
-    const int n = (int)(range.y - range.x);
-    const float rx0 = (float)(tile_x * TILE), ry0 = (float)(tile_y * TILE + half * HALF_ROWS);
-    const float rx1 = fminf(rx0 + (float)(TILE - 1), (float)(W - 1));
-    const float ry1 = fminf(ry0 + (float)(HALF_ROWS - 1), (float)(H - 1));
-
-    constexpr int CAP = 128;
-    __shared__ float4 s_a[CAP + 8];   // x, y, hx, ny
-    __shared__ float4 s_b[CAP + 8];   // hz, opacity, r, g
-    __shared__ float2 s_c[CAP + 8];   // b, depth
-
-    f32x2 T = {1.0f, 1.0f}, Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f}, D = {0.f, 0.f};
-    bool done0 = !in0, done1 = !in1;
-    int fill = 0;
-
-    // blends the `fill` parked entries; returns true when every pixel of the wave is finished
-    auto flush = [&]() -> bool {
-        if (lane < 8) {
-            s_a[fill + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-            s_b[fill + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-            s_c[fill + lane] = make_float2(0.f, 0.f);
-        }
-        __syncthreads();
-        bool all_done = false;
-        for (int j0 = 0; j0 < fill && !all_done; j0 += 8) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u;
-                const float4 a = s_a[j];
-                const float4 b = s_b[j];
-                const float2 c = s_c[j];
-                const float dx = a.x - pxf;
-                const f32x2 dxv = {dx, dx};
-                const f32x2 dy = (f32x2){a.y, a.y} - pyf;
-                const f32x2 t1 = (f32x2){a.w, a.w} * dy;
-                const f32x2 t2 = __builtin_elementwise_fma((f32x2){a.z, a.z}, dxv, t1);
-                const f32x2 t4 = ((f32x2){b.x, b.x} * dy) * dy;
-                const f32x2 power = __builtin_elementwise_fma(dxv, t2, t4);
-                const f32x2 p2 = power * (f32x2){1.4426950408889634f, 1.4426950408889634f};
-                const f32x2 e = {__builtin_amdgcn_exp2f(p2.x), __builtin_amdgcn_exp2f(p2.y)};
-                const f32x2 araw = (f32x2){b.y, b.y} * e;
-                const f32x2 alpha = {fminf(ALPHA_MAX, araw.x), fminf(ALPHA_MAX, araw.y)};
-                const f32x2 test_T = __builtin_elementwise_fma(-alpha, T, T);
-                const bool v0 = !done0 && !(power.x > 0.0f) && !(alpha.x < ALPHA_MIN);
-                const bool v1 = !done1 && !(power.y > 0.0f) && !(alpha.y < ALPHA_MIN);
-                const bool stop0 = v0 && test_T.x < T_EPS, stop1 = v1 && test_T.y < T_EPS;
-                done0 = done0 || stop0;
-                done1 = done1 || stop1;
-                const bool b0 = v0 && !stop0, b1 = v1 && !stop1;
-                const f32x2 aeff = {b0 ? alpha.x : 0.0f, b1 ? alpha.y : 0.0f};
-                const f32x2 w = aeff * T;
-                Cr = __builtin_elementwise_fma((f32x2){b.z, b.z}, w, Cr);
-                Cg = __builtin_elementwise_fma((f32x2){b.w, b.w}, w, Cg);
-                Cb = __builtin_elementwise_fma((f32x2){c.x, c.x}, w, Cb);
-                D = __builtin_elementwise_fma((f32x2){c.y, c.y}, w, D);
-                T = __builtin_elementwise_fma(-aeff, T, T);
-            }
-            all_done = __all(done0 && done1);
-        }
-        __syncthreads();
-        fill = 0;
-        return all_done;
-    };
-
-    // software pipeline over scan batches: indices two batches ahead, records one batch ahead
-    auto load_index = [&](int base) -> uint32_t {
-        return base + lane < n ? gauss_sorted[range.x + base + lane] : 0u;   // 0 < n_env or harmless: filtered below
-    };
-    struct Rec { float2 p; float4 co; float4 cd; bool obj; };
-    auto load_record = [&](uint32_t g, int base) -> Rec {
-        Rec r;
-        r.obj = base + lane < n && (int)g >= sem.n_env;
-        r.p = make_float2(0.f, 0.f);
-        r.co = make_float4(0.f, 0.f, 0.f, 0.f);
-        r.cd = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r.obj) {
-            const float4* rec = splats + (size_t)g * 3;
-            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-            const float* col = sem.colors + 3 * (size_t)(sem.object_id[g] - 1);
-            r.p = make_float2(q0.x, q0.y);
-            r.co = make_float4(q0.z, q0.w, q1.x, q1.y);
-            r.cd = make_float4(col[0], col[1], col[2], q2.y);
-        }
-        return r;
-    };
-    uint32_t g1 = load_index(0);
-    Rec cur = load_record(g1, 0);
-    g1 = load_index(WAVE_BATCH);
-    for (int base = 0; base < n; base += WAVE_BATCH) {
-        const Rec nxt = load_record(g1, base + WAVE_BATCH);         // records of batch b+1 (index arrived by now)
-        g1 = load_index(base + 2 * WAVE_BATCH);                    // indices of batch b+2
-        const bool live = cur.obj && rect_may_contribute(make_cull_splat(cur.p, cur.co), rx0, ry0, rx1, ry1);
-        const unsigned long long mask = __ballot(live);
-        const int cnt = __popcll(mask);
-        if (cnt) {
-            if (fill + cnt > CAP && flush()) goto finished;
-            const int pos = fill + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            if (live) {
-                s_a[pos] = make_float4(cur.p.x, cur.p.y, -0.5f * cur.co.x, -cur.co.y);
-                s_b[pos] = make_float4(-0.5f * cur.co.z, cur.co.w, cur.cd.x, cur.cd.y);
-                s_c[pos] = make_float2(cur.cd.z, cur.cd.w);
-            }
-            fill += cnt;
-        }
-        cur = nxt;
-    }
-    if (fill) flush();
-finished:
-    const size_t P = (size_t)W * H;
-    if (in0) {
-        const size_t pix = (size_t)py0 * W + px;
-        o.color[0 * P + pix] = fmaf(T.x, cam.bg[0], Cr.x);
-        o.color[1 * P + pix] = fmaf(T.x, cam.bg[1], Cg.x);
-        o.color[2 * P + pix] = fmaf(T.x, cam.bg[2], Cb.x);
-        if (o.depth) o.depth[pix] = D.x;
-    }
-    if (in1) {
-        const size_t pix = (size_t)py1 * W + px;
-        o.color[0 * P + pix] = fmaf(T.y, cam.bg[0], Cr.y);
-        o.color[1 * P + pix] = fmaf(T.y, cam.bg[1], Cg.y);
-        o.color[2 * P + pix] = fmaf(T.y, cam.bg[2], Cb.y);
-        if (o.depth) o.depth[pix] = D.y;
-    }
-}
-
 // ---- work order --------------------------------------------------------------------------------
 // The compositor's work items (view, tile, half) are laid out as NUM_XCD interleaved streams: position p
 // belongs to stream p % 8, and the hardware dispatcher is observed to place workgroup b on XCD b % 8

@@ -46,6 +46,9 @@ struct BinView {                 // per-view pointers used by the binning kernel
     uint2* bucket;               // [max_instances] (depth bits, index), unsorted per tile
     uint32_t* gauss_sorted;      // [max_instances]
     uint64_t* alt;               // [max_instances] second key buffer for lists beyond the LDS tiers
+    uint32_t* obj_sorted;        // [max_instances] the sorted list with environment entries removed (same offsets)
+    uint2* obj_ranges;           // [tiles] zero-filled; [start, start + #objects) into obj_sorted
+    int32_t n_env;               // Gaussians < n_env are environment; < 0: no object lists wanted
 };
 
 
@@ -218,11 +221,42 @@ __device__ __forceinline__ int pad_idx(int i) {
     return i + i / E;   // E is a power of two: a shift
 }
 
+// Ordered compaction of the entries with index >= n_env (the objects) of a sorted list into obj_out, for the
+// fused semantic pass: an objects-only cloud's per-tile list is the scene's list minus the environment.
+// `get(i)` returns the i-th sorted index.  Returns (to every thread) the number of object entries.
+template <int THREADS, typename Get>
+__device__ __forceinline__ uint32_t compact_objects(Get get, int n, int n_env, uint32_t* __restrict__ obj_out) {
+    __shared__ uint32_t wave_cnt[THREADS / WAVE];
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    uint32_t base = 0;
+    for (int c0 = 0; c0 < n; c0 += THREADS) {
+        const int i = c0 + (int)threadIdx.x;
+        const uint32_t idx = i < n ? get(i) : 0u;
+        const bool is_obj = i < n && (int)idx >= n_env;
+        const unsigned long long m = __ballot(is_obj);
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < THREADS / WAVE; ++w) {
+            const uint32_t c = wave_cnt[w];
+            before += w < wave ? c : 0u;
+            total += c;
+        }
+        if (is_obj) obj_out[base + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = idx;
+        base += total;
+        __syncthreads();
+    }
+    return base;
+}
+
 // Sorts n <= THREADS*E keys of `bucket` (global, (depth,idx) pairs) into out[] (indices only).
 // skeys must hold THREADS*(E+1) keys.
 template <int THREADS, int E>
 __device__ __forceinline__ void merge_sort_tile(uint64_t* __restrict__ skeys, const uint2* __restrict__ bucket,
-                                                uint32_t* __restrict__ out, int n, uint64_t* keys_out = nullptr) {
+                                                uint32_t* __restrict__ out, int n, uint64_t* keys_out = nullptr,
+                                                int n_env = -1, uint32_t* __restrict__ obj_out = nullptr,
+                                                uint2* __restrict__ obj_range = nullptr, uint32_t range_start = 0) {
     const int t = threadIdx.x;
     uint64_t r[E];
     // the list is unordered, so WHICH keys a thread starts with is free: take them coalesced
@@ -273,6 +307,11 @@ __device__ __forceinline__ void merge_sort_tile(uint64_t* __restrict__ skeys, co
         for (int i = t; i < n; i += THREADS) keys_out[i] = skeys[pad_idx<E>(i)];
     } else {
         for (int i = t; i < n; i += THREADS) out[i] = (uint32_t)skeys[pad_idx<E>(i)];
+        if (n_env >= 0) {
+            const uint32_t cnt = compact_objects<THREADS>([&](int i) { return (uint32_t)skeys[pad_idx<E>(i)]; }, n, n_env,
+                                                          obj_out);
+            if (t == 0) *obj_range = make_uint2(range_start, range_start + cnt);
+        }
     }
 }
 
@@ -308,8 +347,11 @@ __device__ __forceinline__ void merge_round_global(const uint64_t* __restrict__ 
 constexpr int SORT_SMALL_MAX = SORT_THREADS * 16;      // 4096 keys, 32 KiB LDS
 
 // item = view * tiles + tile
+struct ObjOut { int n_env; uint32_t* sorted; uint2* range; uint32_t start; };
+
 __device__ __forceinline__ bool sort_item(const BinView* __restrict__ views, int tiles, uint32_t item,
-                                          const uint2*& bucket, uint32_t*& out, int& n, uint64_t** alt = nullptr) {
+                                          const uint2*& bucket, uint32_t*& out, int& n, ObjOut& oo,
+                                          uint64_t** alt = nullptr) {
     const uint32_t view = item / (uint32_t)tiles;
     const uint32_t tile = item - view * (uint32_t)tiles;
     const BinView& bv = views[view];
@@ -318,6 +360,7 @@ __device__ __forceinline__ bool sort_item(const BinView* __restrict__ views, int
     n = (int)(range.y - range.x);
     bucket = bv.bucket + range.x;
     out = bv.gauss_sorted + range.x;
+    oo = ObjOut{bv.n_env, bv.obj_sorted + range.x, bv.obj_ranges + tile, range.x};
     if (alt) *alt = bv.alt + range.x;
     return n > 0;
 }
@@ -325,13 +368,17 @@ __device__ __forceinline__ bool sort_item(const BinView* __restrict__ views, int
 // grid = n_views * tiles workgroups of 256; lists of 1..4096 entries
 __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* __restrict__ views, int tiles) {
     __shared__ uint64_t skeys[SORT_THREADS * 17];
-    const uint2* bucket; uint32_t* out; int n;
-    if (!sort_item(views, tiles, blockIdx.x, bucket, out, n)) return;
-    if (n > SORT_SMALL_MAX) return;                      // tile_sort_large_kernel's
-    if (n <= SORT_THREADS * 2) merge_sort_tile<SORT_THREADS, 2>(skeys, bucket, out, n);
-    else if (n <= SORT_THREADS * 4) merge_sort_tile<SORT_THREADS, 4>(skeys, bucket, out, n);
-    else if (n <= SORT_THREADS * 8) merge_sort_tile<SORT_THREADS, 8>(skeys, bucket, out, n);
-    else merge_sort_tile<SORT_THREADS, 16>(skeys, bucket, out, n);
+    const uint2* bucket; uint32_t* out; int n; ObjOut oo;
+    if (!sort_item(views, tiles, blockIdx.x, bucket, out, n, oo)) return;
+    if (n > SORT_SMALL_MAX) return;                      // the long tiers'
+    if (n <= SORT_THREADS * 2)
+        merge_sort_tile<SORT_THREADS, 2>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
+    else if (n <= SORT_THREADS * 4)
+        merge_sort_tile<SORT_THREADS, 4>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
+    else if (n <= SORT_THREADS * 8)
+        merge_sort_tile<SORT_THREADS, 8>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
+    else
+        merge_sort_tile<SORT_THREADS, 16>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
 }
 
 // Lists longer than 4096: order_scatter_kernel appends them to long_list (device counter n_long); workgroups
@@ -351,12 +398,12 @@ __global__ __launch_bounds__(THREADS) void tile_sort_long_kernel(const BinView* 
     constexpr int CAP = THREADS * 16;
     const uint32_t cand = *n_long;
     for (uint32_t k = blockIdx.x; k < cand; k += gridDim.x) {
-        const uint2* bucket; uint32_t* out; int n; uint64_t* alt;
-        const bool ok = sort_item(views, tiles, long_list[k], bucket, out, n, &alt);
+        const uint2* bucket; uint32_t* out; int n; uint64_t* alt; ObjOut oo;
+        const bool ok = sort_item(views, tiles, long_list[k], bucket, out, n, oo, &alt);
         const bool mine = THREADS == SORT_MEDIUM_THREADS ? (n > SORT_SMALL_MAX && n <= SORT_MEDIUM_MAX) : n > SORT_MEDIUM_MAX;
         if (ok && mine) {
             if (n <= CAP) {
-                merge_sort_tile<THREADS, 16>(skeys, bucket, out, n);
+                merge_sort_tile<THREADS, 16>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
             } else {
                 uint64_t* gk = reinterpret_cast<uint64_t*>(const_cast<uint2*>(bucket));
                 for (int c0 = 0; c0 < n; c0 += CAP) {
@@ -370,6 +417,12 @@ __global__ __launch_bounds__(THREADS) void tile_sort_long_kernel(const BinView* 
                     uint64_t* tmp = src; src = dst; dst = tmp;
                 }
                 for (int i = threadIdx.x; i < n; i += THREADS) out[i] = (uint32_t)src[i];
+                if (oo.n_env >= 0) {
+                    __syncthreads();
+                    const uint32_t cnt = compact_objects<THREADS>([&](int i) { return (uint32_t)src[i]; }, n, oo.n_env,
+                                                                  oo.sorted);
+                    if (threadIdx.x == 0) *oo.range = make_uint2(oo.start, oo.start + cnt);
+                }
             }
         }
         __syncthreads();   // skeys reuse across loop iterations
