@@ -330,3 +330,30 @@ def test_fused_semantic_pass_is_bit_identical(gpu_device):
     torch.cuda.synchronize()
     for k in ("color", "depth", "seg", "masks"):
         assert torch.equal(f2[k], ref[k]), k
+
+
+def test_large_image_many_tiles(oracle, gpu_device):
+    """More than 16384 tiles: the binning kernels sweep the tile space in several LDS passes."""
+    cloud, _ = scenes.scene_c1(seed=12, n=6000)
+    cloud.scaling[:] += np.float32(np.log(1.5))
+    from pegasus_amd import graphics as G
+    R, t = G.look_at_opencv((0.2, -0.1, -2.2), (0, 0, 0), up=(0, -1, 0))
+    w, h = 2405, 1817          # 151 x 114 = 17214 tiles, ragged on both axes
+    v = scenes.make_view(R, t, w, h, fovx=math.radians(60), fovy=math.radians(60) * h / w)
+    g, o = _run_both(oracle, cloud, v, gpu_device)
+    assert o["ranges"].shape[0] > 16384 and o["num_instances"] > 50_000
+    _check_all(g, o)
+
+
+def test_single_gaussian_and_two_pixel_image(oracle, gpu_device):
+    cloud, views = scenes.scene_c1(seed=13, n=1)
+    cloud.xyz[:] = 0.0
+    g, o = _run_both(oracle, cloud, views[0], gpu_device, bg=(0.3, 0.6, 0.9))
+    _check_all(g, o)
+    assert g["num_instances"] >= 1
+    from pegasus_amd import graphics as G
+    R, t = G.look_at_opencv((0.0, 0.0, -3.0), (0, 0, 0), up=(0, -1, 0))
+    v = scenes.make_view(R, t, 2, 1, fovx=math.radians(50), fovy=math.radians(25))
+    cloud2, _ = scenes.scene_c1(seed=14, n=300)
+    g, o = _run_both(oracle, cloud2, v, gpu_device)
+    _check_all(g, o)
