@@ -196,6 +196,27 @@ int32_t pgr_compose_object(int32_t n, const float *xyz, const float *rot, const 
                            int32_t in_rest_stride, const PgrObjectPose *pose, float *out_xyz, float *out_rot,
                            float *out_rest, int32_t out_rest_stride, void *stream);
 
+/* Gradients returned by pgr_backward (device pointers, any may be NULL = not wanted). */
+typedef struct PgrGradOutputs {
+    float *means2d;              /* [n,3] screen-space mean, NDC-scaled (what viewspace_points.grad receives) */
+    float *means3d;              /* [n,3] */
+    float *opacities;            /* [n]   */
+    float *colors;               /* [n,3] wrt colors_precomp (or the SH-evaluated rgb) */
+    float *shs;                  /* [n,sh_stride,3] */
+    float *cov3d;                /* [n,6] wrt the stored covariance parameters */
+    float *scales;               /* [n,3] */
+    float *rotations;            /* [n,4] */
+} PgrGradOutputs;
+
+/* Backward of ONE view rendered by pgr_forward into `workspace` (which must be untouched since, with the same
+ * n / image size / max_instances), given dL/dcolor [3,H,W] and optionally dL/ddepth [1,H,W], and the forward's
+ * final_T / n_contrib outputs.  Replaces _C.rasterize_gaussians_backward of the reference's extension (used by
+ * training only: /root/reference/src/gs/gs_training.py:7,46).  `grad_rows` is scratch of n*12 floats. */
+int32_t pgr_backward(const PgrScene *scene, const PgrCamera *camera, const float *grad_color,
+                     const float *grad_depth, const float *final_T, const uint32_t *n_contrib,
+                     const int32_t *radii, void *workspace, size_t workspace_bytes, int64_t max_instances,
+                     const PgrGradOutputs *grads, float *grad_rows, void *stream);
+
 /* present[i] = 1 iff Gaussian i passes the near-plane test of `viewmatrix` (device [16]). */
 int32_t pgr_mark_visible(int32_t n, const float *means3d, const float *viewmatrix, uint8_t *present,
                          void *stream);

@@ -22,11 +22,11 @@ _CFLAGS = ["-O2", "-std=c11", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-
 
 def build(force: bool = False) -> Path:
     """Compile the oracle with gcc (same flags as oracle/Makefile)."""
-    src = _HERE / "pgr_oracle.c"
-    if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < max(
-            src.stat().st_mtime, (_HERE / "pgr_oracle.h").stat().st_mtime):
+    srcs = [_HERE / "pgr_oracle.c", _HERE / "pgr_oracle_backward.c"]
+    newest = max(p.stat().st_mtime for p in srcs + [_HERE / "pgr_oracle.h"])
+    if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < newest:
         tmp = _LIB_PATH.with_suffix(f".tmp{os.getpid()}.so")
-        subprocess.run(["gcc", *_CFLAGS, "-shared", "-o", str(tmp), str(src), "-lm"], check=True)
+        subprocess.run(["gcc", *_CFLAGS, "-shared", "-o", str(tmp), *map(str, srcs), "-lm"], check=True)
         os.replace(tmp, _LIB_PATH)
     return _LIB_PATH
 
@@ -55,6 +55,11 @@ class _Out(C.Structure):
     ]
 
 
+class _Grads(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("means2d", "means3d", "opacities", "colors", "shs", "cov3d", "scales",
+                                          "rotations")]
+
+
 _lib = None
 
 
@@ -77,6 +82,8 @@ def lib():
         _lib.pgr_oracle_tile_may_contribute.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                                          C.c_int32]
         _lib.pgr_oracle_tile_may_contribute.restype = C.c_int
+        _lib.pgr_oracle_backward.argtypes = [C.POINTER(_In), C.c_void_p, C.c_void_p, C.POINTER(_Grads), C.c_int]
+        _lib.pgr_oracle_backward.restype = C.c_int
         _lib.pgr_oracle_version.restype = C.c_char_p
     return _lib
 
@@ -167,6 +174,31 @@ def forward(means3d, opacities, *, num_threads=1, want_binning=True, stage="all"
     if want_binning:   # cull_mode 1 emits fewer instances than the rectangle count the arrays were sized for
         r["keys_sorted"] = r["keys_sorted"][:r["num_instances"]]
         r["gauss_sorted"] = r["gauss_sorted"][:r["num_instances"]]
+    del keep
+    return r
+
+
+def backward(means3d, opacities, grad_color, grad_depth=None, *, num_threads=1, **kw):
+    """Gradients of sum(grad_color * color) + sum(grad_depth * depth) wrt the rasterizer inputs (dict of numpy)."""
+    i, keep, n = _make_in(means3d, opacities, **kw)
+    H, W = i.height, i.width
+    gc = _f32(grad_color).reshape(3, H, W)
+    gd = None if grad_depth is None else _f32(grad_depth).reshape(H, W)
+    stride = i.sh_stride
+    r = dict(means2d=np.zeros((n, 3), np.float32), means3d=np.zeros((n, 3), np.float32),
+             opacities=np.zeros(n, np.float32), colors=np.zeros((n, 3), np.float32),
+             cov3d=np.zeros((n, 6), np.float32))
+    if keep["shs"] is not None:
+        r["shs"] = np.zeros((n, stride, 3), np.float32)
+    if keep["scales"] is not None:
+        r["scales"] = np.zeros((n, 3), np.float32)
+        r["rotations"] = np.zeros((n, 4), np.float32)
+    g = _Grads()
+    for k, v in r.items():
+        setattr(g, k, _ptr(v))
+    rc = lib().pgr_oracle_backward(C.byref(i), _ptr(gc), _ptr(gd), C.byref(g), int(num_threads))
+    if rc:
+        raise ValueError(f"pgr_oracle_backward failed: {rc}")
     del keep
     return r
 

@@ -49,6 +49,11 @@ class PgrObjectPose(C.Structure):
                 ("D1", C.c_float * 9), ("D2", C.c_float * 25), ("D3", C.c_float * 49)]
 
 
+class PgrGradOutputs(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("means2d", "means3d", "opacities", "colors", "shs", "cov3d", "scales",
+                                          "rotations")]
+
+
 class PgrWorkspaceView(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("splats", "rects", "gauss_sorted", "ranges", "num_instances")]
 
@@ -79,6 +84,9 @@ SYMBOLS = {
                                                C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_float)]),
     "pgr_workspace_view": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                        C.c_int32, C.c_int32, C.POINTER(PgrWorkspaceView)]),
+    "pgr_backward": (C.c_int32, [C.POINTER(PgrScene), C.POINTER(PgrCamera), C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.POINTER(PgrGradOutputs),
+                                 C.c_void_p, C.c_void_p]),
     "pgr_compose_object": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                        C.POINTER(PgrObjectPose), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                        C.c_void_p]),

@@ -12,7 +12,9 @@ LIB = CSRC / "libpegasus_raster.so"
 ARCH = "gfx950"
 # -ffp-contract=off: every fused multiply-add in the kernels is an explicit fmaf(), which is what
 # makes the integer stages bit-exact against the oracle (DESIGN.md "Arithmetic contract").
-FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", f"--offload-arch={ARCH}"]
+# -munsafe-fp-atomics: the backward pass accumulates with hardware global_atomic_add_f32 instead of a CAS loop.
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC", "-shared",
+         f"--offload-arch={ARCH}"]
 
 
 def sources():

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <vector>
 
+#include "backward.hip.h"
 #include "compose.hip.h"
 #include "composite.hip.h"
 #include "pgr_common.h"
@@ -461,6 +462,39 @@ int32_t pgr_forward_batch_profiled(const PgrScene* scene, const PgrSemantic* sem
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
     return rc;
+}
+
+int32_t pgr_backward(const PgrScene* scene, const PgrCamera* cam, const float* grad_color, const float* grad_depth,
+                     const float* final_T, const uint32_t* n_contrib, const int32_t* radii, void* workspace,
+                     size_t workspace_bytes, int64_t max_instances, const PgrGradOutputs* grads, float* grad_rows,
+                     void* stream_v) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    if (int rc = check_scene(scene)) return rc;
+    if (!cam || !grads || !grad_color || !final_T || !n_contrib || cam->image_width <= 0 || cam->image_height <= 0)
+        return PGR_ERR_INVALID_ARGUMENT;
+    const int N = scene->n, W = cam->image_width, H = cam->image_height;
+    if (N == 0) return PGR_OK;
+    if (!workspace || !grad_rows || !radii) return PGR_ERR_INVALID_ARGUMENT;
+    const Layout L = make_layout(N, W, H, max_instances);
+    const BatchLayout B = make_batch_layout(L, 1);
+    if (workspace_bytes < B.total) return PGR_ERR_WORKSPACE_TOO_SMALL;
+    char* ws = static_cast<char*>(workspace);
+    const ViewWs vw = carve(ws + B.views, L);
+    const CameraDev* camd = reinterpret_cast<const CameraDev*>(ws + B.cams);
+    if (!hip_ok(hipMemsetAsync(grad_rows, 0, (size_t)N * GRAD_ROW * sizeof(float), stream), "memset grad rows"))
+        return PGR_ERR_LAUNCH_FAILURE;
+    composite_backward_wave_kernel<<<2 * L.tiles, WAVE, 0, stream>>>(camd, vw.ranges, vw.gauss_sorted, vw.splats, final_T,
+                                                                     n_contrib, grad_color, grad_depth, grad_rows);
+    const GradOut go{grads->means2d, grads->means3d, grads->opacities, grads->colors, grads->shs, grads->cov3d,
+                     grads->scales, grads->rotations};
+    const int blocks = (N + 255) / 256;
+    switch (scene->shs ? scene->sh_degree : 0) {
+        case 0: preprocess_backward_kernel<0><<<blocks, 256, 0, stream>>>(*scene, camd, radii, grad_rows, go); break;
+        case 1: preprocess_backward_kernel<1><<<blocks, 256, 0, stream>>>(*scene, camd, radii, grad_rows, go); break;
+        case 2: preprocess_backward_kernel<2><<<blocks, 256, 0, stream>>>(*scene, camd, radii, grad_rows, go); break;
+        default: preprocess_backward_kernel<3><<<blocks, 256, 0, stream>>>(*scene, camd, radii, grad_rows, go); break;
+    }
+    return hip_ok(hipGetLastError(), "backward launch") ? PGR_OK : PGR_ERR_LAUNCH_FAILURE;
 }
 
 int32_t pgr_compose_object(int32_t n, const float* xyz, const float* rot, const float* f_rest, int32_t n_rest,

@@ -63,6 +63,95 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     return r["color"], r["radii"], r["depth"]
 
 
+class _RasterizeGaussians(torch.autograd.Function):
+    """Differentiable single-view rasterization (training path).  The forward keeps its own workspace (the
+    backward walks the same per-tile lists), so it does not share the pooled scratch of the no-grad path."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        L = _lib.lib()
+        rs = raster_settings
+        device = means3D.device
+        if device.type != "cuda":
+            raise RuntimeError("GaussianRasterizer needs tensors on a HIP device (torch device 'cuda'); "
+                               "there is no CPU path")
+        H, W, n = int(rs.image_height), int(rs.image_width), int(means3D.shape[0])
+        t = {k: _dev_f32(v, device) for k, v in dict(means3D=means3D, sh=sh, colors=colors_precomp, op=opacities,
+                                                     scales=scales, rot=rotations, cov=cov3Ds_precomp, bg=rs.bg,
+                                                     view=rs.viewmatrix, proj=rs.projmatrix, campos=rs.campos).items()}
+        scene = _lib.PgrScene(n=n, means3d=_ptr(t["means3D"]), opacities=_ptr(t["op"]), scales=_ptr(t["scales"]),
+                              rotations=_ptr(t["rot"]), cov3d_precomp=_ptr(t["cov"]), shs=_ptr(t["sh"]),
+                              colors_precomp=_ptr(t["colors"]), sh_degree=int(rs.sh_degree),
+                              sh_stride=int(t["sh"].shape[1]) if t["sh"] is not None else 0,
+                              scale_modifier=float(rs.scale_modifier))
+        cam = _lib.PgrCamera(image_width=W, image_height=H, tanfovx=float(rs.tanfovx), tanfovy=float(rs.tanfovy),
+                             viewmatrix=_ptr(t["view"]), projmatrix=_ptr(t["proj"]), campos=_ptr(t["campos"]),
+                             bg=_ptr(t["bg"]))
+        color = torch.empty((3, H, W), dtype=torch.float32, device=device)
+        depth = torch.empty((1, H, W), dtype=torch.float32, device=device)
+        radii = torch.empty((n,), dtype=torch.int32, device=device)
+        final_T = torch.empty((H, W), dtype=torch.float32, device=device)
+        n_contrib = torch.empty((H, W), dtype=torch.int32, device=device)
+        outs = _lib.PgrOutputs(color=_ptr(color), depth=_ptr(depth), radii=_ptr(radii), final_T=_ptr(final_T),
+                               n_contrib=_ptr(n_contrib))
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        max_inst = max(1 << 18, 4 * n)
+        need = C.c_int64(0)
+        with torch.cuda.device(device):
+            for _attempt in range(3):
+                ws = torch.empty(L.pgr_workspace_bytes(n, W, H, max_inst), dtype=torch.uint8, device=device)
+                status = L.pgr_forward(C.byref(scene), C.byref(cam), C.byref(outs), C.c_void_p(ws.data_ptr()),
+                                       ws.numel(), max_inst, C.byref(need), stream)
+                if status != _lib.PGR_ERR_INSTANCE_OVERFLOW:
+                    break
+                max_inst = int(need.value * 1.25) + 1024
+            _lib.check(status, "pgr_forward")
+        ctx.rs, ctx.max_inst, ctx.n = rs, max_inst, n
+        ctx.t = t
+        ctx.state = (ws, radii, final_T, n_contrib)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_color, _grad_radii, grad_depth):
+        L = _lib.lib()
+        rs, t, n = ctx.rs, ctx.t, ctx.n
+        ws, radii, final_T, n_contrib = ctx.state
+        device = ws.device
+        H, W = int(rs.image_height), int(rs.image_width)
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=device)
+        g = dict(means2d=z(n, 3), means3d=z(n, 3), opacities=z(n, 1))
+        if t["sh"] is not None:
+            g["shs"] = z(*t["sh"].shape)
+        else:
+            g["colors"] = z(n, 3)
+        if t["cov"] is not None:
+            g["cov3d"] = z(n, 6)
+        else:
+            g["scales"], g["rotations"] = z(n, 3), z(n, 4)
+        grads = _lib.PgrGradOutputs(**{k: _ptr(v) for k, v in g.items()})
+        scene = _lib.PgrScene(n=n, means3d=_ptr(t["means3D"]), opacities=_ptr(t["op"]), scales=_ptr(t["scales"]),
+                              rotations=_ptr(t["rot"]), cov3d_precomp=_ptr(t["cov"]), shs=_ptr(t["sh"]),
+                              colors_precomp=_ptr(t["colors"]), sh_degree=int(rs.sh_degree),
+                              sh_stride=int(t["sh"].shape[1]) if t["sh"] is not None else 0,
+                              scale_modifier=float(rs.scale_modifier))
+        cam = _lib.PgrCamera(image_width=W, image_height=H, tanfovx=float(rs.tanfovx), tanfovy=float(rs.tanfovy),
+                             viewmatrix=_ptr(t["view"]), projmatrix=_ptr(t["proj"]), campos=_ptr(t["campos"]),
+                             bg=_ptr(t["bg"]))
+        gc = grad_color.contiguous().float()
+        gd = None if grad_depth is None else grad_depth.contiguous().float()
+        rows = torch.empty((n, 12), dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            _lib.check(L.pgr_backward(C.byref(scene), C.byref(cam), _ptr(gc), _ptr(gd), _ptr(final_T), _ptr(n_contrib),
+                                      _ptr(radii), C.c_void_p(ws.data_ptr()), ws.numel(), ctx.max_inst,
+                                      C.byref(grads), _ptr(rows),
+                                      C.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "pgr_backward")
+        # means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings
+        return (g["means3d"], g["means2d"], g.get("shs"), g.get("colors"), g["opacities"], g.get("scales"),
+                g.get("rotations"), g.get("cov3d"), None)
+
+
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings: GaussianRasterizationSettings):
         super().__init__()
@@ -93,6 +182,12 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        inputs = (means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp)
+        if torch.is_grad_enabled() and any(x is not None and x.requires_grad for x in inputs):
+            if means2D is None:
+                means2D = torch.zeros_like(means3D, requires_grad=False)
+            return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                             cov3D_precomp, self.raster_settings)
         with torch.no_grad():
             return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                        cov3D_precomp, self.raster_settings)
