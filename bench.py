@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--separate-semantic", action="store_true",
                     help="semantic image by a second full pass over the objects (default: fused into the scene pass)")
     ap.add_argument("--sync-steps", action="store_true", help="one blocking render_batch per step (no pipelining)")
+    ap.add_argument("--input-order", action="store_true",
+                    help="keep the scene in its input order (default: one-time Morton layout per object, outside the timed region)")
     ap.add_argument("--raster-only", action="store_true", help="time only the full-scene RGB+depth pass (R), no masks")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--profile-steps", type=int, default=2, help="steps measured per-stage with HIP events")
@@ -109,7 +111,7 @@ def main():
     my_views = views[rank::world] or views
     act = cloud.activated()
     fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"],
-                         cloud.object_id, sh_degree=3, device=dev)
+                         cloud.object_id, sh_degree=3, device=dev, spatial_order=not args.input_order)
     specs = [fr.view_spec(v) for v in my_views]
     W, H = my_views[0].width, my_views[0].height
     P = W * H
@@ -266,6 +268,8 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": label, "gaussians": N, "width": W, "height": H, "views_per_step": B,
                    "distinct_views": len(my_views), "objects": fr.K,
+                   "scene_layout": ("input order" if fr.order is None else
+                                    "Morton order per object (one-time, at scene load, outside the timed region)"),
                    "outputs": ("color[3,H,W] f32 + depth[1,H,W] f32 + semantic image[3,H,W] f32 + masks[K,H,W] u8"
                                if with_masks else "color[3,H,W] f32 + depth[1,H,W] f32"),
                    "parallelism": f"view-shard x{world}"},

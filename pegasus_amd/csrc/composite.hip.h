@@ -56,6 +56,19 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int HALF_ROWS = 8;     // rows per half tile
 constexpr int WAVE_BATCH = 64;   // list entries staged per round
 
+// tuning knobs (measured on MI355X)
+#ifndef PGR_COMP_UNROLL
+#define PGR_COMP_UNROLL 8        // entries per unrolled group (divides 8)
+#endif
+#ifndef PGR_COMP_WAVES
+#define PGR_COMP_WAVES 0         // 0: let the compiler pick; k: cap VGPRs for k waves/SIMD
+#endif
+#if PGR_COMP_WAVES
+#define PGR_COMP_OCC __attribute__((amdgpu_waves_per_eu(PGR_COMP_WAVES, PGR_COMP_WAVES)))
+#else
+#define PGR_COMP_OCC
+#endif
+
 // SEM = true: PEGASUS's object-only semantic render (/root/reference/src/gs/render.py:68-97: all objects in their
 // semantic colours, environment REMOVED) from the scene's own data: `views` then points at the tiles'
 // OBJECT lists (tile_sort writes them as a by-product: the scene's sorted list minus the environment entries,
@@ -63,7 +76,7 @@ constexpr int WAVE_BATCH = 64;   // list entries staged per round
 // instead of its SH colour.  No second preprocess / binning / sort; pixel arithmetic is the sequence a separate
 // pass would execute, so the image is bit-identical (tests/test_gpu_parity.py).
 template <bool AUX, bool SEM>
-__global__ __launch_bounds__(WAVE) void composite_wave_kernel(const ViewEntry* __restrict__ views,
+__global__ __launch_bounds__(WAVE) PGR_COMP_OCC void composite_wave_kernel(const ViewEntry* __restrict__ views,
                                                               uint32_t items_per_view,
                                                               const uint32_t* __restrict__ work_order,
                                                               SemanticDev sem) {
@@ -93,10 +106,11 @@ __global__ __launch_bounds__(WAVE) void composite_wave_kernel(const ViewEntry* _
     const int n = (int)(range.y - range.x);
 
     constexpr int PADDED = WAVE_BATCH + 8;        // room for the null entries that pad a batch to a multiple of 8
-    __shared__ float4 s_a[2][PADDED];   // x, y, hx, ny
-    __shared__ float4 s_b[2][PADDED];   // hz, opacity, r, g
-    __shared__ float2 s_c[2][PADDED];   // b, depth
-    __shared__ uint32_t s_i[2][PADDED]; // 1-based position in the tile's list (n_contrib bookkeeping)
+    // single-buffered: the workgroup is one wave, which writes a batch, reads it, then writes the next in program order
+    __shared__ float4 s_a[1][PADDED];   // x, y, hx, ny
+    __shared__ float4 s_b[1][PADDED];   // hz, opacity, r, g
+    __shared__ float2 s_c[1][PADDED];   // b, depth
+    __shared__ uint32_t s_i[1][PADDED]; // 1-based position in the tile's list (n_contrib bookkeeping)
 
     f32x2 T = {1.0f, 1.0f}, Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f}, D = {0.f, 0.f};
     uint32_t last0 = 0, last1 = 0;
@@ -123,8 +137,8 @@ __global__ __launch_bounds__(WAVE) void composite_wave_kernel(const ViewEntry* _
     const float rx1 = fminf(rx0 + (float)(TILE - 1), (float)(W - 1));
     const float ry1 = fminf(ry0 + (float)(HALF_ROWS - 1), (float)(H - 1));
 
-    int buf = 0;
-    for (int base = 0; base < n; base += WAVE_BATCH, buf ^= 1) {
+    constexpr int buf = 0;
+    for (int base = 0; base < n; base += WAVE_BATCH) {
         // Skip + compact: lane j decides whether ITS entry can reach alpha >= 1/255 anywhere in this wave's
         // 16x8 pixels (same conservative predicate as the binning, on the half tile).  Entries that cannot are
         // no-ops for every lane, so only the live ones are parked in LDS, compacted in list order; the batch is
@@ -163,9 +177,9 @@ __global__ __launch_bounds__(WAVE) void composite_wave_kernel(const ViewEntry* _
                 cd = make_float4(col[0], col[1], col[2], q2.y);
             }
         }
-        for (int j0 = 0; j0 < cnt; j0 += 8) {
+        for (int j0 = 0; j0 < cnt; j0 += PGR_COMP_UNROLL) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < PGR_COMP_UNROLL; ++u) {
                 const int j = j0 + u;
                 const float4 a = s_a[buf][j];
                 const float4 b = s_b[buf][j];
@@ -230,6 +244,202 @@ finished:
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// composite_quarter_kernel: ONE WAVE per quarter tile (8 x 8 pixels), one pixel per lane.  Same list walk, skip +
+// compaction and per-pixel arithmetic as composite_wave_kernel; the finer unit tightens both the per-entry skip
+// test (8x8 instead of 16x8 pixel rectangle) and the early-out (the wave stops when ITS 64 pixels are saturated).
+// gfx950 issues packed fp32 at the plain fp32 lane rate, so one pixel per lane costs the same per pixel.
+#ifdef PGR_COMP_STATS
+// debug build only: [0] list entries walked, [1] live entries after the skip test, [2] wave-entries evaluated,
+// [3] pixel-entries with the pixel still alive, [4] pixel-entries blended, [5] waves, [6] batches
+__device__ unsigned long long g_comp_stats[8];
+#endif
+
+template <bool AUX, bool SEM>
+__global__ __launch_bounds__(WAVE) PGR_COMP_OCC void composite_quarter_kernel(const ViewEntry* __restrict__ views,
+                                                                              uint32_t items_per_view,
+                                                                              const uint32_t* __restrict__ work_order,
+                                                                              SemanticDev sem) {
+    uint32_t item = work_order ? work_order[blockIdx.x] : blockIdx.x;
+    if (item == INVALID_ITEM) return;
+    const uint32_t view = item / items_per_view;
+    item -= view * items_per_view;
+    const ViewEntry& ve = views[view];
+    if (ve.counters[1] || !ve.out.color) return;
+    const CameraDev& cam = *ve.cam;
+    const uint2* __restrict__ ranges = ve.ranges;
+    const uint32_t* __restrict__ gauss_sorted = ve.gauss_sorted;
+    const float4* __restrict__ splats = ve.splats;
+    const CompOut o = ve.out;
+    const int W = cam.width, H = cam.height;
+    const int tile = (int)(item >> 2), quarter = (int)(item & 3);
+    const int tile_x = tile % cam.grid_x, tile_y = tile / cam.grid_x;
+    const int lane = threadIdx.x;
+    const int qx0 = tile_x * TILE + (quarter & 1) * 8, qy0 = tile_y * TILE + (quarter >> 1) * 8;
+    if (qx0 >= W || qy0 >= H) return;            // quarter entirely outside the image
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const f32x2 pxf = {(float)px, (float)px}, pyf = {(float)py, (float)py};
+
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+
+    // LDS image of a compacted batch, laid out for PAIRS of consecutive entries (2k, 2k+1): the geometry of a pair is
+    // evaluated with packed fp32 (one v_pk_* per two entries; v_pk_fma_f32 costs 1.2x a v_fma_f32 on gfx950,
+    // scripts/microbench/valu_rates.hip) and arrives from LDS already in packed register pairs:
+    //   s_g[3k+0] = (x0, x1, y0, y1)   s_g[3k+1] = (hx0, hx1, ny0, ny1)   s_g[3k+2] = (hz0, hz1, op0, op1)
+    //   s_c[j]    = (r, g, b, depth) of entry j: two packed accumulators (Cr,Cg) and (Cb,D)
+    constexpr int PAIRS = WAVE_BATCH / 2 + 1;     // +1 pair of null entries pads an odd batch
+    __shared__ float4 s_g[3 * PAIRS];
+    __shared__ float4 s_c[2 * PAIRS];
+    __shared__ uint32_t s_i[2 * PAIRS];
+    float* const s_gf = reinterpret_cast<float*>(s_g);
+
+    float T = 1.0f;
+    f32x2 Crg = {0.f, 0.f}, Cbd = {0.f, 0.f};
+    uint32_t last = 0;
+    // pixel state masks live in SGPR pairs: v_cmp writes them, s_and/s_andn2 combine them (scalar unit, beside the
+    // VALU stream), and the all-done test is a scalar compare -- no VALU instruction is spent on control
+    unsigned long long alive = __builtin_amdgcn_ballot_w64(inside);
+
+    float2 p = make_float2(0.f, 0.f);
+    float4 co = make_float4(0.f, 0.f, 0.f, 0.f), cd = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < n) {
+        const uint32_t g = gauss_sorted[range.x + lane];
+        const float4* rec = splats + (size_t)g * 3;
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+        p = make_float2(q0.x, q0.y);
+        co = make_float4(q0.z, q0.w, q1.x, q1.y);
+        cd = make_float4(q1.z, q1.w, q2.x, q2.y);
+        if (SEM) {
+            const float* col = sem.colors + 3 * (size_t)(sem.object_id[g] - 1);
+            cd = make_float4(col[0], col[1], col[2], q2.y);
+        }
+    }
+    const float rx0 = (float)qx0, ry0 = (float)qy0;
+    const float rx1 = fminf(rx0 + 7.0f, (float)(W - 1)), ry1 = fminf(ry0 + 7.0f, (float)(H - 1));
+
+#ifdef PGR_COMP_STATS
+    unsigned long long st_walk = 0, st_live = 0, st_eval = 0, st_alive = 0, st_blend = 0, st_batches = 0;
+#endif
+    for (int base = 0; base < n; base += WAVE_BATCH) {
+        // Skip + compact (see composite_wave_kernel): only entries that can reach alpha >= 1/255 somewhere in this
+        // wave's 8x8 pixels are parked, in list order; an odd batch is padded with one null entry (opacity 0).
+        const bool live = base + lane < n && rect_may_contribute(make_cull_splat(p, co), rx0, ry0, rx1, ry1);
+        const unsigned long long mask = __ballot(live);
+        const int cnt = __popcll(mask);
+        const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+#ifdef PGR_COMP_STATS
+        st_walk += min(WAVE_BATCH, n - base); st_live += cnt; st_batches++;
+#endif
+        if (live) {
+            float* gq = s_gf + 12 * (pos >> 1) + (pos & 1);
+            gq[0] = p.x;  gq[2] = p.y;
+            gq[4] = -0.5f * co.x;  gq[6] = -co.y;
+            gq[8] = -0.5f * co.z;  gq[10] = co.w;
+            s_c[pos] = cd;
+            if (AUX) s_i[pos] = (uint32_t)(base + lane + 1);
+        }
+        if (lane == 0 && (cnt & 1)) {
+            float* gq = s_gf + 12 * (cnt >> 1) + 1;
+            gq[0] = 0.f; gq[2] = 0.f; gq[4] = 0.f; gq[6] = 0.f; gq[8] = 0.f; gq[10] = 0.f;
+            s_c[cnt] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (AUX) s_i[cnt] = 0u;
+        }
+        __syncthreads();
+        // issue the gather of the NEXT batch now; it lands while this batch is composited
+        p = make_float2(0.f, 0.f);
+        co = make_float4(0.f, 0.f, 0.f, 0.f);
+        cd = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (base + WAVE_BATCH + lane < n) {
+            const uint32_t g = gauss_sorted[range.x + base + WAVE_BATCH + lane];
+            const float4* rec = splats + (size_t)g * 3;
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+            p = make_float2(q0.x, q0.y);
+            co = make_float4(q0.z, q0.w, q1.x, q1.y);
+            cd = make_float4(q1.z, q1.w, q2.x, q2.y);
+            if (SEM) {
+                const float* col = sem.colors + 3 * (size_t)(sem.object_id[g] - 1);
+                cd = make_float4(col[0], col[1], col[2], q2.y);
+            }
+        }
+        const int pairs = __builtin_amdgcn_readfirstlane((cnt + 1) >> 1);
+        for (int k = 0; k < pairs; ++k) {
+            const float4 g0 = s_g[3 * k], g1 = s_g[3 * k + 1], g2 = s_g[3 * k + 2];
+            // geometry of entries 2k and 2k+1 side by side; per entry this is the oracle's operation order
+            const f32x2 dx = (f32x2){g0.x, g0.y} - pxf;
+            const f32x2 dy = (f32x2){g0.z, g0.w} - pyf;
+            const f32x2 t1 = (f32x2){g1.z, g1.w} * dy;
+            const f32x2 t2 = __builtin_elementwise_fma((f32x2){g1.x, g1.y}, dx, t1);
+            const f32x2 t4 = ((f32x2){g2.x, g2.y} * dy) * dy;
+            const f32x2 power = __builtin_elementwise_fma(dx, t2, t4);
+            const f32x2 p2 = power * (f32x2){1.4426950408889634f, 1.4426950408889634f};
+            const f32x2 ex = {__builtin_amdgcn_exp2f(p2.x), __builtin_amdgcn_exp2f(p2.y)};
+            const f32x2 araw = (f32x2){g2.z, g2.w} * ex;
+            const unsigned long long m_pw[2] = {__builtin_amdgcn_ballot_w64(!(power.x > 0.0f)),
+                                                __builtin_amdgcn_ballot_w64(!(power.y > 0.0f))};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float4 c = s_c[2 * k + u];
+                const float alpha = fminf(ALPHA_MAX, u ? araw.y : araw.x);
+                const float test_T = fmaf(-alpha, T, T);
+                const unsigned long long valid = alive & m_pw[u] & __builtin_amdgcn_ballot_w64(!(alpha < ALPHA_MIN));
+                const unsigned long long stop = valid & __builtin_amdgcn_ballot_w64(test_T < T_EPS);
+                alive &= ~stop;
+                const unsigned long long blend = valid & ~stop;
+                const bool bl = __builtin_amdgcn_inverse_ballot_w64(blend);
+#ifdef PGR_COMP_STATS
+                st_eval++; st_alive += __popcll(alive | stop); st_blend += __popcll(blend);
+#endif
+                // blended: T' = fma(-alpha, T, T) = test_T; not blended: weight 0 (exact no-op) and T unchanged
+                const float w = bl ? alpha * T : 0.0f;
+                const f32x2 wv = {w, w};
+                Crg = __builtin_elementwise_fma((f32x2){c.x, c.y}, wv, Crg);
+                Cbd = __builtin_elementwise_fma((f32x2){c.z, c.w}, wv, Cbd);
+                T = bl ? test_T : T;
+                if (AUX) last = bl ? s_i[2 * k + u] : last;
+            }
+            if (alive == 0ull) goto finished;
+        }
+        __syncthreads();
+    }
+finished:
+#ifdef PGR_COMP_STATS
+    if (lane == 0 && !SEM) {
+        atomicAdd(&g_comp_stats[0], st_walk); atomicAdd(&g_comp_stats[1], st_live); atomicAdd(&g_comp_stats[2], st_eval);
+        atomicAdd(&g_comp_stats[3], st_alive); atomicAdd(&g_comp_stats[4], st_blend); atomicAdd(&g_comp_stats[5], 1ull);
+        atomicAdd(&g_comp_stats[6], st_batches);
+    }
+#endif
+    if (inside) {
+        const size_t P = (size_t)W * H;
+        const size_t pix = (size_t)py * W + px;
+        o.color[0 * P + pix] = fmaf(T, cam.bg[0], Crg.x);
+        o.color[1 * P + pix] = fmaf(T, cam.bg[1], Crg.y);
+        o.color[2 * P + pix] = fmaf(T, cam.bg[2], Cbd.x);
+        if (o.depth) o.depth[pix] = Cbd.y;
+        if (AUX) {
+            if (o.final_T) o.final_T[pix] = T;
+            if (o.n_contrib) o.n_contrib[pix] = last;
+        }
+    }
+}
+
+#ifndef PGR_COMP_ITEMS
+#define PGR_COMP_ITEMS 4         // work items per tile: 2 = half tiles (16x8, 2 px/lane), 4 = quarter tiles (8x8)
+#endif
+constexpr uint32_t ITEMS_PER_TILE = PGR_COMP_ITEMS;
+
+template <bool AUX, bool SEM>
+inline void launch_composite(uint32_t slots, hipStream_t stream, const ViewEntry* views, uint32_t items_per_view,
+                             const uint32_t* work_order, SemanticDev sem) {
+    if (ITEMS_PER_TILE == 4)
+        composite_quarter_kernel<AUX, SEM><<<slots, WAVE, 0, stream>>>(views, items_per_view, work_order, sem);
+    else
+        composite_wave_kernel<AUX, SEM><<<slots, WAVE, 0, stream>>>(views, items_per_view, work_order, sem);
+}
+
 // Work ordering for the wave compositor: half-tile work items sorted by DESCENDING list length
 // (256 log-spaced length classes), so the long lists start first and the short ones back-fill the
 // SIMDs that finish early (longest-processing-time-first).  Order never affects results.
@@ -269,7 +479,7 @@ __global__ __launch_bounds__(256) void order_count_kernel(const ViewEntry* __res
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < tiles) {
         const uint2 r = views[blockIdx.y].ranges[t];
-        atomicAdd(&hist[xcd_of_tile(t, grid_x) * ORDER_CLASSES_USED + coarse_class(r.y - r.x)], 2u);   // two halves
+        atomicAdd(&hist[xcd_of_tile(t, grid_x) * ORDER_CLASSES_USED + coarse_class(r.y - r.x)], ITEMS_PER_TILE);
     }
     __syncthreads();
     if (threadIdx.x < ORDER_BINS && hist[threadIdx.x]) atomicAdd(&state[threadIdx.x], hist[threadIdx.x]);
@@ -322,17 +532,16 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const ViewEntry* __r
     if (threadIdx.x < ORDER_BINS) {
         const uint32_t tot = wave_cnt[0][threadIdx.x] + wave_cnt[1][threadIdx.x] + wave_cnt[2][threadIdx.x] +
                              wave_cnt[3][threadIdx.x];
-        base[threadIdx.x] = tot ? atomicAdd(&state[threadIdx.x], 2u * tot) : 0u;
+        base[threadIdx.x] = tot ? atomicAdd(&state[threadIdx.x], ITEMS_PER_TILE * tot) : 0u;
     }
     if (threadIdx.x == 0 && n_long_s) long_base_s = atomicAdd(&state[ORDER_BINS], n_long_s);
     __syncthreads();
     if (t < tiles) {
         uint32_t before = 0;
         for (int w = 0; w < wave; ++w) before += wave_cnt[w][bin];
-        const uint32_t r0 = base[bin] + 2u * (before + rank);     // position inside stream x
-        const uint32_t item = (uint32_t)blockIdx.y * 2u * (uint32_t)tiles + 2u * (uint32_t)t;
-        work_order[(size_t)r0 * NUM_XCD + x] = item;
-        work_order[(size_t)(r0 + 1) * NUM_XCD + x] = item + 1u;
+        const uint32_t r0 = base[bin] + ITEMS_PER_TILE * (before + rank);     // position inside stream x
+        const uint32_t item = ITEMS_PER_TILE * ((uint32_t)blockIdx.y * (uint32_t)tiles + (uint32_t)t);
+        for (uint32_t k = 0; k < ITEMS_PER_TILE; ++k) work_order[(size_t)(r0 + k) * NUM_XCD + x] = item + k;
         if (long_rank != INVALID_ITEM) long_list[long_base_s + long_rank] = (uint32_t)blockIdx.y * (uint32_t)tiles + (uint32_t)t;
     }
 }

@@ -137,7 +137,7 @@ static BatchLayout make_batch_layout(const Layout& L, int n_views) {
     B.tile_counts = take((size_t)n_views * L.tiles * 12);  // [tile_count u32 | obj_ranges uint2] x views: one memset
     B.order_state = take(ORDER_STATE_WORDS * 4);
     // NUM_XCD interleaved streams; each holds the items of its band of tile rows for every view
-    B.order_slots = (size_t)NUM_XCD * max_band_rows(L.grid_y) * L.grid_x * 2 * n_views;
+    B.order_slots = (size_t)NUM_XCD * max_band_rows(L.grid_y) * L.grid_x * ITEMS_PER_TILE * n_views;
     B.work_order = take(B.order_slots * 4);
     B.sem_order_state = take(ORDER_STATE_WORDS * 4);
     B.sem_work_order = take(B.order_slots * 4);
@@ -306,13 +306,13 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     tile_sort_kernel<<<n_views * L.tiles, SORT_THREADS, 0, stream>>>(bin_table, L.tiles);
     mark(4);
     // ---- stage 4: compositing of every (view, tile, half) work item in ONE launch
-    const uint32_t items_per_view = 2u * (uint32_t)L.tiles;
+    const uint32_t items_per_view = ITEMS_PER_TILE * (uint32_t)L.tiles;
     const uint32_t slots = (uint32_t)B.order_slots;
     const SemanticDev no_sem{nullptr, nullptr, 0, 0};
     if (want_aux)
-        composite_wave_kernel<true, false><<<slots, WAVE, 0, stream>>>(view_table, items_per_view, work_order, no_sem);
+        launch_composite<true, false>(slots, stream, view_table, items_per_view, work_order, no_sem);
     else
-        composite_wave_kernel<false, false><<<slots, WAVE, 0, stream>>>(view_table, items_per_view, work_order, no_sem);
+        launch_composite<false, false>(slots, stream, view_table, items_per_view, work_order, no_sem);
     mark(5);
     if (want_sem) {
         if (!semantic->object_id || !semantic->colors || semantic->n_env < 0 || semantic->k_objects <= 0)
@@ -328,7 +328,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         order_scan_kernel<<<1, 64, 0, stream>>>(sem_state);
         order_scatter_kernel<<<og, 256, 0, stream>>>(sem_table, L.tiles, L.grid_x, sem_state, sem_order, 0xffffffffu,
                                                      long_list);
-        composite_wave_kernel<false, true><<<slots, WAVE, 0, stream>>>(sem_table, items_per_view, sem_order, sd);
+        launch_composite<false, true>(slots, stream, sem_table, items_per_view, sem_order, sd);
     }
     mark(6);
     if (!hip_ok(hipGetLastError(), "kernel launch")) return PGR_ERR_LAUNCH_FAILURE;
@@ -544,3 +544,12 @@ int32_t pgr_quantize_frame(const float* img_chw, const float* depth_hw, int32_t 
 }
 
 }  // extern "C"
+
+#ifdef PGR_COMP_STATS
+extern "C" int32_t pgr_debug_comp_stats(unsigned long long* out, int32_t reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -4;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pgr::g_comp_stats), 64) != hipSuccess) return -4;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(pgr::g_comp_stats), z, 64) != hipSuccess) return -4; }
+    return 0;
+}
+#endif

@@ -24,15 +24,29 @@ from .sh_utils import RGB2SH
 
 class FrameRenderer:
     def __init__(self, means3d, opacities, scales, rotations, shs, object_id, sh_degree=3, device="cuda:0",
-                 bg=(0.0, 0.0, 0.0), color_mode="bgr"):
+                 bg=(0.0, 0.0, 0.0), color_mode="bgr", spatial_order=True):
         """All arrays are ACTIVATED values (numpy or torch), environment Gaussians first (object_id 0) and
-        each object's Gaussians after (object_id k = 1..K), as PEGASUS merges them."""
+        each object's Gaussians after (object_id k = 1..K), as PEGASUS merges them.
+
+        spatial_order: one-time scene layout step (pegasus_amd/scene_order.py): the resident copy is stored in
+        Morton order inside the environment and inside every object.  Frames do not depend on the storage order
+        (per-tile lists are depth-ordered; only EXACT depth ties fall back to the index), the memory behaviour of
+        binning and gathering does.  ``self.order[i]`` = caller's index of resident Gaussian i (None: unchanged)."""
         self.device = torch.device(device)
+        self.order = None
+        if spatial_order and len(means3d) > 1:
+            from .scene_order import spatial_order as _spatial_order
+            host = lambda a: a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+            perm = _spatial_order(host(means3d), host(object_id))
+            pick = lambda a: (a[torch.as_tensor(perm, device=a.device)] if torch.is_tensor(a) else np.asarray(a)[perm])
+            means3d, opacities, scales, rotations, shs, object_id = (
+                pick(a) for a in (means3d, opacities, scales, rotations, shs, object_id))
+            self.order = perm
         t = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a
                                                         ).to(self.device, dt).contiguous()
         self.means3d, self.opacities, self.scales, self.rotations, self.shs = (
             t(means3d), t(opacities), t(scales), t(rotations), t(shs))
-        oid = np.asarray(object_id).astype(np.int64)
+        oid = (object_id.detach().cpu().numpy() if torch.is_tensor(object_id) else np.asarray(object_id)).astype(np.int64)
         self.sh_degree = int(sh_degree)
         self.bg = t(np.asarray(bg, np.float32))
         self.n = int(self.means3d.shape[0])

@@ -1,0 +1,28 @@
+"""Debug: compositor work statistics from a -DPGR_COMP_STATS build
+(scripts/variant_sweep.sh build "2:0" -DPGR_COMP_ITEMS=4 -DPGR_COMP_STATS; copy it over csrc/libpegasus_raster.so)."""
+import ctypes as C
+import sys
+import torch
+sys.path.insert(0, ".")
+sys.path.insert(0, "..")
+import bench
+from pegasus_amd import _lib, frames as F
+
+L = _lib.lib()
+handle = C.CDLL(str(_lib.LIB_PATH))
+workload = sys.argv[1] if len(sys.argv) > 1 else "c3"
+B = 16
+cloud, views, label = bench.build_workload(workload, 1.0, B)
+act = cloud.activated()
+fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"], cloud.object_id,
+                     sh_degree=3, device="cuda:0")
+specs = [fr.view_spec(v) for v in views[:B]]
+fr.render_frames(specs, None, masks=False)
+out = (C.c_ulonglong * 8)()
+handle.pgr_debug_comp_stats(out, 1)
+fr.render_frames(specs, None, masks=False)
+handle.pgr_debug_comp_stats(out, 1)
+walk, live, ev, alive, blend, waves, batches = [out[i] / B for i in range(7)]
+print(f"{label}: per view: waves {waves:.0f}  batches {batches:.0f}  entries walked {walk/1e6:.2f} M  live after skip {live/1e6:.2f} M "
+      f"({live/walk:.2%})  wave-entries evaluated {ev/1e6:.2f} M  pixel-entries: alive {alive/1e6:.1f} M "
+      f"({alive/(ev*64):.2%} of lanes)  blended {blend/1e6:.1f} M ({blend/(ev*64):.2%})  live/batch {live/batches:.1f}")

@@ -1,0 +1,97 @@
+// Microbenchmark: issue cost (cycles per wave64 instruction) of the VALU instructions the compositor is made of.
+// hipcc --offload-arch=gfx950 -O3 valu_rates.hip -o valu_rates && ./valu_rates
+// Each kernel runs ITER iterations of 16 independent instructions per wave; waves/SIMD = 1, 2, 4, 8.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+constexpr int ITER = 4096;
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+
+template <int KIND>
+__global__ __launch_bounds__(64) void k(float* out, float seed) {
+    float a[16]; f2 p[16];
+    for (int i = 0; i < 16; ++i) { a[i] = seed + i + threadIdx.x; p[i] = (f2){a[i], a[i] + 0.5f}; }
+    float s = seed; f2 ps = {seed, seed};
+    unsigned long long m = 0;
+    for (int it = 0; it < ITER; ++it) {
+        if (KIND == 0) {
+#define X(i) asm volatile("v_fma_f32 %0, %1, %0, %1" : "+v"(a[i]) : "v"(s));
+            REP16(X)
+#undef X
+        } else if (KIND == 1) {
+#define X(i) asm volatile("v_pk_fma_f32 %0, %1, %0, %1" : "+v"(p[i]) : "v"(ps));
+            REP16(X)
+#undef X
+        } else if (KIND == 2) {
+#define X(i) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+            REP16(X)
+#undef X
+        } else if (KIND == 3) {
+#define X(i) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(s));
+            REP16(X)
+#undef X
+        } else if (KIND == 4) {
+#define X(i) asm volatile("v_cmp_gt_f32 vcc, %1, %0\n v_cndmask_b32 %0, 0, %0, vcc" : "+v"(a[i]) : "v"(s) : "vcc");
+            REP16(X)
+#undef X
+        } else if (KIND == 5) {
+#define X(i) asm volatile("v_readlane_b32 s20, %0, 3\n v_add_f32 %0, s20, %0" : "+v"(a[i]) : : "s20");
+            REP16(X)
+#undef X
+        } else if (KIND == 6) {
+#define X(i) asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(p[i]) : "v"(ps));
+            REP16(X)
+#undef X
+        } else if (KIND == 7) {
+#define X(i) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i]) : "v"(s));
+            REP16(X)
+#undef X
+        } else if (KIND == 8) {   // fma with an SGPR operand
+#define X(i) asm volatile("v_fma_f32 %0, s20, %0, %1" : "+v"(a[i]) : "v"(s) : "s20");
+            REP16(X)
+#undef X
+        } else if (KIND == 9) {   // v_min + v_cmp (writes sgpr pair)
+#define X(i) asm volatile("v_min_f32 %0, %1, %0\n v_cmp_lt_f32 s[20:21], %1, %0" : "+v"(a[i]) : "v"(s) : "s20", "s21");
+            REP16(X)
+#undef X
+        }
+    }
+    float r = 0;
+    for (int i = 0; i < 16; ++i) r += a[i] + p[i].x + p[i].y;
+    out[blockIdx.x * 64 + threadIdx.x] = r + (float)m;
+}
+
+template <int KIND>
+int run(const char* name, int per_inst, float* out) {
+    for (int wps : {1, 2, 4, 8}) {
+        const int blocks = 256 * 4 * wps;
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        k<KIND><<<blocks, 64>>>(out, 0.001f);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        k<KIND><<<blocks, 64>>>(out, 0.001f);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double inst_per_simd = (double)ITER * 16 * per_inst * wps;
+        printf("%-28s waves/SIMD %d: %.3f ms  -> %.2f cycles per wave-instruction at 2.4 GHz\n", name, wps, ms,
+               ms * 1e-3 * 2.4e9 / inst_per_simd);
+    }
+    return 0;
+}
+
+int main() {
+    float* out; CK(hipMalloc(&out, 256 * 4 * 8 * 64 * 4));
+    run<0>("v_fma_f32", 1, out);
+    run<1>("v_pk_fma_f32", 1, out);
+    run<7>("v_mul_f32", 1, out);
+    run<6>("v_pk_mul_f32", 1, out);
+    run<2>("v_exp_f32", 1, out);
+    run<3>("v_mov_b32", 1, out);
+    run<4>("v_cmp+v_cndmask (2 inst)", 2, out);
+    run<9>("v_min+v_cmp->sgpr (2 inst)", 2, out);
+    run<5>("v_readlane+v_add (2 inst)", 2, out);
+    run<8>("v_fma_f32 sgpr operand", 1, out);
+    return 0;
+}

@@ -248,6 +248,8 @@ def test_frame_renderer_rgb_depth_masks(oracle, gpu_device):
     torch.cuda.synchronize()
     n_env = fr.n_env
     sem_shs = fr.sem_shs.cpu().numpy()
+    assert fr.order is not None               # resident copy is in Morton order per object: same for the oracle
+    act = {k: np.ascontiguousarray(a[fr.order]) for k, a in act.items()}
     for i, v in enumerate(views):
         o = oracle.forward(**act, sh_degree=3, **v.raster_kwargs(), num_threads=8)
         g = dict(color=out["color"][i].cpu().numpy(), out_depth=out["depth"][i].cpu().numpy())
@@ -357,3 +359,26 @@ def test_single_gaussian_and_two_pixel_image(oracle, gpu_device):
     cloud2, _ = scenes.scene_c1(seed=14, n=300)
     g, o = _run_both(oracle, cloud2, v, gpu_device)
     _check_all(g, o)
+
+
+@pytest.mark.gpu
+def test_spatial_order_does_not_change_frames(gpu_device):
+    """FrameRenderer stores the scene in Morton order per object (scene_order.py); lists are depth-ordered, so the
+    frames are those of the input order (exact depth ties are the only index-dependent case)."""
+    import torch
+    from pegasus_amd import scenes
+    from pegasus_amd.frames import FrameRenderer
+    cloud, views = scenes.scene_c3(scale=0.02, n_views=2)
+    a = cloud.activated()
+    out = []
+    for so in (False, True):
+        fr = FrameRenderer(a["means3d"], a["opacities"], a["scales"], a["rotations"], a["shs"], cloud.object_id,
+                           device=gpu_device, spatial_order=so)
+        assert (fr.order is not None) == so
+        f = fr.render_frames([fr.view_spec(v) for v in views])
+        out.append({k: v.clone() for k, v in f.items()})
+    perm = fr.order
+    assert sorted(perm.tolist()) == list(range(cloud.n)) and np.all(np.diff(cloud.object_id[perm]) >= 0)
+    for k in ("color", "depth", "seg", "masks"):
+        x, y = out[0][k].float(), out[1][k].float()
+        assert torch.equal(x, y) or (x - y).abs().max().item() < 1e-6, k
