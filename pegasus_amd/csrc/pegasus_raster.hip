@@ -553,3 +553,12 @@ extern "C" int32_t pgr_debug_comp_stats(unsigned long long* out, int32_t reset) 
     return 0;
 }
 #endif
+
+#ifdef PGR_SORT_STATS
+extern "C" int32_t pgr_debug_sort_stats(unsigned long long* out, int32_t reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -4;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pgr::g_sort_stats), 64) != hipSuccess) return -4;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(pgr::g_sort_stats), z, 64) != hipSuccess) return -4; }
+    return 0;
+}
+#endif

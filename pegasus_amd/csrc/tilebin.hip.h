@@ -315,6 +315,155 @@ __device__ __forceinline__ void merge_sort_tile(uint64_t* __restrict__ skeys, co
     }
 }
 
+// ---- bucket sort (interpolation sort) of one tile list in LDS ---------------------------------------------------
+// A tile's depths span a narrow interval that its Gaussians fill fairly evenly, so a monotone map of the depth bits
+// onto NB = capacity buckets puts about one key in each: one LDS atomic per key builds the histogram AND hands the
+// key its arrival slot inside the bucket, one scan turns counts into bucket starts, one LDS store parks the key, and
+// the exact order inside a bucket (same 64-bit key compare as the merge sort, so the result is the same permutation)
+// is a count of the smaller keys among the bucket's few members.  ~10 LDS operations per key instead of the merge
+// sort's ~35 (log2(n) merge-path rounds).  Lists whose depths pile up (sum of squared bucket counts > 8 n) are
+// rejected and take the merge sort; the result never depends on which path ran.
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v, int ctrl, int row_mask, bool bound) {
+    switch (ctrl) {   // the builtin wants immediates
+        case 0x111: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x111, 0xF, 0xF, true);
+        case 0x112: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x112, 0xF, 0xF, true);
+        case 0x114: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x114, 0xF, 0xF, true);
+        case 0x118: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x118, 0xF, 0xF, true);
+        case 0x142: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x142, 0xA, 0xF, false);
+        default:    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x143, 0xC, 0xF, false);
+    }
+}
+
+// inclusive prefix sum over the 64 lanes of a wave (row shifts, then the two row broadcasts of gfx9)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    v += dpp_u32(0, v, 0x111, 0xF, true);   // row_shr:1
+    v += dpp_u32(0, v, 0x112, 0xF, true);   // row_shr:2
+    v += dpp_u32(0, v, 0x114, 0xF, true);   // row_shr:4
+    v += dpp_u32(0, v, 0x118, 0xF, true);   // row_shr:8
+    v += dpp_u32(0, v, 0x142, 0xA, false);  // row_bcast:15 -> rows 1, 3
+    v += dpp_u32(0, v, 0x143, 0xC, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+#ifdef PGR_SORT_STATS
+__device__ unsigned long long g_sort_stats[8];   // [0] lists, [1] keys, [2] sum k^2, [3] rejected lists, [4] rejected keys
+#endif
+
+constexpr uint32_t BUCKET_SQ_LIMIT = 8;
+
+// Sorts n <= THREADS*E keys of `bucket` into out[] (indices) -- same contract as merge_sort_tile without keys_out.
+// lds: THREADS*E*12 + 64 bytes.  Returns false (LDS free for reuse, nothing written) when the list is rejected.
+template <int THREADS, int E>
+__device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds, const uint2* __restrict__ bucket,
+                                                 uint32_t* __restrict__ out, int n, int n_env,
+                                                 uint32_t* __restrict__ obj_out, uint2* __restrict__ obj_range,
+                                                 uint32_t range_start) {
+    constexpr int NB = THREADS * E, WAVES = THREADS / WAVE;
+    uint64_t* s_keys = reinterpret_cast<uint64_t*>(lds);                       // [NB]
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(lds + (size_t)NB * 8);      // [NB], later the sorted indices
+    uint32_t* s_misc = s_hist + NB;                                            // [0] min [1] max [2] sum k^2 [4..] wave totals
+    const int t = threadIdx.x, lane = t & (WAVE - 1), wave = t / WAVE;
+
+    uint32_t d[E], id[E];
+    uint32_t dmin = 0xffffffffu, dmax = 0u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = e * THREADS + t;
+        d[e] = 0xffffffffu; id[e] = 0xffffffffu;
+        if (i < n) {
+            const uint2 v = bucket[i];
+            d[e] = v.x; id[e] = v.y;
+            dmin = min(dmin, v.x); dmax = max(dmax, v.x);
+        }
+        s_hist[i] = 0u;
+    }
+    if (t < 4 + WAVES) s_misc[t] = t == 0 ? 0xffffffffu : 0u;
+    __syncthreads();
+    // block min / max of the depth bits: butterfly inside the wave, one LDS atomic per wave
+#pragma unroll
+    for (int m = 1; m < WAVE; m <<= 1) {
+        dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, m));
+        dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, m));
+    }
+    if (lane == 0) { atomicMin(&s_misc[0], dmin); atomicMax(&s_misc[1], dmax); }
+    __syncthreads();
+    const uint32_t mn = s_misc[0];
+    const float scale = (float)NB / ((float)(s_misc[1] - mn) + 1.0f);
+    // monotone in d: uint->float conversion, multiplication by a positive constant, truncation and clamp all are
+    uint32_t br[E];      // bucket << 16 | arrival slot inside the bucket
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        br[e] = 0u;
+        if (e * THREADS + t < n) {
+            const uint32_t b = min((uint32_t)((float)(d[e] - mn) * scale), (uint32_t)(NB - 1));
+            br[e] = (b << 16) | atomicAdd(&s_hist[b], 1u);
+        }
+    }
+    __syncthreads();
+    // pass A: every wave owns NB / WAVES consecutive buckets (E chunks of 64): totals and sum of squares
+    const int wbase = wave * (WAVE * E);
+    uint32_t tot = 0, sq = 0;
+#pragma unroll
+    for (int c = 0; c < E; ++c) {
+        const uint32_t h = s_hist[wbase + c * WAVE + lane];
+        tot += h; sq += h * h;
+    }
+#pragma unroll
+    for (int m = 1; m < WAVE; m <<= 1) { tot += (uint32_t)__shfl_xor((int)tot, m); sq += (uint32_t)__shfl_xor((int)sq, m); }
+    if (lane == 0) { s_misc[4 + wave] = tot; atomicAdd(&s_misc[2], sq); }
+    __syncthreads();
+    const bool reject = s_misc[2] > BUCKET_SQ_LIMIT * (uint32_t)n;
+#ifdef PGR_SORT_STATS
+    if (t == 0) {
+        atomicAdd(&g_sort_stats[0], 1ull); atomicAdd(&g_sort_stats[1], (unsigned long long)n);
+        atomicAdd(&g_sort_stats[2], (unsigned long long)s_misc[2]);
+        if (reject) { atomicAdd(&g_sort_stats[3], 1ull); atomicAdd(&g_sort_stats[4], (unsigned long long)n); }
+    }
+#endif
+    if (reject) { __syncthreads(); return false; }
+    // pass B: exclusive scan of the counts -> bucket starts
+    uint32_t carry = 0;
+    for (int w = 0; w < wave; ++w) carry += s_misc[4 + w];
+#pragma unroll
+    for (int c = 0; c < E; ++c) {
+        const uint32_t h = s_hist[wbase + c * WAVE + lane];
+        const uint32_t incl = wave_inclusive_scan(h);
+        s_hist[wbase + c * WAVE + lane] = carry + incl - h;
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (e * THREADS + t < n) s_keys[s_hist[br[e] >> 16] + (br[e] & 0xffffu)] = ((uint64_t)d[e] << 32) | id[e];
+    __syncthreads();
+    // exact place inside the bucket: number of smaller keys among its members
+    uint32_t fin[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        fin[e] = 0u;
+        if (e * THREADS + t < n) {
+            const uint32_t b = br[e] >> 16;
+            const uint32_t s0 = s_hist[b], s1 = b + 1 < (uint32_t)NB ? s_hist[b + 1] : (uint32_t)n;
+            const uint64_t key = ((uint64_t)d[e] << 32) | id[e];
+            uint32_t rank = 0;
+            for (uint32_t j = s0; j < s1; ++j) rank += s_keys[j] < key ? 1u : 0u;
+            fin[e] = s0 + rank;
+        }
+    }
+    __syncthreads();
+    uint32_t* s_idx = s_hist;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (e * THREADS + t < n) s_idx[fin[e]] = id[e];
+    __syncthreads();
+    for (int i = t; i < n; i += THREADS) out[i] = s_idx[i];
+    if (n_env >= 0) {
+        const uint32_t cnt = compact_objects<THREADS>([&](int i) { return s_idx[i]; }, n, n_env, obj_out);
+        if (t == 0) *obj_range = make_uint2(range_start, range_start + cnt);
+    }
+    return true;
+}
+
 // One merge round over sorted runs of length `run` held in global memory (L2-resident): src -> dst.
 // Each thread produces G consecutive outputs per step; co-ranking by binary search as in the LDS rounds.
 template <int THREADS, int G>
@@ -367,18 +516,24 @@ __device__ __forceinline__ bool sort_item(const BinView* __restrict__ views, int
 
 // grid = n_views * tiles workgroups of 256; lists of 1..4096 entries
 __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* __restrict__ views, int tiles) {
-    __shared__ uint64_t skeys[SORT_THREADS * 17];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[SORT_THREADS * 16 * 12 + 64];
+    uint64_t* skeys = reinterpret_cast<uint64_t*>(lds);     // merge sort: SORT_THREADS * 17 keys fit as well
     const uint2* bucket; uint32_t* out; int n; ObjOut oo;
     if (!sort_item(views, tiles, blockIdx.x, bucket, out, n, oo)) return;
     if (n > SORT_SMALL_MAX) return;                      // the long tiers'
-    if (n <= SORT_THREADS * 2)
-        merge_sort_tile<SORT_THREADS, 2>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
-    else if (n <= SORT_THREADS * 4)
-        merge_sort_tile<SORT_THREADS, 4>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
-    else if (n <= SORT_THREADS * 8)
-        merge_sort_tile<SORT_THREADS, 8>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
-    else
-        merge_sort_tile<SORT_THREADS, 16>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
+    if (n <= SORT_THREADS * 2) {
+        if (!bucket_sort_tile<SORT_THREADS, 2>(lds, bucket, out, n, oo.n_env, oo.sorted, oo.range, oo.start))
+            merge_sort_tile<SORT_THREADS, 2>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
+    } else if (n <= SORT_THREADS * 4) {
+        if (!bucket_sort_tile<SORT_THREADS, 4>(lds, bucket, out, n, oo.n_env, oo.sorted, oo.range, oo.start))
+            merge_sort_tile<SORT_THREADS, 4>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
+    } else if (n <= SORT_THREADS * 8) {
+        if (!bucket_sort_tile<SORT_THREADS, 8>(lds, bucket, out, n, oo.n_env, oo.sorted, oo.range, oo.start))
+            merge_sort_tile<SORT_THREADS, 8>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
+    } else {
+        if (!bucket_sort_tile<SORT_THREADS, 16>(lds, bucket, out, n, oo.n_env, oo.sorted, oo.range, oo.start))
+            merge_sort_tile<SORT_THREADS, 16>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
+    }
 }
 
 // Lists longer than 4096: order_scatter_kernel appends them to long_list (device counter n_long); workgroups
@@ -394,7 +549,10 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS) void tile_sort_long_kernel(const BinView* __restrict__ views, int tiles,
                                                                  const uint32_t* __restrict__ long_list,
                                                                  const uint32_t* __restrict__ n_long) {
-    __shared__ uint64_t skeys[THREADS * 17];
+    // medium tier (512 threads): bucket sort image (12 B per key); large tier: merge sort keys (17 per thread)
+    constexpr size_t LDS_BYTES = THREADS == SORT_MEDIUM_THREADS ? (size_t)THREADS * 16 * 12 + 64 : (size_t)THREADS * 17 * 8;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    uint64_t* skeys = reinterpret_cast<uint64_t*>(lds);
     constexpr int CAP = THREADS * 16;
     const uint32_t cand = *n_long;
     for (uint32_t k = blockIdx.x; k < cand; k += gridDim.x) {
@@ -403,7 +561,11 @@ __global__ __launch_bounds__(THREADS) void tile_sort_long_kernel(const BinView* 
         const bool mine = THREADS == SORT_MEDIUM_THREADS ? (n > SORT_SMALL_MAX && n <= SORT_MEDIUM_MAX) : n > SORT_MEDIUM_MAX;
         if (ok && mine) {
             if (n <= CAP) {
-                merge_sort_tile<THREADS, 16>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
+                bool sorted = false;
+                if constexpr (THREADS == SORT_MEDIUM_THREADS)
+                    sorted = bucket_sort_tile<THREADS, 16>(lds, bucket, out, n, oo.n_env, oo.sorted, oo.range, oo.start);
+                if (!sorted)
+                    merge_sort_tile<THREADS, 16>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
             } else {
                 uint64_t* gk = reinterpret_cast<uint64_t*>(const_cast<uint2*>(bucket));
                 for (int c0 = 0; c0 < n; c0 += CAP) {

@@ -19,6 +19,15 @@ fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotat
 specs = [fr.view_spec(v) for v in views[:B]]
 fr.render_frames(specs, None, masks=False)
 out = (C.c_ulonglong * 8)()
+if hasattr(handle, "pgr_debug_sort_stats"):
+    handle.pgr_debug_sort_stats(out, 1)
+    fr.render_frames(specs, None, masks=False)
+    handle.pgr_debug_sort_stats(out, 1)
+    lists, keys, sq, rl, rk = [out[i] / B for i in range(5)]
+    print(f"{label}: bucket sort per view: lists {lists:.0f}  keys {keys/1e6:.2f} M  sum k^2 / keys {sq/max(keys,1):.2f}  "
+          f"rejected lists {rl:.1f} ({rk/max(keys,1):.2%} of keys)")
+if not hasattr(handle, "pgr_debug_comp_stats"):
+    raise SystemExit(0)
 handle.pgr_debug_comp_stats(out, 1)
 fr.render_frames(specs, None, masks=False)
 handle.pgr_debug_comp_stats(out, 1)
