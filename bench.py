@@ -79,8 +79,7 @@ def algorithmic_bytes(N, V, I, P):
         "bin_count": 0,
         "bin_scatter": 12 * I,
         "tile_sort": 24 * I + 8 * I,
-        "composite": 44 * I + 16 * P,
-        "composite_semantic": 4 * I + 16 * P,   # walks the same lists (indices only) + the objects' records
+        "composite": 44 * I + 16 * P,      # + 16 P for the fused semantic image, not counted (SURVEY's figure)
     }
     return 16 * N + 272 * V + 88 * I + 16 * P, per_stage
 
@@ -220,7 +219,7 @@ def main():
                        "frac": round(B_view * value / world / 1e9 / HBM_PEAK_GBS, 5)},
         "composite_evals_per_s": round(evals * B / (mean_ms[4] * 1e-3), 1) if mean_ms[4] > 0 else None,
         "semantic": "separate objects-only pass" if args.separate_semantic else
-                    "fused: composited from the scene's per-tile lists (stage composite_semantic)",
+                    "fused: second accumulator in the scene's compositing walk (stage composite)",
         "raster_only_views_per_s": round(raster_only_fps, 2) if raster_only_fps else None,
         "N": N, "V": round(V), "I": round(I), "P": P,
     }

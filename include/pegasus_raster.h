@@ -156,14 +156,14 @@ int32_t pgr_batch_status(const void *host_scratch, int32_t n_views, int64_t *num
 /* Profiling twin of pgr_forward_batch (bench / rocprof only): records HIP events on `stream` at the
  * stage boundaries (each stage runs for all views before the next starts), synchronises, and writes the
  * elapsed milliseconds of each stage for the whole batch to stage_ms[PGR_NUM_STAGES] in PgrStage order. */
-#define PGR_NUM_STAGES 6
+#define PGR_NUM_STAGES 5
 typedef enum PgrStage {
     PGR_STAGE_PREPROCESS = 0,  /* camera pack + per-Gaussian projection / EWA / SH */
     PGR_STAGE_BIN_COUNT = 1,   /* per-chunk tile histograms, slice reservation, tile scan */
     PGR_STAGE_BIN_SCATTER = 2, /* (depth, index) pairs into the tiles' slices */
     PGR_STAGE_TILE_SORT = 3,   /* work order + per-tile (depth, index) sort */
-    PGR_STAGE_COMPOSITE = 4,   /* front-to-back alpha compositing of all views */
-    PGR_STAGE_SEMANTIC = 5     /* fused objects-only semantic compositing (0 when not requested) */
+    PGR_STAGE_COMPOSITE = 4    /* front-to-back alpha compositing of all views; with a PgrSemantic the same
+                                  walk also accumulates the objects-only semantic image */
 } PgrStage;
 int32_t pgr_forward_batch_profiled(const PgrScene *scene, const PgrSemantic *semantic, int32_t n_views,
                                    const PgrCamera *cameras, const PgrOutputs *outs, void *workspace,

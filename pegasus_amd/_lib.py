@@ -15,8 +15,8 @@ PGR_ERR_INVALID_ARGUMENT = -1
 PGR_ERR_WORKSPACE_TOO_SMALL = -2
 PGR_ERR_INSTANCE_OVERFLOW = -3
 PGR_ERR_LAUNCH_FAILURE = -4
-PGR_NUM_STAGES = 6
-STAGE_NAMES = ("preprocess", "bin_count", "bin_scatter", "tile_sort", "composite", "composite_semantic")
+PGR_NUM_STAGES = 5
+STAGE_NAMES = ("preprocess", "bin_count", "bin_scatter", "tile_sort", "composite")
 
 
 class PgrScene(C.Structure):

@@ -56,7 +56,6 @@ static Layout make_layout(int32_t n, int32_t width, int32_t height, int64_t max_
     L.bucket = take(I * 8);
     L.alt = take(I * 8);
     L.gauss_sorted = take(I * 4);
-    L.obj_sorted = take(I * 4);
     L.total = off;
     return L;
 }
@@ -85,8 +84,7 @@ struct ViewWs {
     uint2* bucket;
     uint64_t* alt;
     uint32_t* gauss_sorted;
-    uint32_t* obj_sorted;
-    uint2* obj_ranges;   // batch header
+    uint32_t* obj_last;   // batch header
 };
 
 static ViewWs carve(char* ws, const Layout& L) {
@@ -103,22 +101,21 @@ static ViewWs carve(char* ws, const Layout& L) {
     v.bucket = reinterpret_cast<uint2*>(ws + L.bucket);
     v.alt = reinterpret_cast<uint64_t*>(ws + L.alt);
     v.gauss_sorted = reinterpret_cast<uint32_t*>(ws + L.gauss_sorted);
-    v.obj_sorted = reinterpret_cast<uint32_t*>(ws + L.obj_sorted);
-    v.obj_ranges = nullptr;
+    v.obj_last = nullptr;
     return v;
 }
 
 // Batch header placed in front of the per-view slices.
 struct BatchLayout {
-    size_t tables, cams, status, tile_counts, order_state, work_order, sem_order_state, sem_work_order, long_list, views, total;
-    size_t view_table_off, sem_table_off, bin_table_off, pre_table_off, tables_bytes;   // inside `tables` (one H2D copy)
+    size_t tables, cams, status, tile_counts, order_state, work_order, long_list, views, total;
+    size_t view_table_off, bin_table_off, pre_table_off, tables_bytes;   // inside `tables` (one H2D copy)
     size_t order_slots;
     size_t per_view;
 };
 
 // Host-side image of the tables + the status words read back, laid out exactly as on the device.
 static size_t host_scratch_bytes(int n_views) {
-    return 2 * align_up((size_t)n_views * sizeof(ViewEntry), 16) + align_up((size_t)n_views * sizeof(BinView), 16) +
+    return align_up((size_t)n_views * sizeof(ViewEntry), 16) + align_up((size_t)n_views * sizeof(BinView), 16) +
            align_up((size_t)n_views * sizeof(PreOut), 16) + (size_t)n_views * 8;
 }
 
@@ -127,20 +124,17 @@ static BatchLayout make_batch_layout(const Layout& L, int n_views) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes ? bytes : 1); return o; };
     B.view_table_off = 0;
-    B.sem_table_off = B.view_table_off + align_up((size_t)n_views * sizeof(ViewEntry), 16);
-    B.bin_table_off = B.sem_table_off + align_up((size_t)n_views * sizeof(ViewEntry), 16);
+    B.bin_table_off = B.view_table_off + align_up((size_t)n_views * sizeof(ViewEntry), 16);
     B.pre_table_off = B.bin_table_off + align_up((size_t)n_views * sizeof(BinView), 16);
     B.tables_bytes = B.pre_table_off + align_up((size_t)n_views * sizeof(PreOut), 16);
     B.tables = take(B.tables_bytes);
     B.cams = take((size_t)n_views * sizeof(CameraDev));
     B.status = take((size_t)n_views * 8);          // per view: [0] listed instances, [1] overflow flag
-    B.tile_counts = take((size_t)n_views * L.tiles * 12);  // [tile_count u32 | obj_ranges uint2] x views: one memset
+    B.tile_counts = take((size_t)n_views * L.tiles * 8);   // [tile_count u32 | obj_last u32] x views: one memset
     B.order_state = take(ORDER_STATE_WORDS * 4);
     // NUM_XCD interleaved streams; each holds the items of its band of tile rows for every view
     B.order_slots = (size_t)NUM_XCD * max_band_rows(L.grid_y) * L.grid_x * ITEMS_PER_TILE * n_views;
     B.work_order = take(B.order_slots * 4);
-    B.sem_order_state = take(ORDER_STATE_WORDS * 4);
-    B.sem_work_order = take(B.order_slots * 4);
     B.long_list = take((size_t)n_views * L.tiles * 4);
     B.views = off;
     B.per_view = align_up(L.total);
@@ -208,7 +202,6 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     if (workspace_bytes < B.total) return PGR_ERR_WORKSPACE_TOO_SMALL;
     char* ws = static_cast<char*>(workspace);
     auto* view_table = reinterpret_cast<ViewEntry*>(ws + B.tables + B.view_table_off);
-    auto* sem_table = reinterpret_cast<ViewEntry*>(ws + B.tables + B.sem_table_off);
     auto* bin_table = reinterpret_cast<BinView*>(ws + B.tables + B.bin_table_off);
     auto* pre_table = reinterpret_cast<PreOut*>(ws + B.tables + B.pre_table_off);
     auto* cams_dev = reinterpret_cast<CameraDev*>(ws + B.cams);
@@ -224,7 +217,6 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         hs = pageable.data();
     }
     auto* table = reinterpret_cast<ViewEntry*>(hs + B.view_table_off);
-    auto* stable = reinterpret_cast<ViewEntry*>(hs + B.sem_table_off);
     auto* bins = reinterpret_cast<BinView*>(hs + B.bin_table_off);
     auto* pres = reinterpret_cast<PreOut*>(hs + B.pre_table_off);
     auto* h_status = reinterpret_cast<uint32_t*>(hs + B.tables_bytes);
@@ -234,23 +226,21 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         vw[v].cam = cams_dev + v;          // cameras of a batch are contiguous: preprocess walks them
         vw[v].counters = status_dev + 2 * v;   // and so are the status words: one D2H copy per batch
         vw[v].tile_count = reinterpret_cast<uint32_t*>(ws + B.tile_counts) + (size_t)v * L.tiles;
-        vw[v].obj_ranges = reinterpret_cast<uint2*>(ws + B.tile_counts + (size_t)n_views * L.tiles * 4) + (size_t)v * L.tiles;
+        vw[v].obj_last = reinterpret_cast<uint32_t*>(ws + B.tile_counts + (size_t)n_views * L.tiles * 4) + (size_t)v * L.tiles;
         ViewEntry& e = table[v];
         memset(&e, 0, sizeof(e));
         e.cam = vw[v].cam; e.ranges = vw[v].ranges; e.gauss_sorted = vw[v].gauss_sorted; e.splats = vw[v].splats;
         e.out = CompOut{outs[v].color, outs[v].depth, outs[v].final_T, outs[v].n_contrib};
         e.counters = vw[v].counters;
-        // the semantic launch sees the same view through its OBJECT lists and writes the semantic outputs
-        ViewEntry& se = stable[v];
-        se = e;
-        se.ranges = vw[v].obj_ranges;
-        se.gauss_sorted = vw[v].obj_sorted;
-        se.out = CompOut{semantic ? outs[v].sem_color : nullptr, semantic ? outs[v].sem_depth : nullptr, nullptr, nullptr};
-        want_sem = want_sem || (semantic && outs[v].sem_color);
+        // fused semantic pass: the same walk also accumulates the objects-only image
+        e.sem_color = semantic ? outs[v].sem_color : nullptr;
+        e.sem_depth = semantic ? outs[v].sem_depth : nullptr;
+        e.obj_last = vw[v].obj_last;
+        want_sem = want_sem || e.sem_color;
         want_aux = want_aux || outs[v].final_T || outs[v].n_contrib;
         bins[v] = BinView{vw[v].crects, vw[v].splats, vw[v].tile_count, vw[v].rel, vw[v].ranges,
-                          vw[v].counters, vw[v].bucket, vw[v].gauss_sorted, vw[v].alt, vw[v].obj_sorted,
-                          vw[v].obj_ranges, semantic ? semantic->n_env : -1};
+                          vw[v].counters, vw[v].bucket, vw[v].gauss_sorted, vw[v].alt, vw[v].obj_last,
+                          semantic ? semantic->n_env : -1};
         // radii is part of the per-view contract; when the caller does not want it, it lands in the workspace
         pres[v] = PreOut{vw[v].splats, vw[v].rects, vw[v].crects,
                          outs[v].radii ? outs[v].radii : vw[v].radii};
@@ -281,7 +271,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     // ---- stage 1: per-chunk LDS tile histograms + slice reservation, then the tile scan (device only)
     const int grid_x = (W + TILE - 1) / TILE;
     const size_t lds = (size_t)std::min(L.tiles, BIN_LDS_TILES) * 4;
-    if (!hip_ok(hipMemsetAsync(ws + B.tile_counts, 0, (size_t)n_views * L.tiles * 12, stream), "memset tile counts"))
+    if (!hip_ok(hipMemsetAsync(ws + B.tile_counts, 0, (size_t)n_views * L.tiles * 8, stream), "memset tile counts"))
         return PGR_ERR_LAUNCH_FAILURE;
     bin_kernel<false><<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(bin_table, N, grid_x, L.tiles, W, H);
     tile_scan_kernel<<<n_views, 1024, 0, stream>>>(bin_table, L.tiles, (uint32_t)max_instances);
@@ -305,32 +295,25 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         bin_table, L.tiles, long_list, n_long);
     tile_sort_kernel<<<n_views * L.tiles, SORT_THREADS, 0, stream>>>(bin_table, L.tiles);
     mark(4);
-    // ---- stage 4: compositing of every (view, tile, half) work item in ONE launch
+    // ---- stage 4: compositing of every (view, tile, quarter) work item in ONE launch; with `semantic` the same
+    // walk also produces the objects-only semantic image
     const uint32_t items_per_view = ITEMS_PER_TILE * (uint32_t)L.tiles;
     const uint32_t slots = (uint32_t)B.order_slots;
-    const SemanticDev no_sem{nullptr, nullptr, 0, 0};
-    if (want_aux)
-        launch_composite<true, false>(slots, stream, view_table, items_per_view, work_order, no_sem);
-    else
-        launch_composite<false, false>(slots, stream, view_table, items_per_view, work_order, no_sem);
-    mark(5);
+    SemanticDev sd{nullptr, nullptr, 0, 0};
     if (want_sem) {
         if (!semantic->object_id || !semantic->colors || semantic->n_env < 0 || semantic->k_objects <= 0)
             return PGR_ERR_INVALID_ARGUMENT;
-        const SemanticDev sd{semantic->object_id, semantic->colors, semantic->n_env, semantic->k_objects};
-        // its own work order: the object lists' lengths have little to do with the scene lists'
-        auto* sem_state = reinterpret_cast<uint32_t*>(ws + B.sem_order_state);
-        auto* sem_order = reinterpret_cast<uint32_t*>(ws + B.sem_work_order);
-        if (!hip_ok(hipMemsetAsync(sem_state, 0, ORDER_STATE_WORDS * 4, stream), "memset sem order state") ||
-            !hip_ok(hipMemsetAsync(sem_order, 0xff, B.order_slots * 4, stream), "memset sem work order"))
-            return PGR_ERR_LAUNCH_FAILURE;
-        order_count_kernel<<<og, 256, 0, stream>>>(sem_table, L.tiles, L.grid_x, sem_state);
-        order_scan_kernel<<<1, 64, 0, stream>>>(sem_state);
-        order_scatter_kernel<<<og, 256, 0, stream>>>(sem_table, L.tiles, L.grid_x, sem_state, sem_order, 0xffffffffu,
-                                                     long_list);
-        launch_composite<false, true>(slots, stream, sem_table, items_per_view, sem_order, sd);
+        sd = SemanticDev{semantic->object_id, semantic->colors, semantic->n_env, semantic->k_objects};
     }
-    mark(6);
+    if (want_aux && want_sem)
+        launch_composite<true, true>(slots, stream, view_table, items_per_view, work_order, sd);
+    else if (want_aux)
+        launch_composite<true, false>(slots, stream, view_table, items_per_view, work_order, sd);
+    else if (want_sem)
+        launch_composite<false, true>(slots, stream, view_table, items_per_view, work_order, sd);
+    else
+        launch_composite<false, false>(slots, stream, view_table, items_per_view, work_order, sd);
+    mark(5);
     if (!hip_ok(hipGetLastError(), "kernel launch")) return PGR_ERR_LAUNCH_FAILURE;
 
     // the only host read of the batch: instance counts + overflow flags, after everything is enqueued

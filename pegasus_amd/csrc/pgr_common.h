@@ -35,7 +35,7 @@ static_assert(sizeof(CameraDev) == 256, "CameraDev must be 256 B");
 // Workspace carve-up (all offsets multiples of 256 B).
 struct Layout {
     size_t cam, counters, splats, radii, rects, crects, rel, ranges, bucket, alt,
-        gauss_sorted, obj_sorted, total;
+        gauss_sorted, total;
     int32_t tiles, grid_x, grid_y;
     int32_t n_blocks;
     int32_t n_chunks;

@@ -46,9 +46,8 @@ struct BinView {                 // per-view pointers used by the binning kernel
     uint2* bucket;               // [max_instances] (depth bits, index), unsorted per tile
     uint32_t* gauss_sorted;      // [max_instances]
     uint64_t* alt;               // [max_instances] second key buffer for lists beyond the LDS tiers
-    uint32_t* obj_sorted;        // [max_instances] the sorted list with environment entries removed (same offsets)
-    uint2* obj_ranges;           // [tiles] zero-filled; [start, start + #objects) into obj_sorted
-    int32_t n_env;               // Gaussians < n_env are environment; < 0: no object lists wanted
+    uint32_t* obj_last;          // [tiles] zero-filled; 1 + position of the last object entry of the sorted list
+    int32_t n_env;               // Gaussians < n_env are environment; < 0: no semantic pass wanted
 };
 
 
@@ -221,33 +220,17 @@ __device__ __forceinline__ int pad_idx(int i) {
     return i + i / E;   // E is a power of two: a shift
 }
 
-// Ordered compaction of the entries with index >= n_env (the objects) of a sorted list into obj_out, for the
-// fused semantic pass: an objects-only cloud's per-tile list is the scene's list minus the environment.
-// `get(i)` returns the i-th sorted index.  Returns (to every thread) the number of object entries.
+// Fused semantic pass support: *obj_last = 1 + position of the LAST entry with index >= n_env (an object's Gaussian)
+// in the tile's sorted list, 0 if there is none (the word is zero-filled per batch).  The compositor walks a tile's
+// list beyond the saturation of its scene pixels only up to there.  `get(i)` returns the i-th sorted index.
 template <int THREADS, typename Get>
-__device__ __forceinline__ uint32_t compact_objects(Get get, int n, int n_env, uint32_t* __restrict__ obj_out) {
-    __shared__ uint32_t wave_cnt[THREADS / WAVE];
-    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-    uint32_t base = 0;
-    for (int c0 = 0; c0 < n; c0 += THREADS) {
-        const int i = c0 + (int)threadIdx.x;
-        const uint32_t idx = i < n ? get(i) : 0u;
-        const bool is_obj = i < n && (int)idx >= n_env;
-        const unsigned long long m = __ballot(is_obj);
-        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        uint32_t before = 0, total = 0;
+__device__ __forceinline__ void mark_last_object(Get get, int n, int n_env, uint32_t* __restrict__ obj_last) {
+    uint32_t best = 0;
+    for (int i = threadIdx.x; i < n; i += THREADS)
+        if ((int)get(i) >= n_env) best = (uint32_t)i + 1u;
 #pragma unroll
-        for (int w = 0; w < THREADS / WAVE; ++w) {
-            const uint32_t c = wave_cnt[w];
-            before += w < wave ? c : 0u;
-            total += c;
-        }
-        if (is_obj) obj_out[base + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = idx;
-        base += total;
-        __syncthreads();
-    }
-    return base;
+    for (int m = 1; m < WAVE; m <<= 1) best = max(best, (uint32_t)__shfl_xor((int)best, m));
+    if ((threadIdx.x & (WAVE - 1)) == 0 && best) atomicMax(obj_last, best);
 }
 
 // Sorts n <= THREADS*E keys of `bucket` (global, (depth,idx) pairs) into out[] (indices only).
@@ -255,8 +238,7 @@ __device__ __forceinline__ uint32_t compact_objects(Get get, int n, int n_env, u
 template <int THREADS, int E>
 __device__ __forceinline__ void merge_sort_tile(uint64_t* __restrict__ skeys, const uint2* __restrict__ bucket,
                                                 uint32_t* __restrict__ out, int n, uint64_t* keys_out = nullptr,
-                                                int n_env = -1, uint32_t* __restrict__ obj_out = nullptr,
-                                                uint2* __restrict__ obj_range = nullptr, uint32_t range_start = 0) {
+                                                int n_env = -1, uint32_t* __restrict__ obj_last = nullptr) {
     const int t = threadIdx.x;
     uint64_t r[E];
     // the list is unordered, so WHICH keys a thread starts with is free: take them coalesced
@@ -307,11 +289,7 @@ __device__ __forceinline__ void merge_sort_tile(uint64_t* __restrict__ skeys, co
         for (int i = t; i < n; i += THREADS) keys_out[i] = skeys[pad_idx<E>(i)];
     } else {
         for (int i = t; i < n; i += THREADS) out[i] = (uint32_t)skeys[pad_idx<E>(i)];
-        if (n_env >= 0) {
-            const uint32_t cnt = compact_objects<THREADS>([&](int i) { return (uint32_t)skeys[pad_idx<E>(i)]; }, n, n_env,
-                                                          obj_out);
-            if (t == 0) *obj_range = make_uint2(range_start, range_start + cnt);
-        }
+        if (n_env >= 0) mark_last_object<THREADS>([&](int i) { return (uint32_t)skeys[pad_idx<E>(i)]; }, n, n_env, obj_last);
     }
 }
 
@@ -356,8 +334,7 @@ constexpr uint32_t BUCKET_SQ_LIMIT = 8;
 template <int THREADS, int E>
 __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds, const uint2* __restrict__ bucket,
                                                  uint32_t* __restrict__ out, int n, int n_env,
-                                                 uint32_t* __restrict__ obj_out, uint2* __restrict__ obj_range,
-                                                 uint32_t range_start) {
+                                                 uint32_t* __restrict__ obj_last) {
     constexpr int NB = THREADS * E, WAVES = THREADS / WAVE;
     uint64_t* s_keys = reinterpret_cast<uint64_t*>(lds);                       // [NB]
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(lds + (size_t)NB * 8);      // [NB], later the sorted indices
@@ -457,10 +434,7 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
         if (e * THREADS + t < n) s_idx[fin[e]] = id[e];
     __syncthreads();
     for (int i = t; i < n; i += THREADS) out[i] = s_idx[i];
-    if (n_env >= 0) {
-        const uint32_t cnt = compact_objects<THREADS>([&](int i) { return s_idx[i]; }, n, n_env, obj_out);
-        if (t == 0) *obj_range = make_uint2(range_start, range_start + cnt);
-    }
+    if (n_env >= 0) mark_last_object<THREADS>([&](int i) { return s_idx[i]; }, n, n_env, obj_last);
     return true;
 }
 
@@ -496,7 +470,7 @@ __device__ __forceinline__ void merge_round_global(const uint64_t* __restrict__ 
 constexpr int SORT_SMALL_MAX = SORT_THREADS * 16;      // 4096 keys, 32 KiB LDS
 
 // item = view * tiles + tile
-struct ObjOut { int n_env; uint32_t* sorted; uint2* range; uint32_t start; };
+struct ObjOut { int n_env; uint32_t* last; };
 
 __device__ __forceinline__ bool sort_item(const BinView* __restrict__ views, int tiles, uint32_t item,
                                           const uint2*& bucket, uint32_t*& out, int& n, ObjOut& oo,
@@ -509,7 +483,7 @@ __device__ __forceinline__ bool sort_item(const BinView* __restrict__ views, int
     n = (int)(range.y - range.x);
     bucket = bv.bucket + range.x;
     out = bv.gauss_sorted + range.x;
-    oo = ObjOut{bv.n_env, bv.obj_sorted + range.x, bv.obj_ranges + tile, range.x};
+    oo = ObjOut{bv.n_env, bv.obj_last + tile};
     if (alt) *alt = bv.alt + range.x;
     return n > 0;
 }
@@ -522,17 +496,17 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* 
     if (!sort_item(views, tiles, blockIdx.x, bucket, out, n, oo)) return;
     if (n > SORT_SMALL_MAX) return;                      // the long tiers'
     if (n <= SORT_THREADS * 2) {
-        if (!bucket_sort_tile<SORT_THREADS, 2>(lds, bucket, out, n, oo.n_env, oo.sorted, oo.range, oo.start))
-            merge_sort_tile<SORT_THREADS, 2>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
+        if (!bucket_sort_tile<SORT_THREADS, 2>(lds, bucket, out, n, oo.n_env, oo.last))
+            merge_sort_tile<SORT_THREADS, 2>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last);
     } else if (n <= SORT_THREADS * 4) {
-        if (!bucket_sort_tile<SORT_THREADS, 4>(lds, bucket, out, n, oo.n_env, oo.sorted, oo.range, oo.start))
-            merge_sort_tile<SORT_THREADS, 4>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
+        if (!bucket_sort_tile<SORT_THREADS, 4>(lds, bucket, out, n, oo.n_env, oo.last))
+            merge_sort_tile<SORT_THREADS, 4>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last);
     } else if (n <= SORT_THREADS * 8) {
-        if (!bucket_sort_tile<SORT_THREADS, 8>(lds, bucket, out, n, oo.n_env, oo.sorted, oo.range, oo.start))
-            merge_sort_tile<SORT_THREADS, 8>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
+        if (!bucket_sort_tile<SORT_THREADS, 8>(lds, bucket, out, n, oo.n_env, oo.last))
+            merge_sort_tile<SORT_THREADS, 8>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last);
     } else {
-        if (!bucket_sort_tile<SORT_THREADS, 16>(lds, bucket, out, n, oo.n_env, oo.sorted, oo.range, oo.start))
-            merge_sort_tile<SORT_THREADS, 16>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
+        if (!bucket_sort_tile<SORT_THREADS, 16>(lds, bucket, out, n, oo.n_env, oo.last))
+            merge_sort_tile<SORT_THREADS, 16>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last);
     }
 }
 
@@ -563,9 +537,9 @@ __global__ __launch_bounds__(THREADS) void tile_sort_long_kernel(const BinView* 
             if (n <= CAP) {
                 bool sorted = false;
                 if constexpr (THREADS == SORT_MEDIUM_THREADS)
-                    sorted = bucket_sort_tile<THREADS, 16>(lds, bucket, out, n, oo.n_env, oo.sorted, oo.range, oo.start);
+                    sorted = bucket_sort_tile<THREADS, 16>(lds, bucket, out, n, oo.n_env, oo.last);
                 if (!sorted)
-                    merge_sort_tile<THREADS, 16>(skeys, bucket, out, n, nullptr, oo.n_env, oo.sorted, oo.range, oo.start);
+                    merge_sort_tile<THREADS, 16>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last);
             } else {
                 uint64_t* gk = reinterpret_cast<uint64_t*>(const_cast<uint2*>(bucket));
                 for (int c0 = 0; c0 < n; c0 += CAP) {
@@ -579,12 +553,7 @@ __global__ __launch_bounds__(THREADS) void tile_sort_long_kernel(const BinView* 
                     uint64_t* tmp = src; src = dst; dst = tmp;
                 }
                 for (int i = threadIdx.x; i < n; i += THREADS) out[i] = (uint32_t)src[i];
-                if (oo.n_env >= 0) {
-                    __syncthreads();
-                    const uint32_t cnt = compact_objects<THREADS>([&](int i) { return (uint32_t)src[i]; }, n, oo.n_env,
-                                                                  oo.sorted);
-                    if (threadIdx.x == 0) *oo.range = make_uint2(oo.start, oo.start + cnt);
-                }
+                if (oo.n_env >= 0) mark_last_object<THREADS>([&](int i) { return (uint32_t)src[i]; }, n, oo.n_env, oo.last);
             }
         }
         __syncthreads();   // skeys reuse across loop iterations
