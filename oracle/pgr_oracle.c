@@ -110,7 +110,7 @@ static void sh_basis(int deg, float x, float y, float z, float b[16])
  * A (Gaussian, tile) instance only matters if alpha = min(0.99, op*exp(power)) >= 1/255 at some pixel of
  * the tile.  With q = A dx^2 + 2B dx dy + C dy^2 (power = -q/2) that needs q <= 2 ln(255 op) somewhere.
  * The test below bounds q from BELOW over the continuous pixel rectangle of the tile (exact minimum of the
- * convex form: 0 if the centre is inside, else the smallest of the four edge minima) and 2 ln(255 op) from
+ * convex form: 0 if the centre is inside, else the smaller of the minima over the two edges facing the centre) and 2 ln(255 op) from
  * ABOVE (exponent + chord of log2 on the mantissa + 0.0861), adds a rounding margin, and keeps the instance
  * unless the lower bound clears the upper bound.  Dropped instances would have been skipped at every pixel,
  * so every pixel's arithmetic is unchanged.  No transcendental: identical bits on CPU and GPU. */
@@ -134,10 +134,11 @@ int pgr_oracle_tile_may_contribute(const float xy[2], const float co[4], int32_t
     if (mx >= x0 && mx <= x1 && my >= y0 && my <= y1) return 1;
     const float dx0 = x0 - mx, dx1 = x1 - mx, dy0 = y0 - my, dy1 = y1 - my;
     const float rBC = B / C, rBA = B / A;
-    float q = edge_min_q(A, B, C, rBC, dx0, dy0, dy1);
-    q = fminf(q, edge_min_q(A, B, C, rBC, dx1, dy0, dy1));
-    q = fminf(q, edge_min_q(C, B, A, rBA, dy0, dx0, dx1));
-    q = fminf(q, edge_min_q(C, B, A, rBA, dy1, dx0, dx1));
+    /* q grows along every ray from the centre, so its minimum over the rectangle lies on an edge FACING the centre:
+     * the vertical edge on the centre's side in x and the horizontal one on its side in y (when the centre is inside
+     * the rectangle's x- or y-range that axis has no facing edge; the edge taken then only adds a larger candidate) */
+    const float dxn = mx < x0 ? dx0 : dx1, dyn = my < y0 ? dy0 : dy1;
+    const float q = fminf(edge_min_q(A, B, C, rBC, dxn, dy0, dy1), edge_min_q(C, B, A, rBA, dyn, dx0, dx1));
     /* upper bound of 2 ln(255 op): 255 op = m 2^e, log2 m <= (m-1) + 0.0861 */
     const float t = 255.0f * op;
     const uint32_t bits = float_to_bits(t);

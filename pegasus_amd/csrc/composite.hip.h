@@ -225,10 +225,10 @@ __global__ __launch_bounds__(WAVE) PGR_COMP_OCC void composite_quarter_kernel(co
                 const float alpha = fminf(ALPHA_MAX, u ? araw.y : araw.x);
                 // power <= 0 and alpha >= 1/255: the entry counts for this pixel (in either image)
                 const unsigned long long hit = m_pw[u] & __builtin_amdgcn_ballot_w64(!(alpha < ALPHA_MIN));
-                if (!FUSED || alive != 0ull) {
+                // (scalar branch) about a fifth of the parked entries reach no pixel that is still alive
+                if (const unsigned long long valid = alive & hit; valid != 0ull) {
                     const float4 c = s_c[2 * k + u];
                     const float test_T = fmaf(-alpha, T, T);
-                    const unsigned long long valid = alive & hit;
                     const unsigned long long stop = valid & __builtin_amdgcn_ballot_w64(test_T < T_EPS);
                     alive &= ~stop;
                     const unsigned long long blend = valid & ~stop;
@@ -246,14 +246,13 @@ __global__ __launch_bounds__(WAVE) PGR_COMP_OCC void composite_quarter_kernel(co
                 }
                 if (FUSED) {
                     // wave-uniform (scalar) test: is this entry an object's?
-                    if ((objbits >> (2 * k + u)) & 1ull) {
+                    if (const unsigned long long valid = sem_alive & hit; ((objbits >> (2 * k + u)) & 1ull) && valid != 0ull) {
                         const float4 sc = s_s[2 * k + u];
                         const float depth = s_c[2 * k + u].w;
 #ifdef PGR_COMP_STATS
                         st_sem++;
 #endif
                         const float test_T = fmaf(-alpha, Ts, Ts);
-                        const unsigned long long valid = sem_alive & hit;
                         const unsigned long long stop = valid & __builtin_amdgcn_ballot_w64(test_T < T_EPS);
                         sem_alive &= ~stop;
                         const bool bl = __builtin_amdgcn_inverse_ballot_w64(valid & ~stop);

@@ -11,7 +11,7 @@ namespace pgr {
 // A (Gaussian, tile) instance only matters if alpha = min(0.99, op*exp(power)) >= 1/255 at some pixel of the
 // tile.  With q = A dx^2 + 2B dx dy + C dy^2 (power = -q/2) that needs q <= 2 ln(255 op) somewhere.  The
 // test bounds q from BELOW over the tile's continuous pixel rectangle (0 if the centre is inside, else the
-// smallest of the four edge minima of the convex form) and 2 ln(255 op) from ABOVE (exponent + chord of
+// smaller of the minima over the two edges facing the centre) and 2 ln(255 op) from ABOVE (exponent + chord of
 // log2 on the mantissa + 0.0861), adds a rounding margin, and keeps the instance unless the lower bound
 // clears the upper bound.  Dropped instances would be skipped at every pixel, so no pixel's arithmetic
 // changes (oracle: pgr_oracle_tile_may_contribute, same operation order, bit-identical decisions; measured
@@ -46,10 +46,10 @@ __device__ __forceinline__ bool rect_may_contribute(const CullSplat& s, float x0
     if (s.flags & 2u) return true;
     if (s.mx >= x0 && s.mx <= x1 && s.my >= y0 && s.my <= y1) return true;
     const float dx0 = x0 - s.mx, dx1 = x1 - s.mx, dy0 = y0 - s.my, dy1 = y1 - s.my;
-    float q = edge_min_q(s.A, s.B, s.C, s.rBC, dx0, dy0, dy1);
-    q = fminf(q, edge_min_q(s.A, s.B, s.C, s.rBC, dx1, dy0, dy1));
-    q = fminf(q, edge_min_q(s.C, s.B, s.A, s.rBA, dy0, dx0, dx1));
-    q = fminf(q, edge_min_q(s.C, s.B, s.A, s.rBA, dy1, dx0, dx1));
+    // q grows along every ray from the centre: its minimum over the rectangle lies on an edge FACING the centre
+    // (an axis whose range contains the centre has no facing edge; the one taken then only adds a larger candidate)
+    const float dxn = s.mx < x0 ? dx0 : dx1, dyn = s.my < y0 ? dy0 : dy1;
+    const float q = fminf(edge_min_q(s.A, s.B, s.C, s.rBC, dxn, dy0, dy1), edge_min_q(s.C, s.B, s.A, s.rBA, dyn, dx0, dx1));
     const float DX = fmaxf(fabsf(dx0), fabsf(dx1)), DY = fmaxf(fabsf(dy0), fabsf(dy1));
     const float M = s.A * DX * DX + 2.0f * fabsf(s.B) * DX * DY + s.C * DY * DY;
     return !(q > s.tau + 0.00001f * M + 0.01f);       // a NaN anywhere keeps the instance

@@ -270,7 +270,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     mark(1);
     // ---- stage 1: per-chunk LDS tile histograms + slice reservation, then the tile scan (device only)
     const int grid_x = (W + TILE - 1) / TILE;
-    const size_t lds = (size_t)std::min(L.tiles, BIN_LDS_TILES) * 4;
+    const size_t lds = bin_lds_bytes(L.tiles);
     if (!hip_ok(hipMemsetAsync(ws + B.tile_counts, 0, (size_t)n_views * L.tiles * 8, stream), "memset tile counts"))
         return PGR_ERR_LAUNCH_FAILURE;
     bin_kernel<false><<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(bin_table, N, grid_x, L.tiles, W, H);

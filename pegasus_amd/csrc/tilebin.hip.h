@@ -51,23 +51,73 @@ struct BinView {                 // per-view pointers used by the binning kernel
 };
 
 
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v, int ctrl, int row_mask, bool bound) {
+    switch (ctrl) {   // the builtin wants immediates
+        case 0x111: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x111, 0xF, 0xF, true);
+        case 0x112: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x112, 0xF, 0xF, true);
+        case 0x114: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x114, 0xF, 0xF, true);
+        case 0x118: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x118, 0xF, 0xF, true);
+        case 0x142: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x142, 0xA, 0xF, false);
+        default:    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x143, 0xC, 0xF, false);
+    }
+}
+
+// inclusive prefix sum over the 64 lanes of a wave (row shifts, then the two row broadcasts of gfx9)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    v += dpp_u32(0, v, 0x111, 0xF, true);   // row_shr:1
+    v += dpp_u32(0, v, 0x112, 0xF, true);   // row_shr:2
+    v += dpp_u32(0, v, 0x114, 0xF, true);   // row_shr:4
+    v += dpp_u32(0, v, 0x118, 0xF, true);   // row_shr:8
+    v += dpp_u32(0, v, 0x142, 0xA, false);  // row_bcast:15 -> rows 1, 3
+    v += dpp_u32(0, v, 0x143, 0xC, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// inclusive prefix MAX over the 64 lanes (0 is the identity: out-of-row DPP reads return 0)
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v) {
+    v = max(v, dpp_u32(0, v, 0x111, 0xF, true));
+    v = max(v, dpp_u32(0, v, 0x112, 0xF, true));
+    v = max(v, dpp_u32(0, v, 0x114, 0xF, true));
+    v = max(v, dpp_u32(0, v, 0x118, 0xF, true));
+    v = max(v, dpp_u32(0, v, 0x142, 0xA, false));
+    v = max(v, dpp_u32(0, v, 0x143, 0xC, false));
+    return v;
+}
+
 // Both binning passes walk the same candidate space: every tile of every Gaussian's rectangle.  Rectangle
 // areas vary from 1 to hundreds of tiles, so a loop per Gaussian leaves most lanes idle (measured 6x on
-// MI355X).  Instead each wave takes 64 Gaussians, prefix-sums their areas, and its lanes sweep the
-// FLATTENED candidate index space 64 at a time: lane -> candidate c -> owning Gaussian g (binary search
-// over the wave's exclusive prefix with ds_bpermute) -> tile (x,y) of g's rectangle.  Every lane evaluates
-// exactly one candidate per iteration.
+// MI355X).  Instead each wave takes 64 Gaussians, prefix-sums their areas (DPP scan), and its lanes sweep the
+// FLATTENED candidate index space 64 at a time; every lane evaluates exactly one candidate per iteration.
+//   candidate c -> owning Gaussian: every owner whose segment starts inside the 64-candidate window drops a head
+//     flag (position << 6 | lane) at its start; a DPP prefix-max hands every candidate the last head at or before
+//     it (candidates before the first head continue the previous window's owner).  ~14 VALU per iteration where a
+//     binary search over the prefix with ds_bpermute took 6 LDS round trips.
+//   owner's data (cull record, rectangle, depth bits): parked once per 64 Gaussians in a per-wave LDS table of
+//     three float4 and fetched with three ds_read_b128 -- not 12 ds_bpermute per iteration.
+//   tile inside the rectangle: k / w by a reciprocal multiply with an exact +-1 correction, no integer division.
+// The binning kernels were VALU-bound (SQ_ACTIVE_INST_VALU ~ duration): these three cut the instruction count per
+// iteration from ~180 to ~85.
 //   SCATTER = false: lds[] = tile histogram; flushed with one coalesced reserving atomic per touched tile.
 //   SCATTER = true : lds[] = write cursors (range start + this chunk's reserved offset).
+constexpr int BIN_WAVES = BIN_THREADS / WAVE;
+constexpr int BIN_STAGE_WORDS = WAVE * 12 + WAVE;         // per wave: 64 x 3 float4 + 64 head words
+__host__ __device__ inline size_t bin_lds_bytes(int tiles) {
+    return ((size_t)(tiles < BIN_LDS_TILES ? tiles : BIN_LDS_TILES) + 3) / 4 * 16 + (size_t)BIN_WAVES * BIN_STAGE_WORDS * 4;
+}
+
 template <bool SCATTER>
 __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restrict__ views, int n, int grid_x,
                                                           int tiles, int W, int H) {
-    extern __shared__ uint32_t lds[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const BinView& bv = views[blockIdx.y];
     if (SCATTER && bv.counters[1]) return;   // overflow: reported by the host, nothing may be written past the buffers
     const int chunk = blockIdx.x;
     const int begin = chunk * BIN_CHUNK, end = min(n, begin + BIN_CHUNK);
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const int hist_words = (min(tiles, BIN_LDS_TILES) + 3) / 4 * 4;
+    float4* const stage = reinterpret_cast<float4*>(lds + hist_words + wave * BIN_STAGE_WORDS);   // [64][3]
+    // volatile: lanes talk to each other through this array inside one wave (DS operations of a wave are ordered)
+    volatile uint32_t* const heads = reinterpret_cast<volatile uint32_t*>(stage + WAVE * 3);       // [64]
     for (int lo = 0; lo < tiles; lo += BIN_LDS_TILES) {
         const int span = min(BIN_LDS_TILES, tiles - lo);
         for (int t = threadIdx.x; t < span; t += BIN_THREADS)
@@ -75,53 +125,56 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restr
         __syncthreads();
         for (int base = begin + wave * WAVE; base < end; base += BIN_THREADS) {
             const int i = base + lane;
-            uint2 r = make_uint2(0u, 0u);
-            int area = 0;
-            CullSplat cs = {};
-            uint32_t dbits = 0;
+            uint32_t area = 0;
+            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
             if (i < end) {
-                r = bv.rects[i];
+                const uint2 r = bv.rects[i];
                 const int w = (int)(r.y & 0xffff) - (int)(r.x & 0xffff), h = (int)(r.y >> 16) - (int)(r.x >> 16);
                 if (w > 0 && h > 0) {
-                    area = w * h;
+                    area = (uint32_t)(w * h);
                     const float4 q0 = bv.splats[(size_t)i * 3], q1 = bv.splats[(size_t)i * 3 + 1];
-                    cs = make_cull_splat(make_float2(q0.x, q0.y), make_float4(q0.z, q0.w, q1.x, q1.y));
-                    if (SCATTER) dbits = __float_as_uint(bv.splats[(size_t)i * 3 + 2].y);
+                    const CullSplat cs = make_cull_splat(make_float2(q0.x, q0.y), make_float4(q0.z, q0.w, q1.x, q1.y));
+                    s0 = make_float4(cs.mx, cs.my, cs.A, cs.B);
+                    s1 = make_float4(cs.C, cs.rBC, cs.rBA, cs.tau);
+                    s2 = make_float4(__uint_as_float(cs.flags | ((uint32_t)w << 2)), __uint_as_float(r.x), 1.0f / (float)w,
+                                     SCATTER ? bv.splats[(size_t)i * 3 + 2].y : 0.0f);
                 }
             }
-            int incl = area;
-#pragma unroll
-            for (int d = 1; d < WAVE; d <<= 1) {
-                const int t = __shfl_up(incl, d, WAVE);
-                if (lane >= d) incl += t;
-            }
-            const int excl = incl - area;
-            const int total = __shfl(incl, WAVE - 1, WAVE);
-            for (int c0 = 0; c0 < total; c0 += WAVE) {
-                const int c = c0 + lane;
-                int g = 0;   // largest lane whose exclusive prefix is <= c
-#pragma unroll
-                for (int step = WAVE / 2; step >= 1; step >>= 1) {
-                    const int cand = g + step;
-                    const int e = __shfl(excl, cand & (WAVE - 1), WAVE);
-                    if (cand < WAVE && e <= c) g = cand;
-                }
-                const int k = c - __shfl(excl, g, WAVE);
-                const uint32_t rlo = __shfl(r.x, g, WAVE), rhi = __shfl(r.y, g, WAVE);
-                CullSplat s;
-                s.mx = __shfl(cs.mx, g, WAVE); s.my = __shfl(cs.my, g, WAVE);
-                s.A = __shfl(cs.A, g, WAVE); s.B = __shfl(cs.B, g, WAVE); s.C = __shfl(cs.C, g, WAVE);
-                s.rBC = __shfl(cs.rBC, g, WAVE); s.rBA = __shfl(cs.rBA, g, WAVE);
-                s.tau = __shfl(cs.tau, g, WAVE); s.flags = __shfl(cs.flags, g, WAVE);
-                const uint32_t db = SCATTER ? __shfl(dbits, g, WAVE) : 0u;
-                const int minx = (int)(rlo & 0xffff), miny = (int)(rlo >> 16);
-                const int w = max((int)(rhi & 0xffff) - minx, 1);
-                const int ty = k / w, tx = k - ty * w;
-                const int x = minx + tx, y = miny + ty;
+            stage[lane * 3 + 0] = s0; stage[lane * 3 + 1] = s1; stage[lane * 3 + 2] = s2;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t incl = wave_inclusive_scan(area);
+            const uint32_t excl = incl - area;
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+            uint32_t carry_key = 0;        // owner of the candidate just before the window: (start + 1) << 6 | lane
+            for (uint32_t c0 = 0; c0 < total; c0 += WAVE) {
+                heads[lane] = 0u;
+                if (area && excl - c0 < (uint32_t)WAVE) heads[excl - c0] = ((excl + 1u) << 6) | (uint32_t)lane;
+                uint32_t key = wave_inclusive_max(heads[lane]);     // same wave: LDS ops are ordered
+                key = key ? key : carry_key;
+                carry_key = (uint32_t)__builtin_amdgcn_readlane((int)key, WAVE - 1);
+                const uint32_t c = c0 + (uint32_t)lane;
+                const int g = (int)(key & 63u);
+                const uint32_t k = c - ((key >> 6) - 1u);
+                const float4 o2 = stage[g * 3 + 2];
+                const uint32_t fw = __float_as_uint(o2.x), rlo = __float_as_uint(o2.y);
+                const int w = (int)(fw >> 2);
+                // ty = k / w: reciprocal estimate, then an exact +-1 correction
+                int ty = (int)(((float)k + 0.5f) * o2.z);
+                int tx = (int)k - ty * w;
+                if (tx < 0) { --ty; tx += w; } else if (tx >= w) { ++ty; tx -= w; }
+                const int x = (int)(rlo & 0xffff) + tx, y = (int)(rlo >> 16) + ty;
                 const int t = y * grid_x + x - lo;
-                if (c < total && (unsigned)t < (unsigned)span && tile_may_contribute(s, x, y, W, H)) {
+                bool pass = c < total && (unsigned)t < (unsigned)span;
+                if (pass) {
+                    const float4 o0 = stage[g * 3 + 0], o1 = stage[g * 3 + 1];
+                    CullSplat cs;
+                    cs.mx = o0.x; cs.my = o0.y; cs.A = o0.z; cs.B = o0.w;
+                    cs.C = o1.x; cs.rBC = o1.y; cs.rBA = o1.z; cs.tau = o1.w; cs.flags = fw & 3u;
+                    pass = tile_may_contribute(cs, x, y, W, H);
+                }
+                if (pass) {
                     const uint32_t slot = atomicAdd(&lds[t], 1u);
-                    if (SCATTER) bv.bucket[slot] = make_uint2(db, (uint32_t)(base + g));
+                    if (SCATTER) bv.bucket[slot] = make_uint2(__float_as_uint(o2.w), (uint32_t)(base + g));
                 }
             }
         }
@@ -301,28 +354,6 @@ __device__ __forceinline__ void merge_sort_tile(uint64_t* __restrict__ skeys, co
 // is a count of the smaller keys among the bucket's few members.  ~10 LDS operations per key instead of the merge
 // sort's ~35 (log2(n) merge-path rounds).  Lists whose depths pile up (sum of squared bucket counts > 8 n) are
 // rejected and take the merge sort; the result never depends on which path ran.
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v, int ctrl, int row_mask, bool bound) {
-    switch (ctrl) {   // the builtin wants immediates
-        case 0x111: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x111, 0xF, 0xF, true);
-        case 0x112: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x112, 0xF, 0xF, true);
-        case 0x114: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x114, 0xF, 0xF, true);
-        case 0x118: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x118, 0xF, 0xF, true);
-        case 0x142: return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x142, 0xA, 0xF, false);
-        default:    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x143, 0xC, 0xF, false);
-    }
-}
-
-// inclusive prefix sum over the 64 lanes of a wave (row shifts, then the two row broadcasts of gfx9)
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
-    v += dpp_u32(0, v, 0x111, 0xF, true);   // row_shr:1
-    v += dpp_u32(0, v, 0x112, 0xF, true);   // row_shr:2
-    v += dpp_u32(0, v, 0x114, 0xF, true);   // row_shr:4
-    v += dpp_u32(0, v, 0x118, 0xF, true);   // row_shr:8
-    v += dpp_u32(0, v, 0x142, 0xA, false);  // row_bcast:15 -> rows 1, 3
-    v += dpp_u32(0, v, 0x143, 0xC, false);  // row_bcast:31 -> rows 2, 3
-    return v;
-}
-
 #ifdef PGR_SORT_STATS
 __device__ unsigned long long g_sort_stats[8];   // [0] lists, [1] keys, [2] sum k^2, [3] rejected lists, [4] rejected keys
 #endif
