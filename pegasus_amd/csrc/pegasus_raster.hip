@@ -289,9 +289,9 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     order_scatter_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, L.grid_x, order_state, work_order,
                                                  (uint32_t)SORT_SMALL_MAX, long_list);
     const uint32_t* n_long = order_state + ORDER_BINS;
-    tile_sort_long_kernel<SORT_LARGE_THREADS><<<std::min(n_views * L.tiles, 512), SORT_LARGE_THREADS, 0, stream>>>(
+    tile_sort_long_kernel<1024, 16, 4096><<<std::min(n_views * L.tiles, 1024), 1024, 0, stream>>>(
         bin_table, L.tiles, long_list, n_long);
-    tile_sort_long_kernel<SORT_MEDIUM_THREADS><<<std::min(n_views * L.tiles, 1024), SORT_MEDIUM_THREADS, 0, stream>>>(
+    tile_sort_long_kernel<512, 8, SORT_SMALL_MAX><<<std::min(n_views * L.tiles, 2048), 512, 0, stream>>>(
         bin_table, L.tiles, long_list, n_long);
     tile_sort_kernel<<<n_views * L.tiles, SORT_THREADS, 0, stream>>>(bin_table, L.tiles);
     mark(4);

@@ -361,14 +361,19 @@ __device__ unsigned long long g_sort_stats[8];   // [0] lists, [1] keys, [2] sum
 constexpr uint32_t BUCKET_SQ_LIMIT = 8;
 
 // Sorts n <= THREADS*E keys of `bucket` into out[] (indices) -- same contract as merge_sort_tile without keys_out.
-// lds: THREADS*E*12 + 64 bytes.  Returns false (LDS free for reuse, nothing written) when the list is rejected.
-template <int THREADS, int E>
+// NB = number of buckets (multiple of THREADS; THREADS*E = one per key of capacity).  DIRECT: sorted indices go
+// straight to global memory (4-B scattered stores into an L2-resident list) instead of through an LDS image -- the
+// 16384-key tier has no LDS left for one.
+// lds: THREADS*E*8 + NB*4 + 64 bytes (NB >= THREADS*E unless DIRECT).  Returns false (LDS free for reuse, nothing
+// written) when the list is rejected.
+template <int THREADS, int E, int NB = THREADS * E, bool DIRECT = false>
 __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds, const uint2* __restrict__ bucket,
                                                  uint32_t* __restrict__ out, int n, int n_env,
                                                  uint32_t* __restrict__ obj_last) {
-    constexpr int NB = THREADS * E, WAVES = THREADS / WAVE;
-    uint64_t* s_keys = reinterpret_cast<uint64_t*>(lds);                       // [NB]
-    uint32_t* s_hist = reinterpret_cast<uint32_t*>(lds + (size_t)NB * 8);      // [NB], later the sorted indices
+    constexpr int CAP = THREADS * E, WAVES = THREADS / WAVE, CH = NB / (WAVES * WAVE);   // 64-bucket chunks per wave
+    static_assert(NB % (WAVES * WAVE) == 0 && (DIRECT || NB >= CAP), "bucket count");
+    uint64_t* s_keys = reinterpret_cast<uint64_t*>(lds);                       // [CAP]
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(lds + (size_t)CAP * 8);     // [NB], later the sorted indices
     uint32_t* s_misc = s_hist + NB;                                            // [0] min [1] max [2] sum k^2 [4..] wave totals
     const int t = threadIdx.x, lane = t & (WAVE - 1), wave = t / WAVE;
 
@@ -383,8 +388,8 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
             d[e] = v.x; id[e] = v.y;
             dmin = min(dmin, v.x); dmax = max(dmax, v.x);
         }
-        s_hist[i] = 0u;
     }
+    for (int i = t; i < NB; i += THREADS) s_hist[i] = 0u;
     if (t < 4 + WAVES) s_misc[t] = t == 0 ? 0xffffffffu : 0u;
     __syncthreads();
     // block min / max of the depth bits: butterfly inside the wave, one LDS atomic per wave
@@ -408,11 +413,11 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
         }
     }
     __syncthreads();
-    // pass A: every wave owns NB / WAVES consecutive buckets (E chunks of 64): totals and sum of squares
-    const int wbase = wave * (WAVE * E);
+    // pass A: every wave owns NB / WAVES consecutive buckets (CH chunks of 64): totals and sum of squares
+    const int wbase = wave * (WAVE * CH);
     uint32_t tot = 0, sq = 0;
 #pragma unroll
-    for (int c = 0; c < E; ++c) {
+    for (int c = 0; c < CH; ++c) {
         const uint32_t h = s_hist[wbase + c * WAVE + lane];
         tot += h; sq += h * h;
     }
@@ -420,7 +425,8 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
     for (int m = 1; m < WAVE; m <<= 1) { tot += (uint32_t)__shfl_xor((int)tot, m); sq += (uint32_t)__shfl_xor((int)sq, m); }
     if (lane == 0) { s_misc[4 + wave] = tot; atomicAdd(&s_misc[2], sq); }
     __syncthreads();
-    const bool reject = s_misc[2] > BUCKET_SQ_LIMIT * (uint32_t)n;
+    // average occupancy is n / NB by construction: reject when the squares exceed what an even spread would cost
+    const bool reject = s_misc[2] > BUCKET_SQ_LIMIT * (uint32_t)n * (uint32_t)((CAP + NB - 1) / NB);
 #ifdef PGR_SORT_STATS
     if (t == 0) {
         atomicAdd(&g_sort_stats[0], 1ull); atomicAdd(&g_sort_stats[1], (unsigned long long)n);
@@ -433,7 +439,7 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
     uint32_t carry = 0;
     for (int w = 0; w < wave; ++w) carry += s_misc[4 + w];
 #pragma unroll
-    for (int c = 0; c < E; ++c) {
+    for (int c = 0; c < CH; ++c) {
         const uint32_t h = s_hist[wbase + c * WAVE + lane];
         const uint32_t incl = wave_inclusive_scan(h);
         s_hist[wbase + c * WAVE + lane] = carry + incl - h;
@@ -457,6 +463,21 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
             for (uint32_t j = s0; j < s1; ++j) rank += s_keys[j] < key ? 1u : 0u;
             fin[e] = s0 + rank;
         }
+    }
+    if (DIRECT) {
+        uint32_t best = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (e * THREADS + t < n) {
+                out[fin[e]] = id[e];
+                if (n_env >= 0 && (int)id[e] >= n_env) best = max(best, fin[e] + 1u);
+            }
+        if (n_env >= 0) {
+#pragma unroll
+            for (int m = 1; m < WAVE; m <<= 1) best = max(best, (uint32_t)__shfl_xor((int)best, m));
+            if (lane == 0 && best) atomicMax(obj_last, best);
+        }
+        return true;
     }
     __syncthreads();
     uint32_t* s_idx = s_hist;
@@ -498,7 +519,7 @@ __device__ __forceinline__ void merge_round_global(const uint64_t* __restrict__ 
     }
 }
 
-constexpr int SORT_SMALL_MAX = SORT_THREADS * 16;      // 4096 keys, 32 KiB LDS
+constexpr int SORT_SMALL_MAX = SORT_THREADS * 8;       // 2048 keys, 24 KiB of LDS: six workgroups per CU
 
 // item = view * tiles + tile
 struct ObjOut { int n_env; uint32_t* last; };
@@ -519,10 +540,10 @@ __device__ __forceinline__ bool sort_item(const BinView* __restrict__ views, int
     return n > 0;
 }
 
-// grid = n_views * tiles workgroups of 256; lists of 1..4096 entries
+// grid = n_views * tiles workgroups of 256; lists of 1..2048 entries
 __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* __restrict__ views, int tiles) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[SORT_THREADS * 16 * 12 + 64];
-    uint64_t* skeys = reinterpret_cast<uint64_t*>(lds);     // merge sort: SORT_THREADS * 17 keys fit as well
+    __shared__ __attribute__((aligned(16))) unsigned char lds[SORT_THREADS * 8 * 12 + 64];
+    uint64_t* skeys = reinterpret_cast<uint64_t*>(lds);     // merge sort: SORT_THREADS * 9 keys fit as well
     const uint2* bucket; uint32_t* out; int n; ObjOut oo;
     if (!sort_item(views, tiles, blockIdx.x, bucket, out, n, oo)) return;
     if (n > SORT_SMALL_MAX) return;                      // the long tiers'
@@ -532,49 +553,56 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* 
     } else if (n <= SORT_THREADS * 4) {
         if (!bucket_sort_tile<SORT_THREADS, 4>(lds, bucket, out, n, oo.n_env, oo.last))
             merge_sort_tile<SORT_THREADS, 4>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last);
-    } else if (n <= SORT_THREADS * 8) {
+    } else {
         if (!bucket_sort_tile<SORT_THREADS, 8>(lds, bucket, out, n, oo.n_env, oo.last))
             merge_sort_tile<SORT_THREADS, 8>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last);
-    } else {
-        if (!bucket_sort_tile<SORT_THREADS, 16>(lds, bucket, out, n, oo.n_env, oo.last))
-            merge_sort_tile<SORT_THREADS, 16>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last);
     }
 }
 
-// Lists longer than 4096: order_scatter_kernel appends them to long_list (device counter n_long); workgroups
-// stride over the list.  Two launches share the queue: THREADS = 512 takes 4097..8192 keys (68 KiB of LDS, two
-// workgroups per CU), THREADS = 1024 takes 8193..16384 in LDS (136 KiB of the CU's 160 KiB) and anything longer
-// as LDS-sorted 16384-key chunks merged through L2 between the list and its alt buffer.
-constexpr int SORT_MEDIUM_THREADS = 512;
-constexpr int SORT_MEDIUM_MAX = SORT_MEDIUM_THREADS * 16;   // 8192
+// Lists longer than 2048: order_scatter_kernel appends them to long_list (device counter n_long); workgroups
+// stride over the list.  Three launches share the queue (tiers below); the last one sorts 8193..16384 keys in LDS
+// (keys + 4096 buckets: 144 KiB of the CU's 160 KiB, sorted indices stored straight to global memory) and anything
+// longer as merge-sorted 16384-key chunks merged through L2 between the list and its alt buffer.
 constexpr int SORT_LARGE_THREADS = 1024;
 constexpr int SORT_LARGE_MAX = SORT_LARGE_THREADS * 16;     // 16384
+constexpr int SORT_LARGE_BUCKETS = 4096;
 
-template <int THREADS>
+// Queue tiers (THREADS, E): (512, 8) takes 2049..4096 keys (48 KiB of LDS: three workgroups per CU); (1024, 16)
+// takes everything longer -- 4097..8192 with one bucket per key (96 KiB image), 8193..16384 with 4096 buckets --
+// in ONE launch: both need a whole CU's LDS, and the few longest lists then overlap the many medium ones instead of
+// holding a launch of their own (measured 150 us per batch).  LO = the previous tier's capacity.
+template <int THREADS, int E, int LO>
 __global__ __launch_bounds__(THREADS) void tile_sort_long_kernel(const BinView* __restrict__ views, int tiles,
                                                                  const uint32_t* __restrict__ long_list,
                                                                  const uint32_t* __restrict__ n_long) {
-    // medium tier (512 threads): bucket sort image (12 B per key); large tier: merge sort keys (17 per thread)
-    constexpr size_t LDS_BYTES = THREADS == SORT_MEDIUM_THREADS ? (size_t)THREADS * 16 * 12 + 64 : (size_t)THREADS * 17 * 8;
+    constexpr int CAP = THREADS * E;
+    constexpr bool LAST = CAP == SORT_LARGE_MAX;      // the open-ended tier
+    // bucket sort image: 12 B per key, or (last tier) keys + 4096 counters = 144 KiB; the merge sort's padded keys fit
+    constexpr size_t LDS_BYTES = LAST ? (size_t)CAP * 8 + SORT_LARGE_BUCKETS * 4 + 64 : (size_t)CAP * 12 + 64;
+    static_assert((size_t)THREADS * (E + 1) * 8 <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "lds");
+    static_assert(!LAST || (size_t)(CAP / 2) * 12 + 64 <= LDS_BYTES, "half-capacity image");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     uint64_t* skeys = reinterpret_cast<uint64_t*>(lds);
-    constexpr int CAP = THREADS * 16;
     const uint32_t cand = *n_long;
     for (uint32_t k = blockIdx.x; k < cand; k += gridDim.x) {
         const uint2* bucket; uint32_t* out; int n; uint64_t* alt; ObjOut oo;
         const bool ok = sort_item(views, tiles, long_list[k], bucket, out, n, oo, &alt);
-        const bool mine = THREADS == SORT_MEDIUM_THREADS ? (n > SORT_SMALL_MAX && n <= SORT_MEDIUM_MAX) : n > SORT_MEDIUM_MAX;
+        const bool mine = n > LO && (LAST || n <= CAP);
         if (ok && mine) {
-            if (n <= CAP) {
-                bool sorted = false;
-                if constexpr (THREADS == SORT_MEDIUM_THREADS)
-                    sorted = bucket_sort_tile<THREADS, 16>(lds, bucket, out, n, oo.n_env, oo.last);
-                if (!sorted)
-                    merge_sort_tile<THREADS, 16>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last);
+            if (LAST && n <= CAP / 2) {
+                if (!bucket_sort_tile<THREADS, E / 2>(lds, bucket, out, n, oo.n_env, oo.last))
+                    merge_sort_tile<THREADS, E / 2>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last);
+            } else if (n <= CAP) {
+                bool sorted;
+                if constexpr (LAST)
+                    sorted = bucket_sort_tile<THREADS, E, SORT_LARGE_BUCKETS, true>(lds, bucket, out, n, oo.n_env, oo.last);
+                else
+                    sorted = bucket_sort_tile<THREADS, E>(lds, bucket, out, n, oo.n_env, oo.last);
+                if (!sorted) merge_sort_tile<THREADS, E>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last);
             } else {
                 uint64_t* gk = reinterpret_cast<uint64_t*>(const_cast<uint2*>(bucket));
                 for (int c0 = 0; c0 < n; c0 += CAP) {
-                    merge_sort_tile<THREADS, 16>(skeys, bucket + c0, nullptr, min(CAP, n - c0), gk + c0);
+                    merge_sort_tile<THREADS, E>(skeys, bucket + c0, nullptr, min(CAP, n - c0), gk + c0);
                     __syncthreads();
                 }
                 uint64_t *src = gk, *dst = alt;
@@ -587,7 +615,7 @@ __global__ __launch_bounds__(THREADS) void tile_sort_long_kernel(const BinView* 
                 if (oo.n_env >= 0) mark_last_object<THREADS>([&](int i) { return (uint32_t)src[i]; }, n, oo.n_env, oo.last);
             }
         }
-        __syncthreads();   // skeys reuse across loop iterations
+        __syncthreads();   // LDS reuse across loop iterations
     }
 }
 

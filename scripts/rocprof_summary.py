@@ -6,9 +6,9 @@ import sys
 
 
 def short(name: str) -> str:
-    m = re.search(r"pgr::(\w+)", name)
+    m = re.search(r"pgr::(\w+)(<[^>]*>)?", name)
     if m:
-        return "pgr::" + m.group(1)
+        return "pgr::" + m.group(1) + (m.group(2) or "")
     m = re.search(r"radix_sort_onesweep_(\w+?)<", name)
     if m:
         return "rocprim::radix_sort_onesweep_" + m.group(1) + ("#2" if "#2}" in name[-300:] else "")
