@@ -18,6 +18,7 @@ from __future__ import annotations
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -46,6 +47,9 @@ def parse():
     ap.add_argument("--sync-steps", action="store_true", help="one blocking render_batch per step (no pipelining)")
     ap.add_argument("--input-order", action="store_true",
                     help="keep the scene in its input order (default: one-time Morton layout per object, outside the timed region)")
+    ap.add_argument("--dynamic", action="store_true",
+                    help="dynamic sequence: every frame is a TIME STEP with its own object poses (posed inside the "
+                         "preprocess) and one camera, plus its BOP pose records")
     ap.add_argument("--raster-only", action="store_true", help="time only the full-scene RGB+depth pass (R), no masks")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--profile-steps", type=int, default=2, help="steps measured per-stage with HIP events")
@@ -121,10 +125,48 @@ def main():
     def batch_views(i):
         return [specs[(i * B + k) % len(specs)] for k in range(B)]
 
+    # dynamic sequence (BASELINE.json configs[4]): the whole trajectory exists before rendering starts (the reference
+    # simulates first, /root/reference/pegasus.py:216 then :247); time step s moves object k rigidly about its centre
+    pose_seq = m2w_seq = None
+    if args.dynamic:
+        from scipy.spatial.transform import Rotation as Rot
+        from pegasus_amd.compose import pose_table
+        from pegasus_amd import bop_pose
+        oid = cloud.object_id
+        centers = [act["means3d"][oid == k].mean(0) for k in range(1, fr.K + 1)]
+        S = (args.warmup + args.steps + max(1, args.profile_steps) + 1) * B
+        pose_seq = np.zeros((S, fr.K, 20), np.float32)
+        m2w_seq = []
+        for s_i in range(S):
+            pairs, m2w = [], {}
+            for k in range(fr.K):
+                T = np.eye(4)
+                T[:3, :3] = Rot.from_euler("zx", [0.015 * s_i * (1 + 0.1 * k), 0.004 * s_i]).as_matrix()
+                T[:3, 3] = [0.0008 * s_i * math.cos(k), 0.0008 * s_i * math.sin(k), 0.02 * abs(math.sin(0.05 * s_i + k))]
+                pairs.append((T, centers[k]))
+                C4 = np.eye(4); C4[:3, 3] = centers[k]
+                Ci = np.eye(4); Ci[:3, 3] = -centers[k]
+                m2w[k + 1] = C4 @ T @ Ci            # placement of the (already merged) object at time s
+            pose_seq[s_i] = pose_table(pairs)
+            m2w_seq.append(m2w)
+
+    def batch_poses(i):
+        return None if pose_seq is None else pose_seq[(i * B) % len(pose_seq):(i * B) % len(pose_seq) + B]
+
+    def batch_records(i):
+        if pose_seq is None:
+            return None
+        s0 = (i * B) % len(pose_seq)
+        vs = [my_views[(i * B + k) % len(my_views)] for k in range(B)]
+        return bop_pose.batch_pose_records(vs, m2w_seq[s0:s0 + B])
+
     def step(i, **kw):
         if args.separate_semantic:
             return fr.render_batch(batch_views(i), frames, masks=with_masks, **kw)
         kw.pop("sem_stage_ms", None)
+        if pose_seq is not None and kw.get("stage_ms") is None:   # (the profiling entry point has no posed variant:
+            kw.pop("stage_ms", None)                              #  stage times are taken on the unposed scene)
+            return fr.render_frames(batch_views(i), frames, masks=with_masks, poses=batch_poses(i), **kw)
         return fr.render_frames(batch_views(i), frames, masks=with_masks, **kw)
 
     def run_steps(first, count):
@@ -137,7 +179,12 @@ def main():
         pending = None
         for i in range(first, first + count):
             render = fr.render_batch_async if args.separate_semantic else fr.render_frames_async
-            h = render(batch_views(i), frames if i % 2 == 0 else frames2, masks=with_masks, slot=i % 2)
+            if pose_seq is not None:
+                h = fr.render_frames_async(batch_views(i), frames if i % 2 == 0 else frames2, masks=with_masks,
+                                           slot=i % 2, poses=batch_poses(i))
+                batch_records(i)                  # BOP scene_gt / scene_camera entries of the batch (host, overlapped)
+            else:
+                h = render(batch_views(i), frames if i % 2 == 0 else frames2, masks=with_masks, slot=i % 2)
             if pending is not None:
                 pending.wait()
             pending = h
@@ -267,6 +314,8 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": label, "gaussians": N, "width": W, "height": H, "views_per_step": B,
                    "distinct_views": len(my_views), "objects": fr.K,
+                   "sequence": ("dynamic: every frame is a time step with its own object poses (posed inside the "
+                                "preprocess) + BOP pose records" if args.dynamic else "static scene, camera batches"),
                    "scene_layout": ("input order" if fr.order is None else
                                     "Morton order per object (one-time, at scene load, outside the timed region)"),
                    "outputs": ("color[3,H,W] f32 + depth[1,H,W] f32 + semantic image[3,H,W] f32 + masks[K,H,W] u8"

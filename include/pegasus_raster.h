@@ -151,6 +151,26 @@ int32_t pgr_forward_frames_async(const PgrScene *scene, const PgrSemantic *seman
                                  const PgrCamera *cameras, const PgrOutputs *outs, void *workspace,
                                  size_t workspace_bytes, int64_t max_instances_per_view, void *host_scratch,
                                  size_t host_scratch_size, void *stream);
+
+/* Dynamic scenes: per-view rigid poses of the scene's objects, applied INSIDE the preprocess instead of composing a
+ * posed copy of the scene per time step (reference: update_object_pose + deepcopy + merge per frame,
+ * /root/reference/pegasus.py:254-264,387-390; /root/reference/src/gs/pegasus_setup.py:160-226).  A Gaussian with
+ * object_id k > 0 is placed by poses[view][k-1] with the arithmetic of pgr_compose_object (position, orientation);
+ * its view-dependent colour is its own SH evaluated in the object's frame (direction R^T d) -- the function the
+ * band-rotated coefficients of a composed copy represent.  A batch of time steps then runs like a batch of cameras.
+ * Needs scales + rotations (no cov3d_precomp). */
+#define PGR_POSE_STRIDE 20
+typedef struct PgrPosedObjects {
+    const int32_t *object_id;   /* [n] device; 0 = not posed (environment) */
+    const float *poses;         /* [n_views, k_objects, PGR_POSE_STRIDE] device:
+                                   R[9] row-major, t[3], center[3], q[4] = R as unit quaternion (w,x,y,z), pad */
+    int32_t k_objects;
+} PgrPosedObjects;
+/* pgr_forward_frames_async with per-view object poses (`posed` may be NULL = same as pgr_forward_frames_async). */
+int32_t pgr_forward_posed_async(const PgrScene *scene, const PgrSemantic *semantic, const PgrPosedObjects *posed,
+                                int32_t n_views, const PgrCamera *cameras, const PgrOutputs *outs, void *workspace,
+                                size_t workspace_bytes, int64_t max_instances_per_view, void *host_scratch,
+                                size_t host_scratch_size, void *stream);
 int32_t pgr_batch_status(const void *host_scratch, int32_t n_views, int64_t *num_instances);
 
 /* Profiling twin of pgr_forward_batch (bench / rocprof only): records HIP events on `stream` at the

@@ -158,7 +158,16 @@ static void preprocess_one(const PgrOracleIn *in, PgrOracleOut *out, int32_t i, 
     if (out->radii) out->radii[i] = 0;
     if (out->tiles_touched) out->tiles_touched[i] = 0;
 
-    const float px = in->means3d[3 * i + 0], py = in->means3d[3 * i + 1], pz = in->means3d[3 * i + 2];
+    float px = in->means3d[3 * i + 0], py = in->means3d[3 * i + 1], pz = in->means3d[3 * i + 2];
+    /* posed object: same arithmetic as the scene-composition kernel (pegasus_amd/csrc/compose.hip.h) */
+    const float *P = NULL;
+    if (in->object_id && in->object_id[i] > 0) {
+        P = in->poses + (size_t)PGR_POSE_STRIDE * (size_t)(in->object_id[i] - 1);
+        const float dx = px - P[12], dy = py - P[13], dz = pz - P[14];
+        px = fmaf(P[2], dz, fmaf(P[1], dy, P[0] * dx)) + P[12] + P[9];
+        py = fmaf(P[5], dz, fmaf(P[4], dy, P[3] * dx)) + P[13] + P[10];
+        pz = fmaf(P[8], dz, fmaf(P[7], dy, P[6] * dx)) + P[14] + P[11];
+    }
 
     /* view-space position: rows of the usual 4x3 transform, evaluated left to right */
     float tx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
@@ -177,6 +186,14 @@ static void preprocess_one(const PgrOracleIn *in, PgrOracleOut *out, int32_t i, 
     float cov[6];
     if (in->cov3d_precomp) {
         for (int k = 0; k < 6; ++k) cov[k] = in->cov3d_precomp[6 * i + k];
+    } else if (P) {
+        const float *q = in->rotations + 4 * i;
+        const float inv = 1.0f / fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+        const float w = q[0] * inv, x = q[1] * inv, y = q[2] * inv, z = q[3] * inv;
+        const float a = P[15], b = P[16], c = P[17], d = P[18];
+        const float qp[4] = {a * w - b * x - c * y - d * z, a * x + b * w + c * z - d * y,
+                             a * y - b * z + c * w + d * x, a * z + b * y - c * x + d * w};
+        cov3d_from_scale_rot(in->scales + 3 * i, in->scale_modifier, qp, cov);
     } else {
         cov3d_from_scale_rot(in->scales + 3 * i, in->scale_modifier, in->rotations + 4 * i, cov);
     }
@@ -243,6 +260,12 @@ static void preprocess_one(const PgrOracleIn *in, PgrOracleOut *out, int32_t i, 
         float dx = px - in->campos[0], dy = py - in->campos[1], dz = pz - in->campos[2];
         const float len = sqrtf(dx * dx + dy * dy + dz * dz);
         dx = dx / len; dy = dy / len; dz = dz / len;
+        if (P) {   /* the object's own frame: R^T d */
+            const float ox = fmaf(P[6], dz, fmaf(P[3], dy, P[0] * dx));
+            const float oy = fmaf(P[7], dz, fmaf(P[4], dy, P[1] * dx));
+            const float oz = fmaf(P[8], dz, fmaf(P[5], dy, P[2] * dx));
+            dx = ox; dy = oy; dz = oz;
+        }
         float b[16];
         sh_basis(in->sh_degree, dx, dy, dz, b);
         const int ncoef = (in->sh_degree + 1) * (in->sh_degree + 1);
@@ -277,6 +300,7 @@ static int check_in(const PgrOracleIn *in)
         if (have_sr == (in->cov3d_precomp != NULL)) return -1;
         if (in->shs && (in->sh_degree < 0 || in->sh_degree > 3 ||
                         in->sh_stride < (in->sh_degree + 1) * (in->sh_degree + 1))) return -1;
+        if (in->object_id && (!in->poses || in->k_objects <= 0 || in->cov3d_precomp)) return -1;
     }
     return 0;
 }

@@ -65,7 +65,15 @@ typedef struct PgrOracleIn {
                                        1 = tight lists: instances that provably cannot reach alpha >= 1/255 at
                                            any pixel of their tile are dropped (pgr_oracle_tile_may_contribute).
                                            Images are bit-identical in both modes; n_contrib indexes the list. */
+    /* posed objects (dynamic scenes; include/pegasus_raster.h PgrPosedObjects), all NULL/0 = none:
+     * a Gaussian with object_id k > 0 is placed by poses[k-1] exactly as the scene-composition step places it
+     * (x' = R (x - center) + center + t, q' = q_R (x) normalise(q)); its colour is its own SH evaluated in the
+     * object's frame (direction R^T d), the function the band-rotated coefficients of a composed copy represent. */
+    const int32_t *object_id;       /* [n] or NULL */
+    const float *poses;             /* [k_objects, PGR_POSE_STRIDE]: R[9] row-major, t[3], center[3], q[4] (w,x,y,z), pad */
+    int32_t k_objects;
 } PgrOracleIn;
+#define PGR_POSE_STRIDE 20
 
 typedef struct PgrOracleOut {
     /* per-Gaussian (all caller-allocated, any may be NULL) */

@@ -44,6 +44,13 @@ class PgrSemantic(C.Structure):
     _fields_ = [("object_id", C.c_void_p), ("colors", C.c_void_p), ("n_env", C.c_int32), ("k_objects", C.c_int32)]
 
 
+class PgrPosedObjects(C.Structure):
+    _fields_ = [("object_id", C.c_void_p), ("poses", C.c_void_p), ("k_objects", C.c_int32)]
+
+
+PGR_POSE_STRIDE = 20
+
+
 class PgrObjectPose(C.Structure):
     _fields_ = [("R", C.c_float * 9), ("t", C.c_float * 3), ("center", C.c_float * 3), ("q", C.c_float * 4),
                 ("D1", C.c_float * 9), ("D2", C.c_float * 25), ("D3", C.c_float * 49)]
@@ -77,6 +84,9 @@ SYMBOLS = {
     "pgr_forward_frames_async": (C.c_int32, [C.POINTER(PgrScene), C.POINTER(PgrSemantic), C.c_int32,
                                              C.POINTER(PgrCamera), C.POINTER(PgrOutputs), C.c_void_p, C.c_size_t,
                                              C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pgr_forward_posed_async": (C.c_int32, [C.POINTER(PgrScene), C.POINTER(PgrSemantic), C.POINTER(PgrPosedObjects),
+                                            C.c_int32, C.POINTER(PgrCamera), C.POINTER(PgrOutputs), C.c_void_p,
+                                            C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pgr_batch_status": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "pgr_forward_batch_profiled": (C.c_int32, [C.POINTER(PgrScene), C.POINTER(PgrSemantic), C.c_int32,
                                                C.POINTER(PgrCamera),

@@ -37,6 +37,23 @@ def make_pose(T, center) -> _lib.PgrObjectPose:
     return p
 
 
+def pose_table(poses) -> np.ndarray:
+    """[K, 20] float32 rows (R[9] row-major, t[3], center[3], q[4] (w,x,y,z), 0) for the posed-objects path
+    (PgrPosedObjects / oracle ``poses``) from K PgrObjectPose structs (``make_pose``) or (T, center) pairs.
+    (T, center) pairs skip the SH band matrices, which this path does not use."""
+    from scipy.spatial.transform import Rotation as Rot
+    rows = np.zeros((len(poses), _lib.PGR_POSE_STRIDE), dtype=np.float32)
+    for k, p in enumerate(poses):
+        if isinstance(p, _lib.PgrObjectPose):
+            rows[k, 0:9], rows[k, 9:12], rows[k, 12:15], rows[k, 15:19] = list(p.R), list(p.t), list(p.center), list(p.q)
+        else:
+            T, center = np.asarray(p[0], dtype=np.float64).reshape(4, 4), np.asarray(p[1], dtype=np.float64)
+            q = Rot.from_matrix(T[:3, :3]).as_quat()
+            rows[k, 0:9], rows[k, 9:12], rows[k, 12:15] = T[:3, :3].reshape(-1), T[:3, 3], center
+            rows[k, 15:19] = (q[3], q[0], q[1], q[2])
+    return rows
+
+
 def compose_object(xyz, rot, f_rest, pose: _lib.PgrObjectPose, out_xyz, out_rot, out_rest, out_rest_stride=None):
     """Thin wrapper over pgr_compose_object for torch device tensors (f_rest [n,R,3] contiguous)."""
     L = _lib.lib()

@@ -176,8 +176,11 @@ static int zero_outputs(const PgrOutputs* out, size_t P, hipStream_t stream) {
 static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrCamera* cams, const PgrOutputs* outs,
                                   void* workspace, size_t workspace_bytes, int64_t max_instances,
                                   int64_t* num_instances, hipStream_t stream, hipEvent_t* ev,
-                                  void* host_scratch = nullptr, const PgrSemantic* semantic = nullptr) {
+                                  void* host_scratch = nullptr, const PgrSemantic* semantic = nullptr,
+                                  const PgrPosedObjects* posed = nullptr) {
     auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], stream); };
+    if (posed && (!posed->object_id || !posed->poses || posed->k_objects <= 0 || (scene && scene->cov3d_precomp)))
+        return PGR_ERR_INVALID_ARGUMENT;
     if (n_views <= 0 || !cams || !outs) return PGR_ERR_INVALID_ARGUMENT;
     if (num_instances) for (int v = 0; v < n_views; ++v) num_instances[v] = 0;
     if (int rc = check_scene(scene)) return rc;
@@ -261,12 +264,17 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         pack_camera_kernel<<<cnt, 64, 0, stream>>>(cp, W, H, cams_dev + v0);
     }
     // one pass over the Gaussians for the whole batch (scene data read once, per-view outputs written)
-    switch (scene->shs ? scene->sh_degree : 0) {
-        case 0: preprocess_batch_kernel<0><<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, cams_dev, pre_table, n_views); break;
-        case 1: preprocess_batch_kernel<1><<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, cams_dev, pre_table, n_views); break;
-        case 2: preprocess_batch_kernel<2><<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, cams_dev, pre_table, n_views); break;
-        default: preprocess_batch_kernel<3><<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, cams_dev, pre_table, n_views); break;
+    const PosedDev pd{posed ? posed->object_id : nullptr, posed ? posed->poses : nullptr, posed ? posed->k_objects : 0};
+    const int deg = scene->shs ? scene->sh_degree : 0;
+#define PGR_PRE(D, Pz) preprocess_batch_kernel<D, Pz><<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, cams_dev, pre_table, n_views, pd)
+    if (posed) {
+        switch (deg) { case 0: PGR_PRE(0, true); break; case 1: PGR_PRE(1, true); break; case 2: PGR_PRE(2, true); break;
+                       default: PGR_PRE(3, true); break; }
+    } else {
+        switch (deg) { case 0: PGR_PRE(0, false); break; case 1: PGR_PRE(1, false); break; case 2: PGR_PRE(2, false); break;
+                       default: PGR_PRE(3, false); break; }
     }
+#undef PGR_PRE
     mark(1);
     // ---- stage 1: per-chunk LDS tile histograms + slice reservation, then the tile scan (device only)
     const int grid_x = (W + TILE - 1) / TILE;
@@ -412,6 +420,16 @@ int32_t pgr_forward_frames_async(const PgrScene* scene, const PgrSemantic* seman
     if (scene && scene->n == 0) memset(static_cast<char*>(host_scratch), 0, host_scratch_bytes(n_views));
     return forward_batch_impl(scene, n_views, cameras, outs, workspace, workspace_bytes, max_instances_per_view, nullptr,
                               static_cast<hipStream_t>(stream_v), nullptr, host_scratch, semantic);
+}
+
+int32_t pgr_forward_posed_async(const PgrScene* scene, const PgrSemantic* semantic, const PgrPosedObjects* posed,
+                                int32_t n_views, const PgrCamera* cameras, const PgrOutputs* outs, void* workspace,
+                                size_t workspace_bytes, int64_t max_instances_per_view, void* host_scratch,
+                                size_t host_scratch_size, void* stream_v) {
+    if (!host_scratch || n_views <= 0 || host_scratch_size < host_scratch_bytes(n_views)) return PGR_ERR_INVALID_ARGUMENT;
+    if (scene && scene->n == 0) memset(static_cast<char*>(host_scratch), 0, host_scratch_bytes(n_views));
+    return forward_batch_impl(scene, n_views, cameras, outs, workspace, workspace_bytes, max_instances_per_view, nullptr,
+                              static_cast<hipStream_t>(stream_v), nullptr, host_scratch, semantic, posed);
 }
 
 int32_t pgr_batch_status(const void* host_scratch, int32_t n_views, int64_t* num_instances) {

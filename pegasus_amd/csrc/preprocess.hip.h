@@ -199,12 +199,27 @@ __device__ __forceinline__ void load_sh(ShRegs& sh, const float* __restrict__ p,
 // batch instead of once per view (the view-independent 3D covariance is also built once), which turns the
 // kernel from read-bound (~356 MB/view) into write-bound (12 N + 44 V per view).  Per-view arithmetic is
 // unchanged, so the outputs are bit-identical to the single-view form and to the oracle.
-template <int DEG>
+//
+// POSED (dynamic scenes, include/pegasus_raster.h PgrPosedObjects): every view carries its own rigid pose per object
+// and a Gaussian of object k is placed on the fly -- position and orientation with the arithmetic of
+// compose_object_kernel, colour from its own SH coefficients evaluated in the object's frame (direction R^T d) --
+// so a batch of TIME STEPS runs like a batch of cameras: no composed copy of the scene is written (236 B read +
+// 236 B written per object Gaussian and step) and no SH band rotation is evaluated.
+constexpr int POSE_STRIDE = 20;      // floats per pose: R[9] row-major, t[3], center[3], q[4] (w,x,y,z), pad
+struct PosedDev {
+    const int32_t* object_id;        // [n] 0 = not posed
+    const float* poses;              // [n_views, k, POSE_STRIDE]
+    int32_t k;
+};
+
+template <int DEG, bool POSED>
 __global__ __launch_bounds__(PRE_BLOCK) void preprocess_batch_kernel(PgrScene sc, const CameraDev* __restrict__ cams,
-                                                                     const PreOut* __restrict__ outs, int n_views) {
+                                                                     const PreOut* __restrict__ outs, int n_views,
+                                                                     PosedDev posed) {
     const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
     if (i >= sc.n) return;
-    const float px = sc.means3d[3 * i + 0], py = sc.means3d[3 * i + 1], pz = sc.means3d[3 * i + 2];
+    const float bx = sc.means3d[3 * i + 0], by = sc.means3d[3 * i + 1], bz = sc.means3d[3 * i + 2];
+    const int oid = POSED ? posed.object_id[i] : 0;
     float cov[6];
     bool have_cov = false, have_sh = false;
     ShRegs sh;
@@ -217,6 +232,15 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_batch_kernel(PgrScene sc
         uint2 rect = make_uint2(0u, 0u), crect = make_uint2(0u, 0u);
         const float* vm = cam.view;
         const float* pm = cam.proj;
+        float px = bx, py = by, pz = bz;
+        const float* P = nullptr;
+        if (POSED && oid > 0) {
+            P = posed.poses + ((size_t)v * posed.k + (size_t)(oid - 1)) * POSE_STRIDE;
+            const float dx = bx - P[12], dy = by - P[13], dz = bz - P[14];
+            px = fmaf(P[2], dz, fmaf(P[1], dy, P[0] * dx)) + P[12] + P[9];
+            py = fmaf(P[5], dz, fmaf(P[4], dy, P[3] * dx)) + P[13] + P[10];
+            pz = fmaf(P[8], dz, fmaf(P[7], dy, P[6] * dx)) + P[14] + P[11];
+        }
         float tx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
         float ty = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
         const float tz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
@@ -226,7 +250,16 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_batch_kernel(PgrScene sc
             const float hw = pm[3] * px + pm[7] * py + pm[11] * pz + pm[15];
             const float p_w = 1.0f / (hw + 0.0000001f);
             const float ndc_x = hx * p_w, ndc_y = hy * p_w;
-            if (!have_cov) {
+            if (POSED && P) {            // orientation follows the pose: q' = q_R (x) normalise(q), per view
+                const float4 q = reinterpret_cast<const float4*>(sc.rotations)[i];
+                const float inv = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+                const float w = q.x * inv, x = q.y * inv, y = q.z * inv, z = q.w * inv;
+                const float a = P[15], b = P[16], c = P[17], d = P[18];
+                const float4 qp = make_float4(a * w - b * x - c * y - d * z, a * x + b * w + c * z - d * y,
+                                              a * y - b * z + c * w + d * x, a * z + b * y - c * x + d * w);
+                cov3d_from_scale_rot(sc.scales[3 * i + 0], sc.scales[3 * i + 1], sc.scales[3 * i + 2],
+                                     sc.scale_modifier, qp, cov);
+            } else if (!have_cov) {
                 if (sc.cov3d_precomp) {
 #pragma unroll
                     for (int k = 0; k < 6; ++k) cov[k] = sc.cov3d_precomp[6 * (size_t)i + k];
@@ -287,6 +320,12 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_batch_kernel(PgrScene sc
                         float dx = px - cam.campos[0], dy = py - cam.campos[1], dz = pz - cam.campos[2];
                         const float len = sqrtf(dx * dx + dy * dy + dz * dz);
                         dx = dx / len; dy = dy / len; dz = dz / len;
+                        if (POSED && P) {        // the object's own frame: R^T d
+                            const float ox = fmaf(P[6], dz, fmaf(P[3], dy, P[0] * dx));
+                            const float oy = fmaf(P[7], dz, fmaf(P[4], dy, P[1] * dx));
+                            const float oz = fmaf(P[8], dz, fmaf(P[5], dy, P[2] * dx));
+                            dx = ox; dy = oy; dz = oz;
+                        }
                         rgb = sh_regs_to_rgb<DEG>(sh, dx, dy, dz);
                     }
                     radius = rad;

@@ -86,10 +86,24 @@ class FrameRenderer:
             f["masks"] = torch.empty((batch, self.K, height, width), dtype=torch.uint8, device=dev)
         return f
 
-    def render_frames_async(self, specs: Sequence[R.ViewSpec], frames: dict, masks: bool = True, slot: int = 0):
+    def _posed(self, poses, B):
+        """poses [B, K, 20] (pegasus_amd.compose.pose_table per time step) -> the posed-objects argument."""
+        if poses is None:
+            return None
+        if self.K == 0:
+            raise ValueError("the scene has no objects to pose")
+        t = torch.as_tensor(np.asarray(poses, dtype=np.float32) if not torch.is_tensor(poses) else poses)
+        t = t.to(self.device, torch.float32).contiguous()
+        if tuple(t.shape) != (B, self.K, 20):
+            raise ValueError(f"poses must be [{B}, {self.K}, 20]")
+        return dict(object_id=self.semantic["object_id"], poses=t)
+
+    def render_frames_async(self, specs: Sequence[R.ViewSpec], frames: dict, masks: bool = True, slot: int = 0,
+                            poses=None):
         """The fast path: ONE batch call renders the scene (color, depth) and -- from the same per-tile lists --
         the objects-only semantic image (seg), then one mask launch; enqueued on side stream ``slot`` (2 slots =
-        two batches in flight on two streams).  Returns a ``wait()``-able handle; nothing synchronises the host."""
+        two batches in flight on two streams).  Returns a ``wait()``-able handle; nothing synchronises the host.
+        ``poses`` [B, K, 20]: dynamic scene -- frame i shows object k at poses[i, k-1] (time steps as a batch)."""
         B = len(specs)
         dev = self.device
         cur = torch.cuda.current_stream(dev)
@@ -105,7 +119,8 @@ class FrameRenderer:
         with torch.cuda.stream(st):
             h = R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales,
                                 rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False, outputs=outs,
-                                async_slot=("frames", slot), semantic=self.semantic if fused else None)
+                                async_slot=("frames", slot), semantic=self.semantic if fused else None,
+                                posed=self._posed(poses, B))
             if fused:
                 M.color_masks(frames["seg"][:B], self.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])
             ev = torch.cuda.Event()
@@ -174,7 +189,7 @@ class FrameRenderer:
         return _Pending()
 
     def render_frames(self, specs: Sequence[R.ViewSpec], frames: dict = None, masks: bool = True,
-                      stage_ms: list = None):
+                      stage_ms: list = None, poses=None):
         """Blocking form of render_frames_async on the current stream (fused semantic pass); ``stage_ms``
         receives the HIP-event stage times of the whole batch."""
         B = len(specs)
@@ -188,7 +203,7 @@ class FrameRenderer:
                 outs[i]["sem_color"], outs[i]["sem_depth"] = frames["seg"][i], frames["seg_depth"][i]
         R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales,
                         rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False, outputs=outs,
-                        stage_ms=stage_ms, semantic=self.semantic if fused else None)
+                        stage_ms=stage_ms, semantic=self.semantic if fused else None, posed=self._posed(poses, B))
         if fused:
             M.color_masks(frames["seg"][:B], self.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])
         return frames

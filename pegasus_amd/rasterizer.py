@@ -110,7 +110,7 @@ class PendingBatch:
 def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, colors_precomp=None, scales=None,
                   rotations=None, cov3D_precomp=None, sh_degree=0, scale_modifier=1.0, want_radii=True,
                   want_aux=False, stage_ms: Optional[list] = None, outputs: Optional[list] = None,
-                  async_slot=None, semantic: Optional[dict] = None):
+                  async_slot=None, semantic: Optional[dict] = None, posed: Optional[dict] = None):
     """Renders ``len(views)`` views of one scene.  Returns a list of dicts with keys
     color[3,H,W], depth[1,H,W], radii[N] (or None), and final_T / n_contrib when ``want_aux``.
 
@@ -121,6 +121,8 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
     PendingBatch; the slot names the workspace / pinned scratch to use (one batch in flight per slot).
     ``semantic``: dict(object_id int32[N], colors float32[K,3], n_env, k) -> the fused objects-only semantic
     render is written to r["sem_color"] (and r["sem_depth"]) of every view (pgr_forward_frames_async).
+    ``posed``: dict(object_id int32[N], poses float32[len(views), K, 20]) -> dynamic scene: view i places object k by
+    poses[i, k-1] inside the preprocess (pgr_forward_posed_async; pegasus_amd.compose.pose_table builds the rows).
     """
     L = _lib.lib()
     device = means3D.device
@@ -177,14 +179,24 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     key = (device, n, W, H)
     max_inst = _WS.capacity_hint.get(key, max(1 << 20, 6 * n))
-    sem_struct = None
+    sem_struct = posed_struct = None
+    if posed is not None:
+        if stage_ms is not None:
+            raise ValueError("the profiling entry point does not take posed objects")
+        poses = dev_f32(posed["poses"], device)
+        if poses.dim() != 3 or poses.shape[0] != nv or poses.shape[2] != _lib.PGR_POSE_STRIDE:
+            raise ValueError("posed['poses'] must be [n_views, K, 20]")
+        keep.append(poses)
+        posed_struct = _lib.PgrPosedObjects(object_id=_ptr(posed["object_id"]), poses=_ptr(poses),
+                                            k_objects=int(poses.shape[1]))
     if semantic is not None:
         sem_struct = _lib.PgrSemantic(object_id=_ptr(semantic["object_id"]), colors=_ptr(semantic["colors"]),
                                       n_env=int(semantic["n_env"]), k_objects=int(semantic["k"]))
+    if semantic is not None or posed is not None:
         if async_slot is None and stage_ms is None:      # synchronous fused call: enqueue asynchronously, wait, retry on overflow
             kw = dict(shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
                       cov3D_precomp=cov3D_precomp, sh_degree=sh_degree, scale_modifier=scale_modifier,
-                      want_radii=want_radii, want_aux=want_aux, outputs=results, semantic=semantic)
+                      want_radii=want_radii, want_aux=want_aux, outputs=results, semantic=semantic, posed=posed)
             for _attempt in range(3):
                 pb = forward_views(means3D, opacities, views, async_slot="sync-fused", **kw)
                 pb._redo = None
@@ -202,15 +214,16 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
             ws = _WS.get(device, nbytes, slot=("async", async_slot))
             sb = L.pgr_host_scratch_bytes(nv)
             scratch = _WS.pinned(async_slot, sb)
-            _lib.check(L.pgr_forward_frames_async(C.byref(scene), C.byref(sem_struct) if sem_struct else None, nv,
-                                                  cams, outs, C.c_void_p(ws.data_ptr()), ws.numel(), max_inst,
-                                                  C.c_void_p(scratch.data_ptr()), scratch.numel(), stream),
-                       "pgr_forward_frames_async")
+            _lib.check(L.pgr_forward_posed_async(C.byref(scene), C.byref(sem_struct) if sem_struct else None,
+                                                 C.byref(posed_struct) if posed_struct else None, nv,
+                                                 cams, outs, C.c_void_p(ws.data_ptr()), ws.numel(), max_inst,
+                                                 C.c_void_p(scratch.data_ptr()), scratch.numel(), stream),
+                       "pgr_forward_posed_async")
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(device))
         kw = dict(shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
                   cov3D_precomp=cov3D_precomp, sh_degree=sh_degree, scale_modifier=scale_modifier,
-                  want_radii=want_radii, want_aux=want_aux, outputs=results, semantic=semantic)
+                  want_radii=want_radii, want_aux=want_aux, outputs=results, semantic=semantic, posed=posed)
         redo = lambda: forward_views(means3D, opacities, views, **kw)
         pb = PendingBatch(results, ev, scratch, nv, key, max_inst, redo)
         pb._keep = (keep, ws, cams, outs, scene)
