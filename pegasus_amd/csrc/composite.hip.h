@@ -174,9 +174,18 @@ __global__ __launch_bounds__(WAVE) PGR_COMP_OCC void composite_quarter_kernel(co
 #endif
     for (int base = 0; base < n; base += WAVE_BATCH) {
         if (alive == 0ull && (sem_alive == 0ull || base >= n_sem)) break;
+        // The skip test only has to cover pixels that can still change: the bounding box of the alive lanes (lane =
+        // 8 y + x), which shrinks as the quarter saturates (scalar bit tricks on the SGPR masks).
+        const unsigned long long any = alive | sem_alive;
+        const int ay0 = __builtin_ctzll(any) >> 3, ay1 = (63 - __builtin_clzll(any)) >> 3;
+        unsigned int cols = (unsigned int)(any | (any >> 32));
+        cols |= cols >> 16; cols |= cols >> 8; cols &= 0xffu;
+        const int ax0 = __builtin_ctz(cols), ax1 = 31 - __builtin_clz(cols);
+        const float bx0 = rx0 + (float)ax0, by0 = ry0 + (float)ay0;
+        const float bx1 = fminf(rx0 + (float)ax1, rx1), by1 = fminf(ry0 + (float)ay1, ry1);
         // with the scene pixels saturated only object entries are still of interest
         const bool live = have && (alive != 0ull || cs.w != 0.0f) &&
-                          rect_may_contribute(make_cull_splat(p, co), rx0, ry0, rx1, ry1);
+                          rect_may_contribute(make_cull_splat(p, co), bx0, by0, bx1, by1);
         const unsigned long long mask = __ballot(live);
         const int cnt = __popcll(mask);
         const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
