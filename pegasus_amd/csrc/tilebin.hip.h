@@ -277,10 +277,11 @@ __device__ __forceinline__ int pad_idx(int i) {
 // in the tile's sorted list, 0 if there is none (the word is zero-filled per batch).  The compositor walks a tile's
 // list beyond the saturation of its scene pixels only up to there.  `get(i)` returns the i-th sorted index.
 template <int THREADS, typename Get>
-__device__ __forceinline__ void mark_last_object(Get get, int n, int n_env, uint32_t* __restrict__ obj_last) {
+__device__ __forceinline__ void mark_last_object(Get get, int n, int n_env, uint32_t* __restrict__ obj_last,
+                                                 uint32_t pos_offset = 0) {
     uint32_t best = 0;
     for (int i = threadIdx.x; i < n; i += THREADS)
-        if ((int)get(i) >= n_env) best = (uint32_t)i + 1u;
+        if ((int)get(i) >= n_env) best = pos_offset + (uint32_t)i + 1u;
 #pragma unroll
     for (int m = 1; m < WAVE; m <<= 1) best = max(best, (uint32_t)__shfl_xor((int)best, m));
     if ((threadIdx.x & (WAVE - 1)) == 0 && best) atomicMax(obj_last, best);
@@ -291,7 +292,8 @@ __device__ __forceinline__ void mark_last_object(Get get, int n, int n_env, uint
 template <int THREADS, int E>
 __device__ __forceinline__ void merge_sort_tile(uint64_t* __restrict__ skeys, const uint2* __restrict__ bucket,
                                                 uint32_t* __restrict__ out, int n, uint64_t* keys_out = nullptr,
-                                                int n_env = -1, uint32_t* __restrict__ obj_last = nullptr) {
+                                                int n_env = -1, uint32_t* __restrict__ obj_last = nullptr,
+                                                uint32_t pos_offset = 0) {
     const int t = threadIdx.x;
     uint64_t r[E];
     // the list is unordered, so WHICH keys a thread starts with is free: take them coalesced
@@ -342,7 +344,8 @@ __device__ __forceinline__ void merge_sort_tile(uint64_t* __restrict__ skeys, co
         for (int i = t; i < n; i += THREADS) keys_out[i] = skeys[pad_idx<E>(i)];
     } else {
         for (int i = t; i < n; i += THREADS) out[i] = (uint32_t)skeys[pad_idx<E>(i)];
-        if (n_env >= 0) mark_last_object<THREADS>([&](int i) { return (uint32_t)skeys[pad_idx<E>(i)]; }, n, n_env, obj_last);
+        if (n_env >= 0)
+            mark_last_object<THREADS>([&](int i) { return (uint32_t)skeys[pad_idx<E>(i)]; }, n, n_env, obj_last, pos_offset);
     }
 }
 
@@ -364,14 +367,15 @@ constexpr uint32_t BUCKET_SQ_LIMIT = 8;
 // NB = number of buckets (multiple of THREADS; THREADS*E = one per key of capacity).  DIRECT: sorted indices go
 // straight to global memory (4-B scattered stores into an L2-resident list) instead of through an LDS image -- the
 // 16384-key tier has no LDS left for one.
-// lds: THREADS*E*8 + NB*4 + 64 bytes (NB >= THREADS*E unless DIRECT).  Returns false (LDS free for reuse, nothing
+// lds: THREADS*E*8 + NB*4 + 128 bytes (NB >= THREADS*E unless DIRECT).  Returns false (LDS free for reuse, nothing
 // written) when the list is rejected.
 template <int THREADS, int E, int NB = THREADS * E, bool DIRECT = false>
 __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds, const uint2* __restrict__ bucket,
                                                  uint32_t* __restrict__ out, int n, int n_env,
-                                                 uint32_t* __restrict__ obj_last) {
+                                                 uint32_t* __restrict__ obj_last, uint32_t pos_offset = 0) {
     constexpr int CAP = THREADS * E, WAVES = THREADS / WAVE, CH = NB / (WAVES * WAVE);   // 64-bucket chunks per wave
     static_assert(NB % (WAVES * WAVE) == 0 && (DIRECT || NB >= CAP), "bucket count");
+    static_assert((4 + WAVES) * 4 <= 128, "s_misc must fit the 128 bytes the callers reserve behind the counters");
     uint64_t* s_keys = reinterpret_cast<uint64_t*>(lds);                       // [CAP]
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(lds + (size_t)CAP * 8);     // [NB], later the sorted indices
     uint32_t* s_misc = s_hist + NB;                                            // [0] min [1] max [2] sum k^2 [4..] wave totals
@@ -470,7 +474,7 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
         for (int e = 0; e < E; ++e)
             if (e * THREADS + t < n) {
                 out[fin[e]] = id[e];
-                if (n_env >= 0 && (int)id[e] >= n_env) best = max(best, fin[e] + 1u);
+                if (n_env >= 0 && (int)id[e] >= n_env) best = max(best, pos_offset + fin[e] + 1u);
             }
         if (n_env >= 0) {
 #pragma unroll
@@ -486,7 +490,100 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
         if (e * THREADS + t < n) s_idx[fin[e]] = id[e];
     __syncthreads();
     for (int i = t; i < n; i += THREADS) out[i] = s_idx[i];
-    if (n_env >= 0) mark_last_object<THREADS>([&](int i) { return s_idx[i]; }, n, n_env, obj_last);
+    if (n_env >= 0) mark_last_object<THREADS>([&](int i) { return s_idx[i]; }, n, n_env, obj_last, pos_offset);
+    return true;
+}
+
+// Lists beyond one LDS sort (> CAP keys): ONE counting-sort pass by coarse depth bucket through the alt buffer
+// (L2-resident), cut at the first bucket start at or after every multiple of CAP / 2 -- with no bucket larger than
+// CAP / 2 every segment holds < CAP keys, and all of its depths precede the next segment's -- then each segment is
+// sorted in LDS like a list of its own and written at its offset.  Returns false (nothing written to out) when a
+// coarse bucket piles up or the list needs more than PART_MAX_SEGMENTS segments; the caller then merges LDS-sorted
+// chunks through L2.
+constexpr int SORT_LARGE_THREADS = 1024;
+constexpr int SORT_LARGE_MAX = SORT_LARGE_THREADS * 16;     // 16384
+constexpr int SORT_LARGE_BUCKETS = 4096;
+constexpr int PART_BUCKETS = 4096;
+constexpr int PART_MAX_SEGMENTS = 63;
+
+template <int THREADS, int E>
+__device__ __forceinline__ bool partition_sort_long(unsigned char* __restrict__ lds, uint32_t* __restrict__ s_cut,
+                                                    const uint2* __restrict__ bucket, uint2* __restrict__ alt,
+                                                    uint32_t* __restrict__ out, int n, int n_env,
+                                                    uint32_t* __restrict__ obj_last) {
+    constexpr int CAP = THREADS * E, HALF = CAP / 2, WAVES = THREADS / WAVE, CH = PART_BUCKETS / (WAVES * WAVE);
+    static_assert(PART_BUCKETS % (WAVES * WAVE) == 0, "bucket count");
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(lds);         // [PART_BUCKETS] counts -> starts -> cursors
+    uint32_t* s_misc = s_hist + PART_BUCKETS;                    // [0] min [1] max [2] largest bucket [4..] wave totals
+    const int t = threadIdx.x, lane = t & (WAVE - 1), wave = t / WAVE;
+    if ((n + HALF - 1) / HALF > PART_MAX_SEGMENTS) return false;
+    uint32_t dmin = 0xffffffffu, dmax = 0u;
+    for (int i = t; i < n; i += THREADS) { const uint32_t d = bucket[i].x; dmin = min(dmin, d); dmax = max(dmax, d); }
+    for (int i = t; i < PART_BUCKETS; i += THREADS) s_hist[i] = 0u;
+    if (t < 4 + WAVES) s_misc[t] = t == 0 ? 0xffffffffu : 0u;
+    if (t < PART_MAX_SEGMENTS + 2) s_cut[t] = (uint32_t)n;      // segment g starts at s_cut[g]; n = not opened
+    __syncthreads();
+#pragma unroll
+    for (int m = 1; m < WAVE; m <<= 1) {
+        dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, m));
+        dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, m));
+    }
+    if (lane == 0) { atomicMin(&s_misc[0], dmin); atomicMax(&s_misc[1], dmax); }
+    __syncthreads();
+    const uint32_t mn = s_misc[0];
+    const float scale = (float)PART_BUCKETS / ((float)(s_misc[1] - mn) + 1.0f);
+    auto coarse = [&](uint32_t d) { return min((uint32_t)((float)(d - mn) * scale), (uint32_t)(PART_BUCKETS - 1)); };
+    for (int i = t; i < n; i += THREADS) atomicAdd(&s_hist[coarse(bucket[i].x)], 1u);
+    __syncthreads();
+    const int wbase = wave * (WAVE * CH);
+    uint32_t tot = 0, big = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const uint32_t h = s_hist[wbase + c * WAVE + lane];
+        tot += h; big = max(big, h);
+    }
+#pragma unroll
+    for (int m = 1; m < WAVE; m <<= 1) {
+        tot += (uint32_t)__shfl_xor((int)tot, m);
+        big = max(big, (uint32_t)__shfl_xor((int)big, m));
+    }
+    if (lane == 0) { s_misc[4 + wave] = tot; atomicMax(&s_misc[2], big); }
+    __syncthreads();
+    if (s_misc[2] > (uint32_t)HALF) { __syncthreads(); return false; }
+    uint32_t carry = 0;
+    for (int w = 0; w < wave; ++w) carry += s_misc[4 + w];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const uint32_t h = s_hist[wbase + c * WAVE + lane];
+        const uint32_t incl = wave_inclusive_scan(h);
+        s_hist[wbase + c * WAVE + lane] = carry + incl - h;
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+    }
+    __syncthreads();
+    // segment g begins at the smallest bucket start >= g * HALF; bucket sizes <= HALF, so every g up to the last one
+    // is hit and consecutive cuts are < CAP apart
+    for (int b = t; b < PART_BUCKETS; b += THREADS) {
+        const uint32_t s0 = s_hist[b];
+        const uint32_t g = (s0 + (uint32_t)HALF - 1u) / (uint32_t)HALF;
+        const bool first = b == 0 || (s_hist[b - 1] + (uint32_t)HALF - 1u) / (uint32_t)HALF != g;
+        if (first && s0 < (uint32_t)n) atomicMin(&s_cut[g], s0);
+    }
+    __syncthreads();
+    // counting-sort scatter through the alt buffer (the starts become the cursors)
+    for (int i = t; i < n; i += THREADS) {
+        const uint2 v = bucket[i];
+        alt[atomicAdd(&s_hist[coarse(v.x)], 1u)] = v;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int g = 0; g <= PART_MAX_SEGMENTS; ++g) {
+        const uint32_t a = s_cut[g];
+        if (a >= (uint32_t)n) break;
+        const int n_seg = (int)(s_cut[g + 1] - a);
+        if (!bucket_sort_tile<THREADS, E, SORT_LARGE_BUCKETS, true>(lds, alt + a, out + a, n_seg, n_env, obj_last, a))
+            merge_sort_tile<THREADS, E>(reinterpret_cast<uint64_t*>(lds), alt + a, out + a, n_seg, nullptr, n_env, obj_last, a);
+        __syncthreads();
+    }
     return true;
 }
 
@@ -542,7 +639,7 @@ __device__ __forceinline__ bool sort_item(const BinView* __restrict__ views, int
 
 // grid = n_views * tiles workgroups of 256; lists of 1..2048 entries
 __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* __restrict__ views, int tiles) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[SORT_THREADS * 8 * 12 + 64];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[SORT_THREADS * 8 * 12 + 128];
     uint64_t* skeys = reinterpret_cast<uint64_t*>(lds);     // merge sort: SORT_THREADS * 9 keys fit as well
     const uint2* bucket; uint32_t* out; int n; ObjOut oo;
     if (!sort_item(views, tiles, blockIdx.x, bucket, out, n, oo)) return;
@@ -563,10 +660,6 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* 
 // stride over the list.  Three launches share the queue (tiers below); the last one sorts 8193..16384 keys in LDS
 // (keys + 4096 buckets: 144 KiB of the CU's 160 KiB, sorted indices stored straight to global memory) and anything
 // longer as merge-sorted 16384-key chunks merged through L2 between the list and its alt buffer.
-constexpr int SORT_LARGE_THREADS = 1024;
-constexpr int SORT_LARGE_MAX = SORT_LARGE_THREADS * 16;     // 16384
-constexpr int SORT_LARGE_BUCKETS = 4096;
-
 // Queue tiers (THREADS, E): (512, 8) takes 2049..4096 keys (48 KiB of LDS: three workgroups per CU); (1024, 16)
 // takes everything longer -- 4097..8192 with one bucket per key (96 KiB image), 8193..16384 with 4096 buckets --
 // in ONE launch: both need a whole CU's LDS, and the few longest lists then overlap the many medium ones instead of
@@ -578,10 +671,11 @@ __global__ __launch_bounds__(THREADS) void tile_sort_long_kernel(const BinView* 
     constexpr int CAP = THREADS * E;
     constexpr bool LAST = CAP == SORT_LARGE_MAX;      // the open-ended tier
     // bucket sort image: 12 B per key, or (last tier) keys + 4096 counters = 144 KiB; the merge sort's padded keys fit
-    constexpr size_t LDS_BYTES = LAST ? (size_t)CAP * 8 + SORT_LARGE_BUCKETS * 4 + 64 : (size_t)CAP * 12 + 64;
+    constexpr size_t LDS_BYTES = LAST ? (size_t)CAP * 8 + SORT_LARGE_BUCKETS * 4 + 128 : (size_t)CAP * 12 + 128;
     static_assert((size_t)THREADS * (E + 1) * 8 <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "lds");
-    static_assert(!LAST || (size_t)(CAP / 2) * 12 + 64 <= LDS_BYTES, "half-capacity image");
+    static_assert(!LAST || (size_t)(CAP / 2) * 12 + 128 <= LDS_BYTES, "half-capacity image");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    __shared__ uint32_t s_cut[PART_MAX_SEGMENTS + 3];
     uint64_t* skeys = reinterpret_cast<uint64_t*>(lds);
     const uint32_t cand = *n_long;
     for (uint32_t k = blockIdx.x; k < cand; k += gridDim.x) {
@@ -599,6 +693,9 @@ __global__ __launch_bounds__(THREADS) void tile_sort_long_kernel(const BinView* 
                 else
                     sorted = bucket_sort_tile<THREADS, E>(lds, bucket, out, n, oo.n_env, oo.last);
                 if (!sorted) merge_sort_tile<THREADS, E>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last);
+            } else if (partition_sort_long<THREADS, E>(lds, s_cut, bucket, reinterpret_cast<uint2*>(alt), out, n, oo.n_env,
+                                                       oo.last)) {
+                // done: depth-partitioned through the alt buffer, every segment sorted in LDS
             } else {
                 uint64_t* gk = reinterpret_cast<uint64_t*>(const_cast<uint2*>(bucket));
                 for (int c0 = 0; c0 < n; c0 += CAP) {

@@ -382,3 +382,18 @@ def test_spatial_order_does_not_change_frames(gpu_device):
     for k in ("color", "depth", "seg", "masks"):
         x, y = out[0][k].float(), out[1][k].float()
         assert torch.equal(x, y) or (x - y).abs().max().item() < 1e-6, k
+
+
+@pytest.mark.parametrize("n,spread", [(120000, 0.05), (300000, 0.08)])
+def test_very_long_lists_depth_partitioned(oracle, gpu_device, n, spread):
+    """Lists of 20-100 k entries with smoothly spread depths: the sort partitions them by depth through the alt
+    buffer and sorts every < 16384-key segment in LDS (tilebin.hip.h partition_sort_long)."""
+    rng = np.random.default_rng(n)
+    cloud, views = scenes.scene_c1(seed=4, n=n)
+    cloud.xyz[:] = rng.normal(0, spread, size=(n, 3)).astype(np.float32)
+    cloud.scaling[:] = np.log(0.004).astype(np.float32)
+    cloud.opacity[:] = rng.normal(-4.0, 0.5, size=(n, 1)).astype(np.float32)   # faint: no early saturation
+    g, o = _run_both(oracle, cloud, views[0], gpu_device)
+    lens = o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]
+    assert lens.max() > 2 * 16384, lens.max()
+    _check_all(g, o)
