@@ -98,7 +98,8 @@ typedef struct PgrSemantic {
 typedef struct PgrWorkspaceView {
     const float *splats;         /* [n,12] per-Gaussian record: x, y, conic A, B, C, opacity, r, g, b, depth, 0, 0
                                     (defined only for Gaussians with a non-empty rectangle) */
-    const uint16_t *rects;       /* [n,4] tile rectangle minx,miny,maxx,maxy (max exclusive); zeros = culled */
+    const uint16_t *rects;       /* [n,4] tile rectangle minx,miny,maxx,maxy (max exclusive); zeros = culled.
+                                    Written only for views rendered WITH a radii output. */
     const uint32_t *gauss_sorted;/* [num_instances] Gaussian index, tile-major, (depth, index) ascending per tile */
     const uint32_t *ranges;      /* [tiles,2] start,end into gauss_sorted */
     const uint32_t *num_instances; /* [0] listed instances, [1] overflow flag */

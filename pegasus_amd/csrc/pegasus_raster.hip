@@ -244,9 +244,9 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         bins[v] = BinView{vw[v].crects, vw[v].splats, vw[v].tile_count, vw[v].rel, vw[v].ranges,
                           vw[v].counters, vw[v].bucket, vw[v].gauss_sorted, vw[v].alt, vw[v].obj_last,
                           semantic ? semantic->n_env : -1};
-        // radii is part of the per-view contract; when the caller does not want it, it lands in the workspace
-        pres[v] = PreOut{vw[v].splats, vw[v].rects, vw[v].crects,
-                         outs[v].radii ? outs[v].radii : vw[v].radii};
+        // radii and the reference-style 3-sigma rectangles are per-view OUTPUTS: written only when the caller asks for
+        // radii (12 N bytes per view the frame path never reads; pgr_workspace_view's `rects` is valid only then)
+        pres[v] = PreOut{vw[v].splats, outs[v].radii ? vw[v].rects : nullptr, vw[v].crects, outs[v].radii};
     }
     if (!hip_ok(hipMemcpyAsync(ws + B.tables, hs, B.tables_bytes, hipMemcpyHostToDevice, stream), "memcpy tables"))
         return PGR_ERR_LAUNCH_FAILURE;

@@ -154,9 +154,9 @@ constexpr int SPLAT_F4 = 3;
 
 struct PreOut {
     float4* splats;          // [n, SPLAT_F4]
-    uint2* rects;            // packed tile rectangle (4 x uint16: minx,miny,maxx,maxy), all zero when culled
+    uint2* rects;            // packed tile rectangle (4 x uint16: minx,miny,maxx,maxy), all zero when culled; NULL = not wanted
     uint2* crects;           // candidate rectangle for binning: rects clipped to the alpha >= 1/255 ellipse's box
-    int32_t* radii;
+    int32_t* radii;          // NULL = not wanted
 };
 
 // SH coefficients of one Gaussian held in registers across the views of a batch.
@@ -340,8 +340,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_batch_kernel(PgrScene sc
                 }
             }
         }
-        o.radii[i] = radius;
-        o.rects[i] = rect;
+        if (o.radii) o.radii[i] = radius;
+        if (o.rects) o.rects[i] = rect;
         o.crects[i] = crect;
     }
 }
