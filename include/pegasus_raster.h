@@ -59,6 +59,10 @@ typedef struct PgrScene {
     int32_t sh_degree;           /* active degree 0..3 */
     int32_t sh_stride;           /* coefficients stored per Gaussian, >= (sh_degree+1)^2 */
     float scale_modifier;
+    const int32_t *tie_index;    /* [n] a permutation of 0..n-1, or NULL = the position itself.  The per-tile order is
+                                    (depth, index): where two depths are EXACTLY equal the smaller tie_index comes
+                                    first.  A scene stored in another order than the caller's (FrameRenderer's Morton
+                                    layout) passes the caller's indices here and renders the caller's image bit for bit. */
 } PgrScene;
 
 /* The fields of GaussianRasterizationSettings that describe one view.  Scalars are host values;

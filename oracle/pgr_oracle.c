@@ -471,7 +471,24 @@ int pgr_oracle_forward(const PgrOracleIn *in, PgrOracleOut *out, int num_threads
             kept[i] = c;
         }
     }
-    for (int32_t i = 0; i < n; ++i) { total += kept[i]; offs[i] = total; }
+    /* emission order = ascending tie index (the position itself without one): the stable sort below then breaks
+     * exact depth ties by it */
+    if (in->tie_index) {
+        int32_t *seq = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+        for (int32_t i = 0; i < n; ++i) seq[i] = -1;
+        for (int32_t i = 0; i < n; ++i) {
+            const int32_t k = in->tie_index[i];
+            if (k >= 0 && k < n) seq[k] = i;
+        }
+        for (int32_t j = 0; j < n; ++j) {
+            const int32_t i = seq[j];
+            if (i < 0) { rc = -1; continue; }       /* not a permutation */
+            total += kept[i]; offs[i] = total;
+        }
+        free(seq);
+    } else {
+        for (int32_t i = 0; i < n; ++i) { total += kept[i]; offs[i] = total; }
+    }
     out->num_instances = total;
 
     uint64_t *keys = NULL;

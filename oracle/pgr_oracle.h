@@ -72,6 +72,8 @@ typedef struct PgrOracleIn {
     const int32_t *object_id;       /* [n] or NULL */
     const float *poses;             /* [k_objects, PGR_POSE_STRIDE]: R[9] row-major, t[3], center[3], q[4] (w,x,y,z), pad */
     int32_t k_objects;
+    const int32_t *tie_index;       /* [n] permutation or NULL: exact depth ties are broken by tie_index instead of the
+                                       position (include/pegasus_raster.h PgrScene::tie_index) */
 } PgrOracleIn;
 #define PGR_POSE_STRIDE 20
 

@@ -107,7 +107,7 @@ static ViewWs carve(char* ws, const Layout& L) {
 
 // Batch header placed in front of the per-view slices.
 struct BatchLayout {
-    size_t tables, cams, status, tile_counts, order_state, work_order, long_list, views, total;
+    size_t tables, cams, status, tile_counts, order_state, work_order, long_list, tie_inv, views, total;
     size_t view_table_off, bin_table_off, pre_table_off, tables_bytes;   // inside `tables` (one H2D copy)
     size_t order_slots;
     size_t per_view;
@@ -119,7 +119,7 @@ static size_t host_scratch_bytes(int n_views) {
            align_up((size_t)n_views * sizeof(PreOut), 16) + (size_t)n_views * 8;
 }
 
-static BatchLayout make_batch_layout(const Layout& L, int n_views) {
+static BatchLayout make_batch_layout(const Layout& L, int n_views, size_t n_scene) {
     BatchLayout B{};
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes ? bytes : 1); return o; };
@@ -136,6 +136,7 @@ static BatchLayout make_batch_layout(const Layout& L, int n_views) {
     B.order_slots = (size_t)NUM_XCD * max_band_rows(L.grid_y) * L.grid_x * ITEMS_PER_TILE * n_views;
     B.work_order = take(B.order_slots * 4);
     B.long_list = take((size_t)n_views * L.tiles * 4);
+    B.tie_inv = take((size_t)n_scene * 4);     // inverse of PgrScene::tie_index (filled only when one is given)
     B.views = off;
     B.per_view = align_up(L.total);
     B.total = off + (size_t)n_views * B.per_view;
@@ -201,7 +202,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
 
     if (!workspace) return PGR_ERR_INVALID_ARGUMENT;
     const Layout L = make_layout(N, W, H, max_instances);
-    const BatchLayout B = make_batch_layout(L, n_views);
+    const BatchLayout B = make_batch_layout(L, n_views, (size_t)N);
     if (workspace_bytes < B.total) return PGR_ERR_WORKSPACE_TOO_SMALL;
     char* ws = static_cast<char*>(workspace);
     auto* view_table = reinterpret_cast<ViewEntry*>(ws + B.tables + B.view_table_off);
@@ -243,7 +244,8 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         want_aux = want_aux || outs[v].final_T || outs[v].n_contrib;
         bins[v] = BinView{vw[v].crects, vw[v].splats, vw[v].tile_count, vw[v].rel, vw[v].ranges,
                           vw[v].counters, vw[v].bucket, vw[v].gauss_sorted, vw[v].alt, vw[v].obj_last,
-                          semantic ? semantic->n_env : -1};
+                          semantic ? semantic->n_env : -1, scene->tie_index,
+                          scene->tie_index ? reinterpret_cast<const uint32_t*>(ws + B.tie_inv) : nullptr};
         // radii and the reference-style 3-sigma rectangles are per-view OUTPUTS: written only when the caller asks for
         // radii (12 N bytes per view the frame path never reads; pgr_workspace_view's `rects` is valid only then)
         pres[v] = PreOut{vw[v].splats, outs[v].radii ? vw[v].rects : nullptr, vw[v].crects, outs[v].radii};
@@ -253,6 +255,9 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
 
     // ---- stage 0: camera pack + per-Gaussian preprocess
     mark(0);
+    if (scene->tie_index)
+        invert_tie_index_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, scene->tie_index,
+                                                                      reinterpret_cast<uint32_t*>(ws + B.tie_inv));
     for (int v0 = 0; v0 < n_views; v0 += CAM_PACK_MAX) {
         CamPack cp;
         const int cnt = std::min(CAM_PACK_MAX, n_views - v0);
@@ -363,7 +368,7 @@ const char* pgr_last_hip_error(void) { return g_hip_error; }
 size_t pgr_batch_workspace_bytes(int32_t n, int32_t width, int32_t height, int64_t max_instances, int32_t n_views) {
     if (n < 0 || width <= 0 || height <= 0 || max_instances < 0 || max_instances > 0x7fffffffLL || n_views <= 0)
         return 0;
-    return make_batch_layout(make_layout(n, width, height, max_instances), n_views).total;
+    return make_batch_layout(make_layout(n, width, height, max_instances), n_views, (size_t)n).total;
 }
 
 size_t pgr_workspace_bytes(int32_t n, int32_t width, int32_t height, int64_t max_instances) {
@@ -376,7 +381,7 @@ int32_t pgr_workspace_view(void* workspace, size_t workspace_bytes, int32_t n, i
         view_index < 0 || view_index >= n_views)
         return PGR_ERR_INVALID_ARGUMENT;
     const Layout L = make_layout(n, width, height, max_instances);
-    const BatchLayout B = make_batch_layout(L, n_views);
+    const BatchLayout B = make_batch_layout(L, n_views, (size_t)n);
     if (workspace_bytes < B.total) return PGR_ERR_WORKSPACE_TOO_SMALL;
     const ViewWs w = carve(static_cast<char*>(workspace) + B.views + (size_t)view_index * B.per_view, L);
     v->splats = reinterpret_cast<const float*>(w.splats);
@@ -477,7 +482,7 @@ int32_t pgr_backward(const PgrScene* scene, const PgrCamera* cam, const float* g
     if (N == 0) return PGR_OK;
     if (!workspace || !grad_rows || !radii) return PGR_ERR_INVALID_ARGUMENT;
     const Layout L = make_layout(N, W, H, max_instances);
-    const BatchLayout B = make_batch_layout(L, 1);
+    const BatchLayout B = make_batch_layout(L, 1, (size_t)N);
     if (workspace_bytes < B.total) return PGR_ERR_WORKSPACE_TOO_SMALL;
     char* ws = static_cast<char*>(workspace);
     const ViewWs vw = carve(ws + B.views, L);

@@ -48,6 +48,13 @@ struct BinView {                 // per-view pointers used by the binning kernel
     uint64_t* alt;               // [max_instances] second key buffer for lists beyond the LDS tiers
     uint32_t* obj_last;          // [tiles] zero-filled; 1 + position of the last object entry of the sorted list
     int32_t n_env;               // Gaussians < n_env are environment; < 0: no semantic pass wanted
+    // Exact depth ties are broken by tie_index[i] instead of the position i (PgrScene::tie_index: a scene stored in
+    // another order than the caller's keeps the caller's tie order).  Lists are sorted by (depth, position) as always;
+    // the bucket sort then looks the tie index up for the few keys that share their depth with another key of the
+    // list and corrects their ranks; the merge-sort fallback (piled-up depths) sorts (depth, tie index) keys and maps
+    // them back to positions through tie_inv.  NULL = the position is the tie index.
+    const int32_t* tie_index;
+    const uint32_t* tie_inv;
 };
 
 
@@ -189,6 +196,14 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restr
     }
 }
 
+// tie_inv[tie_index[i]] = i  (tie_index is a permutation; entries out of range are ignored)
+__global__ void invert_tie_index_kernel(int n, const int32_t* __restrict__ tie_index, uint32_t* __restrict__ tie_inv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int k = tie_index[i];
+    if ((unsigned)k < (unsigned)n) tie_inv[k] = (uint32_t)i;
+}
+
 // one workgroup per view
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const BinView* __restrict__ views, int tiles,
                                                          uint32_t max_instances) {
@@ -234,6 +249,9 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const BinView* __restri
 // from HBM once (8 B/entry) and the sorted indices written once (4 B/entry).
 
 constexpr uint64_t KEY_INF = ~0ull;
+
+// low word of a sort key -> position; inv == NULL: they are the same
+__device__ __forceinline__ uint32_t key_to_pos(const uint32_t* __restrict__ inv, uint32_t tk) { return inv ? inv[tk] : tk; }
 
 template <int E>
 __device__ __forceinline__ void register_sort(uint64_t (&r)[E]) {
@@ -293,7 +311,8 @@ template <int THREADS, int E>
 __device__ __forceinline__ void merge_sort_tile(uint64_t* __restrict__ skeys, const uint2* __restrict__ bucket,
                                                 uint32_t* __restrict__ out, int n, uint64_t* keys_out = nullptr,
                                                 int n_env = -1, uint32_t* __restrict__ obj_last = nullptr,
-                                                uint32_t pos_offset = 0) {
+                                                uint32_t pos_offset = 0, const int32_t* __restrict__ tie = nullptr,
+                                                const uint32_t* __restrict__ inv = nullptr) {
     const int t = threadIdx.x;
     uint64_t r[E];
     // the list is unordered, so WHICH keys a thread starts with is free: take them coalesced
@@ -303,7 +322,7 @@ __device__ __forceinline__ void merge_sort_tile(uint64_t* __restrict__ skeys, co
         uint64_t k = KEY_INF;
         if (i < n) {
             const uint2 v = bucket[i];
-            k = ((uint64_t)v.x << 32) | v.y;
+            k = ((uint64_t)v.x << 32) | (tie ? (uint32_t)tie[v.y] : v.y);
         }
         r[e] = k;
     }
@@ -343,9 +362,10 @@ __device__ __forceinline__ void merge_sort_tile(uint64_t* __restrict__ skeys, co
     if (keys_out) {
         for (int i = t; i < n; i += THREADS) keys_out[i] = skeys[pad_idx<E>(i)];
     } else {
-        for (int i = t; i < n; i += THREADS) out[i] = (uint32_t)skeys[pad_idx<E>(i)];
+        for (int i = t; i < n; i += THREADS) out[i] = key_to_pos(inv, (uint32_t)skeys[pad_idx<E>(i)]);
         if (n_env >= 0)
-            mark_last_object<THREADS>([&](int i) { return (uint32_t)skeys[pad_idx<E>(i)]; }, n, n_env, obj_last, pos_offset);
+            mark_last_object<THREADS>([&](int i) { return key_to_pos(inv, (uint32_t)skeys[pad_idx<E>(i)]); }, n, n_env, obj_last,
+                                      pos_offset);
     }
 }
 
@@ -372,7 +392,8 @@ constexpr uint32_t BUCKET_SQ_LIMIT = 8;
 template <int THREADS, int E, int NB = THREADS * E, bool DIRECT = false>
 __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds, const uint2* __restrict__ bucket,
                                                  uint32_t* __restrict__ out, int n, int n_env,
-                                                 uint32_t* __restrict__ obj_last, uint32_t pos_offset = 0) {
+                                                 uint32_t* __restrict__ obj_last, uint32_t pos_offset = 0,
+                                                 const int32_t* __restrict__ tie = nullptr) {
     constexpr int CAP = THREADS * E, WAVES = THREADS / WAVE, CH = NB / (WAVES * WAVE);   // 64-bucket chunks per wave
     static_assert(NB % (WAVES * WAVE) == 0 && (DIRECT || NB >= CAP), "bucket count");
     static_assert((4 + WAVES) * 4 <= 128, "s_misc must fit the 128 bytes the callers reserve behind the counters");
@@ -463,8 +484,23 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
             const uint32_t b = br[e] >> 16;
             const uint32_t s0 = s_hist[b], s1 = b + 1 < (uint32_t)NB ? s_hist[b + 1] : (uint32_t)n;
             const uint64_t key = ((uint64_t)d[e] << 32) | id[e];
-            uint32_t rank = 0;
-            for (uint32_t j = s0; j < s1; ++j) rank += s_keys[j] < key ? 1u : 0u;
+            uint32_t rank = 0, same = 0;             // same: members with this key's depth bits (itself included)
+            for (uint32_t j = s0; j < s1; ++j) {
+                const uint64_t kj = s_keys[j];
+                rank += kj < key ? 1u : 0u;
+                same += (uint32_t)(kj >> 32) == d[e] ? 1u : 0u;
+            }
+            if (tie && same > 1u) {
+                // exact depth tie between different Gaussians: the CALLER's index decides (a few keys per list;
+                // measured: cheaper than carrying the tie index in the bucket entries or in the LDS keys)
+                const int32_t mine = tie[id[e]];
+                rank = 0;
+                for (uint32_t j = s0; j < s1; ++j) {
+                    const uint64_t kj = s_keys[j];
+                    const uint32_t dj = (uint32_t)(kj >> 32);
+                    rank += (dj < d[e] || (dj == d[e] && (uint32_t)kj != id[e] && tie[(uint32_t)kj] < mine)) ? 1u : 0u;
+                }
+            }
             fin[e] = s0 + rank;
         }
     }
@@ -510,7 +546,8 @@ template <int THREADS, int E>
 __device__ __forceinline__ bool partition_sort_long(unsigned char* __restrict__ lds, uint32_t* __restrict__ s_cut,
                                                     const uint2* __restrict__ bucket, uint2* __restrict__ alt,
                                                     uint32_t* __restrict__ out, int n, int n_env,
-                                                    uint32_t* __restrict__ obj_last) {
+                                                    uint32_t* __restrict__ obj_last, const int32_t* __restrict__ tie,
+                                                    const uint32_t* __restrict__ inv) {
     constexpr int CAP = THREADS * E, HALF = CAP / 2, WAVES = THREADS / WAVE, CH = PART_BUCKETS / (WAVES * WAVE);
     static_assert(PART_BUCKETS % (WAVES * WAVE) == 0, "bucket count");
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(lds);         // [PART_BUCKETS] counts -> starts -> cursors
@@ -580,8 +617,9 @@ __device__ __forceinline__ bool partition_sort_long(unsigned char* __restrict__ 
         const uint32_t a = s_cut[g];
         if (a >= (uint32_t)n) break;
         const int n_seg = (int)(s_cut[g + 1] - a);
-        if (!bucket_sort_tile<THREADS, E, SORT_LARGE_BUCKETS, true>(lds, alt + a, out + a, n_seg, n_env, obj_last, a))
-            merge_sort_tile<THREADS, E>(reinterpret_cast<uint64_t*>(lds), alt + a, out + a, n_seg, nullptr, n_env, obj_last, a);
+        if (!bucket_sort_tile<THREADS, E, SORT_LARGE_BUCKETS, true>(lds, alt + a, out + a, n_seg, n_env, obj_last, a, tie))
+            merge_sort_tile<THREADS, E>(reinterpret_cast<uint64_t*>(lds), alt + a, out + a, n_seg, nullptr, n_env, obj_last, a,
+                                        tie, inv);
         __syncthreads();
     }
     return true;
@@ -619,7 +657,7 @@ __device__ __forceinline__ void merge_round_global(const uint64_t* __restrict__ 
 constexpr int SORT_SMALL_MAX = SORT_THREADS * 8;       // 2048 keys, 24 KiB of LDS: six workgroups per CU
 
 // item = view * tiles + tile
-struct ObjOut { int n_env; uint32_t* last; };
+struct ObjOut { int n_env; uint32_t* last; const int32_t* tie; const uint32_t* inv; };
 
 __device__ __forceinline__ bool sort_item(const BinView* __restrict__ views, int tiles, uint32_t item,
                                           const uint2*& bucket, uint32_t*& out, int& n, ObjOut& oo,
@@ -632,7 +670,7 @@ __device__ __forceinline__ bool sort_item(const BinView* __restrict__ views, int
     n = (int)(range.y - range.x);
     bucket = bv.bucket + range.x;
     out = bv.gauss_sorted + range.x;
-    oo = ObjOut{bv.n_env, bv.obj_last + tile};
+    oo = ObjOut{bv.n_env, bv.obj_last + tile, bv.tie_index, bv.tie_inv};
     if (alt) *alt = bv.alt + range.x;
     return n > 0;
 }
@@ -645,14 +683,14 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* 
     if (!sort_item(views, tiles, blockIdx.x, bucket, out, n, oo)) return;
     if (n > SORT_SMALL_MAX) return;                      // the long tiers'
     if (n <= SORT_THREADS * 2) {
-        if (!bucket_sort_tile<SORT_THREADS, 2>(lds, bucket, out, n, oo.n_env, oo.last))
-            merge_sort_tile<SORT_THREADS, 2>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last);
+        if (!bucket_sort_tile<SORT_THREADS, 2>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+            merge_sort_tile<SORT_THREADS, 2>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
     } else if (n <= SORT_THREADS * 4) {
-        if (!bucket_sort_tile<SORT_THREADS, 4>(lds, bucket, out, n, oo.n_env, oo.last))
-            merge_sort_tile<SORT_THREADS, 4>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last);
+        if (!bucket_sort_tile<SORT_THREADS, 4>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+            merge_sort_tile<SORT_THREADS, 4>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
     } else {
-        if (!bucket_sort_tile<SORT_THREADS, 8>(lds, bucket, out, n, oo.n_env, oo.last))
-            merge_sort_tile<SORT_THREADS, 8>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last);
+        if (!bucket_sort_tile<SORT_THREADS, 8>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+            merge_sort_tile<SORT_THREADS, 8>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
     }
 }
 
@@ -684,22 +722,22 @@ __global__ __launch_bounds__(THREADS) void tile_sort_long_kernel(const BinView* 
         const bool mine = n > LO && (LAST || n <= CAP);
         if (ok && mine) {
             if (LAST && n <= CAP / 2) {
-                if (!bucket_sort_tile<THREADS, E / 2>(lds, bucket, out, n, oo.n_env, oo.last))
-                    merge_sort_tile<THREADS, E / 2>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last);
+                if (!bucket_sort_tile<THREADS, E / 2>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+                    merge_sort_tile<THREADS, E / 2>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
             } else if (n <= CAP) {
                 bool sorted;
                 if constexpr (LAST)
-                    sorted = bucket_sort_tile<THREADS, E, SORT_LARGE_BUCKETS, true>(lds, bucket, out, n, oo.n_env, oo.last);
+                    sorted = bucket_sort_tile<THREADS, E, SORT_LARGE_BUCKETS, true>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie);
                 else
-                    sorted = bucket_sort_tile<THREADS, E>(lds, bucket, out, n, oo.n_env, oo.last);
-                if (!sorted) merge_sort_tile<THREADS, E>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last);
+                    sorted = bucket_sort_tile<THREADS, E>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie);
+                if (!sorted) merge_sort_tile<THREADS, E>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
             } else if (partition_sort_long<THREADS, E>(lds, s_cut, bucket, reinterpret_cast<uint2*>(alt), out, n, oo.n_env,
-                                                       oo.last)) {
+                                                       oo.last, oo.tie, oo.inv)) {
                 // done: depth-partitioned through the alt buffer, every segment sorted in LDS
             } else {
                 uint64_t* gk = reinterpret_cast<uint64_t*>(const_cast<uint2*>(bucket));
                 for (int c0 = 0; c0 < n; c0 += CAP) {
-                    merge_sort_tile<THREADS, E>(skeys, bucket + c0, nullptr, min(CAP, n - c0), gk + c0);
+                    merge_sort_tile<THREADS, E>(skeys, bucket + c0, nullptr, min(CAP, n - c0), gk + c0, -1, nullptr, 0u, oo.tie);
                     __syncthreads();
                 }
                 uint64_t *src = gk, *dst = alt;
@@ -708,8 +746,9 @@ __global__ __launch_bounds__(THREADS) void tile_sort_long_kernel(const BinView* 
                     __syncthreads();
                     uint64_t* tmp = src; src = dst; dst = tmp;
                 }
-                for (int i = threadIdx.x; i < n; i += THREADS) out[i] = (uint32_t)src[i];
-                if (oo.n_env >= 0) mark_last_object<THREADS>([&](int i) { return (uint32_t)src[i]; }, n, oo.n_env, oo.last);
+                for (int i = threadIdx.x; i < n; i += THREADS) out[i] = key_to_pos(oo.inv, (uint32_t)src[i]);
+                if (oo.n_env >= 0)
+                    mark_last_object<THREADS>([&](int i) { return key_to_pos(oo.inv, (uint32_t)src[i]); }, n, oo.n_env, oo.last);
             }
         }
         __syncthreads();   // LDS reuse across loop iterations

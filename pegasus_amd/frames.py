@@ -42,6 +42,9 @@ class FrameRenderer:
             means3d, opacities, scales, rotations, shs, object_id = (
                 pick(a) for a in (means3d, opacities, scales, rotations, shs, object_id))
             self.order = perm
+        # the resident copy keeps the CALLER's tie order: exact depth ties are broken by the caller's index, so the
+        # frames are bit-identical to rendering the arrays as passed (PgrScene.tie_index)
+        self.tie_index = None if self.order is None else torch.from_numpy(self.order.astype(np.int32)).to(self.device)
         t = lambda a, dt=torch.float32: torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a
                                                         ).to(self.device, dt).contiguous()
         self.means3d, self.opacities, self.scales, self.rotations, self.shs = (
@@ -70,6 +73,8 @@ class FrameRenderer:
             s = slice(self.n_env, self.n)
             self.obj = dict(means3d=self.means3d[s], opacities=self.opacities[s], scales=self.scales[s],
                             rotations=self.rotations[s])
+            # tie order of the objects-only cloud: the caller's order of the object Gaussians among themselves
+            self.obj_tie_index = None if self.tie_index is None else (self.tie_index[s] - self.n_env).contiguous()
 
     def view_spec(self, view) -> R.ViewSpec:
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
@@ -117,7 +122,7 @@ class FrameRenderer:
                 outs[i]["sem_color"], outs[i]["sem_depth"] = frames["seg"][i], frames["seg_depth"][i]
         st.wait_stream(cur)
         with torch.cuda.stream(st):
-            h = R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales,
+            h = R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales, tie_index=self.tie_index,
                                 rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False, outputs=outs,
                                 async_slot=("frames", slot), semantic=self.semantic if fused else None,
                                 posed=self._posed(poses, B))
@@ -156,7 +161,7 @@ class FrameRenderer:
         outs = [dict(color=frames["color"][i], depth=frames["depth"][i], radii=None) for i in range(B)]
         s_scene.wait_stream(cur)
         with torch.cuda.stream(s_scene):
-            h1 = R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales,
+            h1 = R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales, tie_index=self.tie_index,
                                  rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False, outputs=outs,
                                  async_slot=("scene", slot))
         h2 = None
@@ -164,7 +169,7 @@ class FrameRenderer:
             souts = [dict(color=frames["seg"][i], depth=frames["seg_depth"][i], radii=None) for i in range(B)]
             s_sem.wait_stream(cur)
             with torch.cuda.stream(s_sem):
-                h2 = R.forward_views(self.obj["means3d"], self.obj["opacities"], specs, shs=self.sem_shs,
+                h2 = R.forward_views(self.obj["means3d"], self.obj["opacities"], specs, shs=self.sem_shs, tie_index=self.obj_tie_index,
                                      scales=self.obj["scales"], rotations=self.obj["rotations"], sh_degree=0,
                                      want_radii=False, outputs=souts, async_slot=("sem", slot))
                 M.color_masks(frames["seg"][:B], self.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])
@@ -201,7 +206,7 @@ class FrameRenderer:
         if fused:
             for i in range(B):
                 outs[i]["sem_color"], outs[i]["sem_depth"] = frames["seg"][i], frames["seg_depth"][i]
-        R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales,
+        R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales, tie_index=self.tie_index,
                         rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False, outputs=outs,
                         stage_ms=stage_ms, semantic=self.semantic if fused else None, posed=self._posed(poses, B))
         if fused:
@@ -217,12 +222,12 @@ class FrameRenderer:
         if frames is None:
             frames = self.alloc_frames(B, H, W, masks)
         outs = [dict(color=frames["color"][i], depth=frames["depth"][i], radii=None) for i in range(B)]
-        R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales,
+        R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales, tie_index=self.tie_index,
                         rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False, outputs=outs,
                         stage_ms=stage_ms)
         if masks and self.K:
             souts = [dict(color=frames["seg"][i], depth=frames["seg_depth"][i], radii=None) for i in range(B)]
-            R.forward_views(self.obj["means3d"], self.obj["opacities"], specs, shs=self.sem_shs,
+            R.forward_views(self.obj["means3d"], self.obj["opacities"], specs, shs=self.sem_shs, tie_index=self.obj_tie_index,
                             scales=self.obj["scales"], rotations=self.obj["rotations"], sh_degree=0,
                             want_radii=False, outputs=souts, stage_ms=sem_stage_ms)
             M.color_masks(frames["seg"][:B], self.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])

@@ -110,7 +110,7 @@ class PendingBatch:
 def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, colors_precomp=None, scales=None,
                   rotations=None, cov3D_precomp=None, sh_degree=0, scale_modifier=1.0, want_radii=True,
                   want_aux=False, stage_ms: Optional[list] = None, outputs: Optional[list] = None,
-                  async_slot=None, semantic: Optional[dict] = None, posed: Optional[dict] = None):
+                  async_slot=None, semantic: Optional[dict] = None, posed: Optional[dict] = None, tie_index=None):
     """Renders ``len(views)`` views of one scene.  Returns a list of dicts with keys
     color[3,H,W], depth[1,H,W], radii[N] (or None), and final_T / n_contrib when ``want_aux``.
 
@@ -121,6 +121,7 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
     PendingBatch; the slot names the workspace / pinned scratch to use (one batch in flight per slot).
     ``semantic``: dict(object_id int32[N], colors float32[K,3], n_env, k) -> the fused objects-only semantic
     render is written to r["sem_color"] (and r["sem_depth"]) of every view (pgr_forward_frames_async).
+    ``tie_index``: int32[N] permutation -- exact depth ties are broken by it instead of the position (PgrScene.tie_index).
     ``posed``: dict(object_id int32[N], poses float32[len(views), K, 20]) -> dynamic scene: view i places object k by
     poses[i, k-1] inside the preprocess (pgr_forward_posed_async; pegasus_amd.compose.pose_table builds the rows).
     """
@@ -145,7 +146,7 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
         n=n, means3d=_ptr(means3D), opacities=_ptr(opacities), scales=_ptr(scales), rotations=_ptr(rotations),
         cov3d_precomp=_ptr(cov3D_precomp), shs=_ptr(shs), colors_precomp=_ptr(colors_precomp),
         sh_degree=int(sh_degree), sh_stride=int(shs.shape[1]) if shs is not None else 0,
-        scale_modifier=float(scale_modifier))
+        scale_modifier=float(scale_modifier), tie_index=_ptr(tie_index))
 
     cams = (_lib.PgrCamera * nv)()
     outs = (_lib.PgrOutputs * nv)()
@@ -196,7 +197,8 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
         if async_slot is None and stage_ms is None:      # synchronous fused call: enqueue asynchronously, wait, retry on overflow
             kw = dict(shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
                       cov3D_precomp=cov3D_precomp, sh_degree=sh_degree, scale_modifier=scale_modifier,
-                      want_radii=want_radii, want_aux=want_aux, outputs=results, semantic=semantic, posed=posed)
+                      want_radii=want_radii, want_aux=want_aux, outputs=results, semantic=semantic, posed=posed,
+                      tie_index=tie_index)
             for _attempt in range(3):
                 pb = forward_views(means3D, opacities, views, async_slot="sync-fused", **kw)
                 pb._redo = None
@@ -223,7 +225,8 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
             ev.record(torch.cuda.current_stream(device))
         kw = dict(shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
                   cov3D_precomp=cov3D_precomp, sh_degree=sh_degree, scale_modifier=scale_modifier,
-                  want_radii=want_radii, want_aux=want_aux, outputs=results, semantic=semantic, posed=posed)
+                  want_radii=want_radii, want_aux=want_aux, outputs=results, semantic=semantic, posed=posed,
+                      tie_index=tie_index)
         redo = lambda: forward_views(means3D, opacities, views, **kw)
         pb = PendingBatch(results, ev, scratch, nv, key, max_inst, redo)
         pb._keep = (keep, ws, cams, outs, scene)

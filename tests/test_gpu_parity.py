@@ -251,14 +251,14 @@ def test_frame_renderer_rgb_depth_masks(oracle, gpu_device):
     assert fr.order is not None               # resident copy is in Morton order per object: same for the oracle
     act = {k: np.ascontiguousarray(a[fr.order]) for k, a in act.items()}
     for i, v in enumerate(views):
-        o = oracle.forward(**act, sh_degree=3, **v.raster_kwargs(), num_threads=8)
+        o = oracle.forward(**act, sh_degree=3, **v.raster_kwargs(), num_threads=8, tie_index=fr.order)
         g = dict(color=out["color"][i].cpu().numpy(), out_depth=out["depth"][i].cpu().numpy())
         amb = o["ambig"].astype(bool)
         assert np.abs(g["color"] - o["color"])[:, ~amb].max() <= 1e-4
         assert np.abs(g["out_depth"] - o["out_depth"])[:, ~amb].max() <= 1e-4
         so = oracle.forward(act["means3d"][n_env:], act["opacities"][n_env:], scales=act["scales"][n_env:],
                             rotations=act["rotations"][n_env:], shs=sem_shs, sh_degree=0, **v.raster_kwargs(),
-                            num_threads=8)
+                            num_threads=8, tie_index=fr.order[n_env:] - n_env)
         samb = so["ambig"].astype(bool)
         seg = out["seg"][i].cpu().numpy()
         assert np.abs(seg - so["color"])[:, ~samb].max() <= 1e-4
@@ -363,8 +363,8 @@ def test_single_gaussian_and_two_pixel_image(oracle, gpu_device):
 
 @pytest.mark.gpu
 def test_spatial_order_does_not_change_frames(gpu_device):
-    """FrameRenderer stores the scene in Morton order per object (scene_order.py); lists are depth-ordered, so the
-    frames are those of the input order (exact depth ties are the only index-dependent case)."""
+    """FrameRenderer stores the scene in Morton order per object (scene_order.py); lists are depth-ordered and exact
+    depth ties are broken by the caller's index, so the frames are those of the input order, bit for bit."""
     import torch
     from pegasus_amd import scenes
     from pegasus_amd.frames import FrameRenderer
@@ -379,9 +379,8 @@ def test_spatial_order_does_not_change_frames(gpu_device):
         out.append({k: v.clone() for k, v in f.items()})
     perm = fr.order
     assert sorted(perm.tolist()) == list(range(cloud.n)) and np.all(np.diff(cloud.object_id[perm]) >= 0)
-    for k in ("color", "depth", "seg", "masks"):
-        x, y = out[0][k].float(), out[1][k].float()
-        assert torch.equal(x, y) or (x - y).abs().max().item() < 1e-6, k
+    for k in ("color", "depth", "seg", "masks"):      # exact depth ties keep the caller's order (PgrScene.tie_index)
+        assert torch.equal(out[0][k], out[1][k]), k
 
 
 @pytest.mark.parametrize("n,spread", [(120000, 0.05), (300000, 0.08)])
@@ -397,3 +396,37 @@ def test_very_long_lists_depth_partitioned(oracle, gpu_device, n, spread):
     lens = o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]
     assert lens.max() > 2 * 16384, lens.max()
     _check_all(g, o)
+
+
+@pytest.mark.parametrize("n,spread,equal", [(16000, 0.02, True), (90000, 0.05, True), (120000, 0.05, False)])
+def test_tie_index_order_on_long_lists(oracle, gpu_device, n, spread, equal):
+    """PgrScene.tie_index: exact depth ties (thousands of them here) follow an arbitrary caller permutation through
+    every sort path (bucket sort with 12-byte entries, merge-sort fallback, depth-partitioned and L2-merged lists);
+    lists bit-exact against the oracle with the same tie_index."""
+    import torch
+    from helpers import fetch_workspace
+    from pegasus_amd import rasterizer as R
+    rng = np.random.default_rng(n + 1)
+    cloud, views = scenes.scene_c1(seed=3, n=n)
+    cloud.xyz[:] = rng.normal(0, spread, size=(n, 3)).astype(np.float32)
+    if equal:
+        cloud.xyz[: n // 3, 2] = np.float32(0.125)
+    cloud.scaling[:] = np.log(0.004).astype(np.float32)
+    cloud.opacity[:] = rng.normal(-4.0, 0.5, size=(n, 1)).astype(np.float32)
+    tie = rng.permutation(n).astype(np.int32)
+    act, v = cloud.activated(), views[0]
+    o = oracle.forward(**act, sh_degree=3, **v.raster_kwargs(), num_threads=8, cull_mode=1, tie_index=tie)
+    o_pos = oracle.forward(**act, sh_degree=3, **v.raster_kwargs(), num_threads=8, cull_mode=1)
+    if equal:
+        assert not np.array_equal(o["gauss_sorted"], o_pos["gauss_sorted"])      # the tie order does matter here
+    t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(gpu_device, dt)
+    spec = R.ViewSpec(v.height, v.width, v.tanfovx, v.tanfovy, t(np.zeros(3, np.float32)), t(v.world_view_transform),
+                      t(v.full_proj_transform), t(v.camera_center))
+    res = R.forward_views(t(act["means3d"]), t(act["opacities"]), [spec], shs=t(act["shs"]), scales=t(act["scales"]),
+                          rotations=t(act["rotations"]), sh_degree=3, want_radii=True, want_aux=True,
+                          tie_index=t(tie, torch.int32))
+    torch.cuda.synchronize()
+    w = fetch_workspace(0, n, v.width, v.height)
+    np.testing.assert_array_equal(w["gauss_sorted"], o["gauss_sorted"])
+    amb = o["ambig"].astype(bool)
+    assert np.abs(res[0]["color"].cpu().numpy() - o["color"])[:, ~amb].max() <= 1e-4

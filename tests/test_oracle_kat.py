@@ -211,3 +211,24 @@ def test_masks_and_quantisation_match_numpy(oracle):
     rgb8, mm = oracle.quantize(img, depth)
     np.testing.assert_array_equal(rgb8, (hwc * 255).astype(np.uint8))
     np.testing.assert_array_equal(mm, (depth * 1000).astype(np.uint16))
+
+
+def test_tie_index_breaks_exact_depth_ties(oracle):
+    """Two coincident-depth Gaussians overlapping a pixel: the smaller tie_index is blended first, whatever the
+    storage order (PgrScene.tie_index / PgrOracleIn.tie_index)."""
+    import numpy as np
+    from pegasus_amd import scenes
+    _, views = scenes.scene_c1(n=16)
+    v = views[0]
+    mk = lambda order: dict(
+        means3d=np.array([[0.0, 0.0, 0.0], [0.0, 0.0, 0.0]], np.float32)[order],
+        opacities=np.array([0.6, 0.6], np.float32)[order],
+        scales=np.full((2, 3), 0.05, np.float32), rotations=np.tile(np.array([1, 0, 0, 0], np.float32), (2, 1)),
+        colors_precomp=np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]], np.float32)[order])
+    a = oracle.forward(**mk([0, 1]), **v.raster_kwargs(), num_threads=1)
+    b = oracle.forward(**mk([1, 0]), **v.raster_kwargs(), num_threads=1)                       # stored swapped
+    c = oracle.forward(**mk([1, 0]), **v.raster_kwargs(), num_threads=1, tie_index=[1, 0])     # ... with the caller's order
+    cy, cx = v.height // 2, v.width // 2
+    assert a["color"][0, cy, cx] > a["color"][1, cy, cx] and b["color"][1, cy, cx] > b["color"][0, cy, cx]
+    np.testing.assert_array_equal(a["color"], c["color"])
+    np.testing.assert_array_equal(c["gauss_sorted"][:4] ^ 1, a["gauss_sorted"][:4])   # positions differ, order by tie index
