@@ -221,6 +221,14 @@ int32_t pgr_compose_object(int32_t n, const float *xyz, const float *rot, const 
                            int32_t in_rest_stride, const PgrObjectPose *pose, float *out_xyz, float *out_rot,
                            float *out_rest, int32_t out_rest_stride, void *stream);
 
+/* Mean squared distance to the 3 nearest neighbours of every point (replaces simple_knn._C.distCUDA2 of the reference's
+ * second absent submodule: GaussianModel.create_from_pcd, /root/reference/src/gs/gaussian_model.py:25,147).  Exact
+ * 3-NN over a device-built uniform grid; with fewer than 4 points the missing neighbours count as FLT_MAX, as upstream.
+ * `xyz` [n,3] and `out` [n] are device pointers; workspace of pgr_knn_workspace_bytes(n) bytes. */
+size_t pgr_knn_workspace_bytes(int32_t n);
+int32_t pgr_knn_mean_dist2(int32_t n, const float *xyz, float *out, void *workspace, size_t workspace_bytes,
+                           void *stream);
+
 /* Gradients returned by pgr_backward (device pointers, any may be NULL = not wanted). */
 typedef struct PgrGradOutputs {
     float *means2d;              /* [n,3] screen-space mean, NDC-scaled (what viewspace_points.grad receives) */

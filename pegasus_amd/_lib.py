@@ -104,6 +104,8 @@ SYMBOLS = {
     "pgr_mark_visible": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgr_color_masks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
                                     C.c_void_p, C.c_void_p]),
+    "pgr_knn_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "pgr_knn_mean_dist2": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pgr_quantize_frame": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
 }

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "backward.hip.h"
+#include "knn.hip.h"
 #include "compose.hip.h"
 #include "composite.hip.h"
 #include "pgr_common.h"
@@ -568,3 +569,56 @@ extern "C" int32_t pgr_debug_sort_stats(unsigned long long* out, int32_t reset) 
     return 0;
 }
 #endif
+
+// ---- 3-nearest-neighbour mean squared distance (simple_knn.distCUDA2) ---------------------------------------------
+namespace {
+struct KnnLayout { size_t grid, count, start, sorted, total; int target; size_t cells; };
+KnnLayout knn_layout(int32_t n) {
+    KnnLayout K{};
+    int target = 1;
+    while (target < KNN_MAX_GRID && (double)target * target * target < 0.5 * (double)n) ++target;   // ~2 points per cell
+    K.target = target;
+    K.cells = (size_t)target * target * target;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes ? bytes : 1); return o; };
+    K.grid = take(sizeof(KnnGrid));
+    K.count = take(K.cells * 4);
+    K.start = take((K.cells + 1) * 4);
+    K.sorted = take((size_t)(n > 0 ? n : 1) * 16);
+    K.total = off;
+    return K;
+}
+}  // namespace
+
+size_t pgr_knn_workspace_bytes(int32_t n) { return n < 0 ? 0 : knn_layout(n).total; }
+
+int32_t pgr_knn_mean_dist2(int32_t n, const float* xyz, float* out, void* workspace, size_t workspace_bytes,
+                           void* stream_v) {
+    if (n < 0) return PGR_ERR_INVALID_ARGUMENT;
+    if (n == 0) return PGR_OK;
+    if (!xyz || !out || !workspace) return PGR_ERR_INVALID_ARGUMENT;
+    const KnnLayout K = knn_layout(n);
+    if (workspace_bytes < K.total) return PGR_ERR_WORKSPACE_TOO_SMALL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    char* ws = static_cast<char*>(workspace);
+    auto* grid = reinterpret_cast<KnnGrid*>(ws + K.grid);
+    auto* count = reinterpret_cast<uint32_t*>(ws + K.count);
+    auto* start = reinterpret_cast<uint32_t*>(ws + K.start);
+    auto* sorted = reinterpret_cast<float4*>(ws + K.sorted);
+    KnnGrid init{};
+    for (int a = 0; a < 3; ++a) { init.lo[a] = 0xffffffffu; init.hi[a] = 0u; }
+    if (!hip_ok(hipMemcpyAsync(grid, &init, sizeof(init), hipMemcpyHostToDevice, stream), "memcpy knn grid") ||
+        !hip_ok(hipMemsetAsync(count, 0, K.cells * 4, stream), "memset knn counts"))
+        return PGR_ERR_LAUNCH_FAILURE;
+    const int blocks = (n + 255) / 256;
+    knn_bbox_kernel<<<blocks, 256, 0, stream>>>(n, xyz, grid);
+    knn_grid_kernel<<<1, 1, 0, stream>>>(grid, K.target);
+    knn_count_kernel<<<blocks, 256, 0, stream>>>(n, xyz, grid, count);
+    knn_scan_kernel<<<1, 1024, 0, stream>>>(grid, count, start);
+    // the counts become the cursors
+    if (!hip_ok(hipMemcpyAsync(count, start, K.cells * 4, hipMemcpyDeviceToDevice, stream), "memcpy knn cursors"))
+        return PGR_ERR_LAUNCH_FAILURE;
+    knn_scatter_kernel<<<blocks, 256, 0, stream>>>(n, xyz, grid, count, sorted);
+    knn_search_kernel<<<blocks, 256, 0, stream>>>(n, grid, start, sorted, out);
+    return hip_ok(hipGetLastError(), "knn launch") ? PGR_OK : PGR_ERR_LAUNCH_FAILURE;
+}

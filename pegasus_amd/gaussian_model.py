@@ -188,8 +188,33 @@ class GaussianModel:
         translation[mask] = + t
         self._xyz = self._xyz + translation
 
-    # ---- training: not part of this build
-    def training_setup(self, *a, **k):
-        raise NotImplementedError("training (optimizer, densification, backward) is out of scope: SURVEY.md section 8f row 4")
+    def create_from_pcd(self, pcd, spatial_lr_scale: float = 1.0):
+        """Initial splats from a point cloud (`pcd.points` [N,3], `pcd.colors` [N,3] in 0..1), as the reference does it
+        (/root/reference/src/gs/gaussian_model.py:134-162): isotropic scales from the mean distance to the three
+        nearest neighbours (pegasus_amd.knn.distCUDA2), identity rotations, opacity 0.1, colours as SH degree 0."""
+        from .knn import distCUDA2
+        from .sh_utils import RGB2SH
+        self.spatial_lr_scale = spatial_lr_scale
+        dev = self.device
+        pts = torch.tensor(np.asarray(pcd.points), dtype=torch.float, device=dev)
+        col = RGB2SH(torch.tensor(np.asarray(pcd.colors), dtype=torch.float, device=dev))
+        feats = torch.zeros((col.shape[0], 3, (self.max_sh_degree + 1) ** 2), dtype=torch.float, device=dev)
+        feats[:, :3, 0] = col
+        d2 = torch.clamp_min(distCUDA2(pts), 0.0000001)
+        scales = torch.log(torch.sqrt(d2))[..., None].repeat(1, 3)
+        rots = torch.zeros((pts.shape[0], 4), device=dev)
+        rots[:, 0] = 1
+        opac = torch.full((pts.shape[0], 1), 0.1, dtype=torch.float, device=dev)
+        self._xyz = pts
+        self._features_dc = feats[:, :, 0:1].transpose(1, 2).contiguous()
+        self._features_rest = feats[:, :, 1:].transpose(1, 2).contiguous()
+        self._scaling = scales
+        self._rotation = rots
+        self._opacity = torch.log(opac / (1 - opac))          # inverse_sigmoid
+        self.max_radii2D = torch.zeros((pts.shape[0],), device=dev)
 
-    create_from_pcd = densify_and_prune = training_setup
+    # ---- training loop: not part of this build (the differentiable rasterizer it would call is: pgr_backward)
+    def training_setup(self, *a, **k):
+        raise NotImplementedError("the training loop (optimizer, densification) is out of scope: SURVEY.md section 8f row 4")
+
+    densify_and_prune = training_setup

@@ -93,3 +93,39 @@ def test_render_facade_and_mask_wrappers(oracle, gpu_device):
         np.testing.assert_array_equal(sem, (np.ascontiguousarray(seg.numpy()) * 255).astype("uint8"))
     finally:
         sys.path.remove(str(ROOT / "compat"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n", [("uniform", 20000), ("clustered", 30000), ("plane", 10000), ("tiny", 3), ("one", 1),
+                                    ("duplicates", 5000)])
+def test_distCUDA2_matches_kdtree(gpu_device, kind, n):
+    """simple_knn._C.distCUDA2 (pgr_knn_mean_dist2): mean squared distance to the 3 nearest neighbours, against
+    scipy's exact k-d tree in float64."""
+    import sys
+    import torch
+    from pathlib import Path
+    from scipy.spatial import cKDTree
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "compat"))
+    from simple_knn._C import distCUDA2
+    rng = np.random.default_rng(n)
+    if kind == "uniform":
+        pts = rng.uniform(-1, 1, size=(n, 3))
+    elif kind == "clustered":
+        centres = rng.uniform(-5, 5, size=(20, 3))
+        pts = centres[rng.integers(20, size=n)] + rng.normal(0, 0.01, size=(n, 3))
+        pts[:50] = rng.uniform(-50, 50, size=(50, 3))                        # far outliers: many empty shells
+    elif kind == "plane":
+        pts = np.concatenate([rng.uniform(-1, 1, size=(n, 2)), np.zeros((n, 1))], axis=1)   # degenerate axis
+    elif kind == "duplicates":
+        pts = np.repeat(rng.uniform(-1, 1, size=(n // 5, 3)), 5, axis=0)    # 4 coincident neighbours each
+    else:
+        pts = rng.uniform(-1, 1, size=(n, 3))
+    pts = pts.astype(np.float32)
+    got = distCUDA2(torch.from_numpy(pts).to(gpu_device)).cpu().numpy()
+    assert got.shape == (n,)
+    if n < 4:
+        assert (got > 1e30).all()            # fewer than 3 neighbours: FLT_MAX terms, as upstream
+        return
+    d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
+    ref = (d[:, 1:] ** 2).mean(axis=1)
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-12)
