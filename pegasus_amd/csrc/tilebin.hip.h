@@ -123,8 +123,10 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restr
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
     const int hist_words = (min(tiles, BIN_LDS_TILES) + 3) / 4 * 4;
     float4* const stage = reinterpret_cast<float4*>(lds + hist_words + wave * BIN_STAGE_WORDS);   // [64][3]
-    // volatile: lanes talk to each other through this array inside one wave (DS operations of a wave are ordered)
-    volatile uint32_t* const heads = reinterpret_cast<volatile uint32_t*>(stage + WAVE * 3);       // [64]
+    // lanes talk to each other through this array inside one wave: DS operations of a wave execute in order, and a
+    // compiler memory barrier keeps the load behind the stores.  (NOT volatile: a volatile generic pointer turns the
+    // three accesses into flat_store/flat_load ... sc0 sc1 with a vmcnt(0) wait each.)
+    uint32_t* const heads = reinterpret_cast<uint32_t*>(stage + WAVE * 3);                           // [64]
     for (int lo = 0; lo < tiles; lo += BIN_LDS_TILES) {
         const int span = min(BIN_LDS_TILES, tiles - lo);
         for (int t = threadIdx.x; t < span; t += BIN_THREADS)
@@ -155,8 +157,11 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restr
             uint32_t carry_key = 0;        // owner of the candidate just before the window: (start + 1) << 6 | lane
             for (uint32_t c0 = 0; c0 < total; c0 += WAVE) {
                 heads[lane] = 0u;
+                asm volatile("" ::: "memory");
                 if (area && excl - c0 < (uint32_t)WAVE) heads[excl - c0] = ((excl + 1u) << 6) | (uint32_t)lane;
+                asm volatile("" ::: "memory");
                 uint32_t key = wave_inclusive_max(heads[lane]);     // same wave: LDS ops are ordered
+                asm volatile("" ::: "memory");
                 key = key ? key : carry_key;
                 carry_key = (uint32_t)__builtin_amdgcn_readlane((int)key, WAVE - 1);
                 const uint32_t c = c0 + (uint32_t)lane;
