@@ -70,3 +70,48 @@ def test_pose_interpolation_matches_reference_golden():
     g = np.load(GOLD / "pose_interpolation.npz")
     for p1, p2, t, out in zip(g["pose1"], g["pose2"], g["t"], g["out"]):
         np.testing.assert_allclose(interpolate_pose(float(t), 0.0, p1, 1.0, p2), out, atol=1e-6)
+
+
+def test_spatial_order_is_group_preserving_morton_permutation():
+    """scene_order.spatial_order: a permutation, environment first / objects in id order, Morton-coherent inside a
+    group (neighbours in the order are neighbours in space)."""
+    from pegasus_amd.scene_order import morton_codes, spatial_order
+    rng = np.random.default_rng(0)
+    n = 20000
+    xyz = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    oid = np.sort(rng.integers(0, 4, size=n)).astype(np.int32)
+    perm = spatial_order(xyz, oid)
+    assert sorted(perm.tolist()) == list(range(n))
+    assert (np.diff(oid[perm]) >= 0).all()
+    codes = morton_codes(xyz)                        # one bounding box for the whole cloud, as spatial_order uses
+    for k in range(4):
+        sel = perm[oid[perm] == k]
+        assert (np.diff(codes[sel].astype(np.int64)) >= 0).all()
+    # locality: mean distance between consecutive points drops by an order of magnitude against the input order
+    d_in = np.linalg.norm(np.diff(xyz[oid == 1], axis=0), axis=1).mean()
+    d_mo = np.linalg.norm(np.diff(xyz[perm][oid[perm] == 1], axis=0), axis=1).mean()
+    assert d_mo < 0.2 * d_in
+    assert spatial_order(np.zeros((0, 3), np.float32)).shape == (0,)
+    assert sorted(spatial_order(xyz[:100]).tolist()) == list(range(100))
+
+
+def test_pose_table_rows():
+    """compose.pose_table: [K,20] rows R|t|center|q(wxyz)|0 from (T, center) pairs; q is R as a unit quaternion."""
+    from scipy.spatial.transform import Rotation as Rot
+    from pegasus_amd.compose import pose_table
+    rng = np.random.default_rng(1)
+    pairs = []
+    for _ in range(3):
+        T = np.eye(4)
+        T[:3, :3] = Rot.from_rotvec(rng.normal(0, 1, 3)).as_matrix()
+        T[:3, 3] = rng.normal(0, 1, 3)
+        pairs.append((T, rng.normal(0, 1, 3)))
+    rows = pose_table(pairs)
+    assert rows.shape == (3, 20) and rows.dtype == np.float32
+    for r, (T, c) in zip(rows, pairs):
+        np.testing.assert_allclose(r[0:9].reshape(3, 3), T[:3, :3], atol=1e-6)
+        np.testing.assert_allclose(r[9:12], T[:3, 3], atol=1e-6)
+        np.testing.assert_allclose(r[12:15], c, atol=1e-6)
+        w, x, y, z = r[15:19]
+        np.testing.assert_allclose(Rot.from_quat([x, y, z, w]).as_matrix(), T[:3, :3], atol=1e-5)
+        assert r[19] == 0.0
