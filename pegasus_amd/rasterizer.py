@@ -96,7 +96,8 @@ class PendingBatch:
             self.num_instances = [int(x) for x in need]
             peak = max(self.num_instances)
             if peak > 0.8 * self._max_inst:
-                _WS.capacity_hint[self._key] = max(_WS.capacity_hint.get(self._key, 0), int(peak * 1.3) + 1024)
+                _WS.capacity_hint[self._key] = max(_WS.capacity_hint.get(self._key, 0), int(peak * 1.6) + 1024)   # few, large steps:
+                # every growth reallocates the multi-GB workspace (tens of ms)
             self._event = None
             if status == _lib.PGR_ERR_INSTANCE_OVERFLOW:
                 self._was_redone = True
@@ -208,7 +209,7 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
                 if status != _lib.PGR_ERR_INSTANCE_OVERFLOW:
                     _lib.check(status, "pgr_forward_frames_async")
                     return results
-                _WS.capacity_hint[key] = int(max(need) * 1.3) + 1024
+                _WS.capacity_hint[key] = int(max(need) * 1.6) + 1024
             raise RuntimeError("instance capacity did not converge")
     if async_slot is not None:
         with torch.cuda.device(device):
@@ -253,7 +254,7 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
     used_max_inst = max_inst
     peak = max(need) if nv else 0
     if peak > 0.8 * max_inst:
-        max_inst = int(peak * 1.3) + 1024
+        max_inst = int(peak * 1.6) + 1024
     _WS.capacity_hint[key] = max_inst
     if stage_ms is not None:
         stage_ms[:] = list(ms)
