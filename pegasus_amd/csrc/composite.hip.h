@@ -311,15 +311,12 @@ inline void launch_composite(uint32_t slots, hipStream_t stream, const ViewEntry
     composite_quarter_kernel<AUX, FUSED><<<slots, WAVE, 0, stream>>>(views, items_per_view, work_order, sem);
 }
 
-// Work ordering for the wave compositor: half-tile work items sorted by DESCENDING list length
-// (256 log-spaced length classes), so the long lists start first and the short ones back-fill the
-// SIMDs that finish early (longest-processing-time-first).  Order never affects results.
 // ---- work order --------------------------------------------------------------------------------
-// The compositor's work items (view, tile, half) are laid out as NUM_XCD interleaved streams: position p
+// The compositor's work items (view, tile, quarter) are laid out as NUM_XCD interleaved streams: position p
 // belongs to stream p % 8, and the hardware dispatcher is observed to place workgroup b on XCD b % 8
 // (MI355X_MICROARCH.md, a speed hint only -- any placement is correct).  Stream x owns every 8th band of
 // ORDER_BAND_ROWS tile rows of every view, and inside a stream the items keep their row-major order, so a tile's
-// two halves and its horizontal neighbours -- whose lists share most of their Gaussians -- run back to back on
+// four quarters and its horizontal neighbours -- whose lists share most of their Gaussians -- run back to back on
 // the SAME XCD and find each other's gathers in its L2 (PMC before: 486 MB/view fetched from the fabric for
 // 161 MB of algorithmic bytes).  Only a coarse longest-first split is kept (ORDER_CLASSES_USED length classes:
 // the long lists of every stream start first, short ones back-fill).  Unused slots hold INVALID_ITEM.

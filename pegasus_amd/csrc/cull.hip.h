@@ -1,5 +1,5 @@
 // cull.hip.h -- the "can this splat reach alpha >= 1/255 anywhere in this pixel rectangle?" predicate.
-// Used by the binning kernels (tile rectangle: tight lists) and by the compositor (half-tile rectangle:
+// Used by the binning kernels (tile rectangle: tight lists) and by the compositor (quarter-tile rectangle:
 // per-wave skip mask).  Conservative by construction, bit-reproducible (no transcendental), and mirrored
 // operation-for-operation by the oracle (pgr_oracle_tile_may_contribute).
 #pragma once

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Compositor tuning sweep: builds libpegasus_raster.so variants (here, no GPU needed) or runs bench.py over them (GPU box).
 #   scripts/variant_sweep.sh build "U:W U:W ..." [extra -D flags]   -> build_variants/lib_u<U>_w<W>.so
+#     W = PGR_COMP_WAVES (compositor occupancy cap, 0 = compiler's choice); U is a label only (the unroll knob of the
+#     half-tile compositor it once selected is gone) -- pass other knobs as extra -D flags (-DPGR_COMP_STATS, ...)
 #   scripts/variant_sweep.sh run  [bench args]                      -> one result line per variant
 set -e
 cd "$(dirname "$0")/.."
@@ -10,7 +12,7 @@ if [ "$mode" = build ]; then
   for s in $specs; do
     U=${s%%:*}; Wv=${s##*:}
     ( cd pegasus_amd/csrc && hipcc -O3 -std=c++17 -ffp-contract=off -munsafe-fp-atomics -fPIC -shared --offload-arch=gfx950 \
-        -DPGR_COMP_UNROLL=$U -DPGR_COMP_WAVES=$Wv "$@" -o ../../build_variants/lib_u${U}_w${Wv}.so pegasus_raster.hip ) &
+        -DPGR_COMP_WAVES=$Wv "$@" -o ../../build_variants/lib_u${U}_w${Wv}.so pegasus_raster.hip ) &
   done
   wait
   ls -la build_variants
