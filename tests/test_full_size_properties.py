@@ -125,3 +125,33 @@ def test_fused_semantic_equals_separate_pass_full_size(c3_full, gpu_device):
     for k in ("color", "depth", "seg", "masks"):
         assert torch.equal(fused[k], sep[k]), k
     assert fused["masks"].sum().item() > 10_000
+
+
+def test_c5_view_matches_oracle(oracle, gpu_device):
+    """BASELINE.json configs[4] scene (5 M Gaussians): one view against the oracle -- lists bit-exact (this scene has
+    tile lists of 16-30 k entries: the depth-partitioned sort path on real data, with the Morton copy's tie order),
+    image within 1e-4."""
+    import torch
+    from helpers import assert_images_match, fetch_workspace
+    from pegasus_amd import rasterizer as R
+    from pegasus_amd.frames import FrameRenderer
+    cloud, views = scenes.scene_c5(n_views=4)
+    act = cloud.activated()
+    fr = FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"], cloud.object_id,
+                       device=gpu_device)
+    v = views[0]
+    res = R.forward_views(fr.means3d, fr.opacities, [fr.view_spec(v)], shs=fr.shs, scales=fr.scales,
+                          rotations=fr.rotations, sh_degree=3, want_radii=True, want_aux=True, tie_index=fr.tie_index)
+    torch.cuda.synchronize()
+    w = fetch_workspace(0, cloud.n, v.width, v.height)
+    act_r = {k: np.ascontiguousarray(a[fr.order]) for k, a in act.items()}
+    o = oracle.forward(**act_r, sh_degree=3, **v.raster_kwargs(), num_threads=8, cull_mode=1, tie_index=fr.order)
+    lens = o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]
+    assert lens.max() > 16384
+    np.testing.assert_array_equal(res[0]["radii"].cpu().numpy(), o["radii"])
+    np.testing.assert_array_equal(w["gauss_sorted"], o["gauss_sorted"])
+    g = dict(color=res[0]["color"].cpu().numpy(), out_depth=res[0]["depth"].cpu().numpy(),
+             final_T=res[0]["final_T"].cpu().numpy(), n_contrib=res[0]["n_contrib"].cpu().numpy())
+    assert_images_match(g, o)
+    del fr
+    torch.cuda.empty_cache()
