@@ -39,8 +39,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c5"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink Gaussian counts (debug only; INVALID as a result)")
-    ap.add_argument("--views", type=int, default=64, help="distinct cameras cycled through")
-    ap.add_argument("--batch", type=int, default=16, help="views per step (one pgr_forward_batch call)")
+    ap.add_argument("--views", type=int, default=512, help="distinct cameras cycled through (configs[2]: 512 views)")
+    ap.add_argument("--batch", type=int, default=32,
+                    help="views per step (one batch call); 16 default steps x 32 = the 512 views of configs[2], each once")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--separate-semantic", action="store_true",
                     help="semantic image by a second full pass over the objects (default: fused into the scene pass)")
@@ -52,7 +53,8 @@ def parse():
                          "preprocess) and one camera, plus its BOP pose records")
     ap.add_argument("--raster-only", action="store_true", help="time only the full-scene RGB+depth pass (R), no masks")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
-    ap.add_argument("--profile-steps", type=int, default=2, help="steps measured per-stage with HIP events")
+    ap.add_argument("--profile-steps", type=int, default=0,
+                    help="batches measured per-stage with HIP events (0 = the same batches as the timed steps)")
     return ap.parse_args()
 
 
@@ -134,7 +136,7 @@ def main():
         from pegasus_amd import bop_pose
         oid = cloud.object_id
         centers = [act["means3d"][oid == k].mean(0) for k in range(1, fr.K + 1)]
-        S = (args.warmup + args.steps + max(1, args.profile_steps) + 1) * B
+        S = (2 * (args.warmup + args.steps) + max(1, args.profile_steps) + 1) * B
         pose_seq = np.zeros((S, fr.K, 20), np.float32)
         m2w_seq = []
         for s_i in range(S):
@@ -214,8 +216,8 @@ def main():
     stats = []
     raster_only_fps = None
     if rank == 0:
-        for i in range(max(1, args.profile_steps)):
-            res = rasterizer.forward_views(fr.means3d, fr.opacities, batch_views(i), shs=fr.shs, scales=fr.scales,
+        for i in range(args.profile_steps if args.profile_steps > 0 else min(4, args.steps)):   # N, V, I, evaluations
+            res = rasterizer.forward_views(fr.means3d, fr.opacities, batch_views(args.warmup + i), shs=fr.shs, scales=fr.scales,
                                            rotations=fr.rotations, sh_degree=3, want_radii=True, want_aux=True)
             info = rasterizer.last_forward_info()
             for k, r in enumerate(res):
@@ -223,7 +225,9 @@ def main():
                                   evals=int(r["n_contrib"].sum(dtype=torch.int64).item())))
             del res
         rows, srows = [], []
-        for i in range(max(1, args.profile_steps)):
+        prof = (range(args.warmup, args.warmup + args.steps) if args.profile_steps <= 0
+                else range(max(1, args.profile_steps)))
+        for i in prof:
             ms, sms = [], []
             step(i, stage_ms=ms, sem_stage_ms=sms)
             rows.append(ms)

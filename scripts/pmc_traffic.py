@@ -33,7 +33,7 @@ def per_kernel(db_path, counter):
     return acc, disp
 
 
-def main(fetch_db, write_db, out_json, out_txt, batch=16, workload="c3", command=""):
+def main(fetch_db, write_db, out_json, out_txt, batch=32, workload="c3", command=""):
     f, fd = per_kernel(fetch_db, "FETCH_SIZE")
     w, wd = per_kernel(write_db, "WRITE_SIZE")
     n_batches = len(fd.get("preprocess_batch_kernel<3, false>", fd.get("preprocess_batch_kernel<3>", {1})))
@@ -50,7 +50,7 @@ def main(fetch_db, write_db, out_json, out_txt, batch=16, workload="c3", command
                 break
     out = {"workload": workload, "batch": batch,
            "source": ("profiles (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes; " + command +
-                      "; per 16-view batch; counter unit KiB; FETCH_SIZE doubled: gfx950 correction for 16-B-per-lane loads, "
+                      "; per batch (one compositor launch); counter unit KiB; FETCH_SIZE doubled: gfx950 correction for 16-B-per-lane loads, "
                       "MI355X_MICROARCH.md HBM section, confirmed on this pipeline's gather pattern by "
                       "scripts/microbench/fetch_calib.hip)"),
            "kernels": {st: {"fetch_bytes_per_launch": int(2 * v["fetch_kib"] * 1024), "write_bytes_per_launch": int(v["write_kib"] * 1024),
@@ -58,7 +58,7 @@ def main(fetch_db, write_db, out_json, out_txt, batch=16, workload="c3", command
                        for st, v in stages.items()}}
     json.dump(out, open(out_json, "w"), indent=1)
     lines.append("")
-    lines.append("# per stage and 16-view batch (composite = the fused frames compositor): raw KiB, and bytes with FETCH_SIZE x 2")
+    lines.append(f"# per stage and {batch}-view batch (composite = the fused frames compositor): raw KiB, and bytes with FETCH_SIZE x 2")
     for st, v in out["kernels"].items():
         lines.append(f"{st:14s} fetch {v['fetch_size_kib_raw']:10d} KiB  write {v['write_size_kib_raw']:10d} KiB   "
                      f"-> {v['fetch_bytes_per_launch'] + v['write_bytes_per_launch']:14d} B")
