@@ -34,6 +34,9 @@ class FrameRenderer:
         binning and gathering does.  ``self.order[i]`` = caller's index of resident Gaussian i (None: unchanged)."""
         self.device = torch.device(device)
         self.order = None
+        _oid = (object_id.detach().cpu().numpy() if torch.is_tensor(object_id) else np.asarray(object_id)).astype(np.int64)
+        if _oid.size and (np.diff(_oid) < 0).any():
+            raise ValueError("object_id must be non-decreasing: environment Gaussians first (0), then object 1, 2, ...")
         if spatial_order and len(means3d) > 1:
             from .scene_order import spatial_order as _spatial_order
             host = lambda a: a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
