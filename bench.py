@@ -305,8 +305,12 @@ def main():
                 oracle.color_masks(seg["color"], fr.colors_np, 0.1)
             t_cpu += time.perf_counter() - t1
             n_done += 1
+        try:
+            cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+        except (OSError, StopIteration):
+            cpu_model = "unknown"
         cpu = {"value": round(n_done / t_cpu, 4), "unit": "frames/s" if with_masks else "views/s", "cores": cores,
-               "kind": "port",
+               "kind": "port", "cpu_model": cpu_model,
                "sample": f"first {n_done} frame(s) of the same scene and cameras, oracle/pgr_oracle.c with OpenMP "
                          f"({cores} threads), reference-style lists; no reference CPU rasterizer exists"}
 
