@@ -143,8 +143,11 @@ def main():
             pairs, m2w = [], {}
             for k in range(fr.K):
                 T = np.eye(4)
-                T[:3, :3] = Rot.from_euler("zx", [0.015 * s_i * (1 + 0.1 * k), 0.004 * s_i]).as_matrix()
-                T[:3, 3] = [0.0008 * s_i * math.cos(k), 0.0008 * s_i * math.sin(k), 0.02 * abs(math.sin(0.05 * s_i + k))]
+                # bounded, periodic motion: the objects spin, rock, slide within a few centimetres and bounce -- the
+                # workload stays the same however long the sequence runs
+                T[:3, :3] = Rot.from_euler("zx", [0.015 * s_i * (1 + 0.1 * k), 0.3 * math.sin(0.013 * s_i + k)]).as_matrix()
+                T[:3, 3] = [0.04 * math.sin(0.02 * s_i + k), 0.04 * math.cos(0.017 * s_i + 2 * k),
+                            0.02 * abs(math.sin(0.05 * s_i + k))]
                 pairs.append((T, centers[k]))
                 C4 = np.eye(4); C4[:3, 3] = centers[k]
                 Ci = np.eye(4); Ci[:3, 3] = -centers[k]
