@@ -1,0 +1,96 @@
+"""BOP-layout writer for the batch path ("mask/depth writers").
+
+Layout and naming follow the reference's writer (/root/reference/src/visualization/object_visualization.py:373-391,
+458-480; /root/reference/pegasus.py:347-358):
+
+    <out>/train/<scene:06d>/rgb/<frame:06d>.png              8-bit RGB,  (img * 255).astype(uint8)
+    <out>/train/<scene:06d>/depth/<frame:06d>.png            16-bit grey, (depth * 1000).astype(uint16)  (millimetres)
+    <out>/train/<scene:06d>/mask_visib/<frame:06d>_<obj:06d>.png   8-bit 0/255
+    <out>/train/<scene:06d>/scene_gt.json, scene_camera.json      pegasus_amd.bop_pose records
+
+The reference encodes PNGs with imageio (absent here); PNG is deflate + CRC, so zlib is all it takes.  Quantisation
+runs on the GPU (pgr_quantize_frame); only the 8/16-bit images cross PCIe.
+"""
+from __future__ import annotations
+
+import json
+import struct
+import zlib
+from pathlib import Path
+
+import numpy as np
+
+
+def encode_png(a: np.ndarray, level: int = 1) -> bytes:
+    """uint8 [H,W] / [H,W,3] or uint16 [H,W] -> PNG bytes (colour type 0 or 2, no interlace, filter 0)."""
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.uint8 and a.ndim == 2:
+        depth, ctype, rows = 8, 0, a
+    elif a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == 3:
+        depth, ctype, rows = 8, 2, a.reshape(a.shape[0], -1)
+    elif a.dtype == np.uint16 and a.ndim == 2:
+        depth, ctype, rows = 16, 0, a.astype(">u2").view(np.uint8).reshape(a.shape[0], -1)     # big-endian samples
+    else:
+        raise ValueError("encode_png takes uint8 [H,W], uint8 [H,W,3] or uint16 [H,W]")
+    h, w = a.shape[:2]
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), rows], axis=1).tobytes()                  # filter type 0 per row
+
+    def chunk(tag: bytes, data: bytes) -> bytes:
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(raw, level)) + chunk(b"IEND", b""))
+
+
+def decode_png(data: bytes) -> np.ndarray:
+    """Inverse of encode_png for the files this module writes (filter 0 only): used by the tests."""
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, hdr = 8, b"", None
+    while pos < len(data):
+        n, tag = struct.unpack(">I", data[pos:pos + 4])[0], data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + n]
+        if tag == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    w, h, depth, ctype = hdr[:4]
+    ch = 3 if ctype == 2 else 1
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * ch * depth // 8)
+    assert not raw[:, 0].any()
+    body = raw[:, 1:]
+    if depth == 16:
+        return body.reshape(h, w, 2).copy().view(">u2").reshape(h, w).astype(np.uint16)
+    return body.reshape(h, w, 3).copy() if ch == 3 else body.copy()
+
+
+class BopSceneWriter:
+    """Collects the frames of one scene; `add_batch` takes FrameRenderer output (device tensors) + pose records."""
+
+    def __init__(self, out_dir, scene_id: int = 0, png_level: int = 1):
+        self.scene = Path(out_dir) / "train" / f"{scene_id:06d}"
+        for d in ("rgb", "depth", "mask_visib"):
+            (self.scene / d).mkdir(parents=True, exist_ok=True)
+        self.scene_gt, self.scene_camera = {}, {}
+        self.n_frames, self.level = 0, png_level
+
+    def add_batch(self, frames: dict, scene_gt: dict, scene_camera: dict, n: int = None):
+        from . import masks as M
+        n = frames["color"].shape[0] if n is None else n
+        for i in range(n):
+            rgb8, mm = M.quantize_frame(frames["color"][i], frames["depth"][i, 0])          # GPU: uint8 HWC, uint16 mm
+            fid = self.n_frames
+            (self.scene / "rgb" / f"{fid:06d}.png").write_bytes(encode_png(rgb8.cpu().numpy(), self.level))
+            (self.scene / "depth" / f"{fid:06d}.png").write_bytes(
+                encode_png(mm.cpu().numpy().view(np.uint16), self.level))
+            if "masks" in frames:
+                mk = (frames["masks"][i] * 255).cpu().numpy()
+                for k in range(mk.shape[0]):
+                    (self.scene / "mask_visib" / f"{fid:06d}_{k:06d}.png").write_bytes(encode_png(mk[k], self.level))
+            self.scene_gt[str(fid)] = scene_gt[str(i)]
+            self.scene_camera[str(fid)] = scene_camera[str(i)]
+            self.n_frames += 1
+
+    def close(self):
+        (self.scene / "scene_gt.json").write_text(json.dumps(self.scene_gt))
+        (self.scene / "scene_camera.json").write_text(json.dumps(self.scene_camera))
+        return self.scene

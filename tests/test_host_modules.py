@@ -115,3 +115,17 @@ def test_pose_table_rows():
         w, x, y, z = r[15:19]
         np.testing.assert_allclose(Rot.from_quat([x, y, z, w]).as_matrix(), T[:3, :3], atol=1e-5)
         assert r[19] == 0.0
+
+
+def test_png_round_trip():
+    """dataset_writer.encode_png: valid PNG (signature, CRCs via decode) for the three image kinds the dataset holds."""
+    from pegasus_amd.dataset_writer import decode_png, encode_png
+    rng = np.random.default_rng(0)
+    for a in (rng.integers(0, 256, size=(37, 53, 3), dtype=np.uint8), rng.integers(0, 256, size=(20, 31), dtype=np.uint8),
+              rng.integers(0, 65536, size=(16, 45)).astype(np.uint16)):
+        png = encode_png(a)
+        assert png[:8] == bytes([0x89]) + b"PNG\r\n\x1a\n"
+        np.testing.assert_array_equal(decode_png(png), a)
+    import pytest
+    with pytest.raises(ValueError):
+        encode_png(np.zeros((4, 4), np.float32))
