@@ -430,3 +430,40 @@ def test_tie_index_order_on_long_lists(oracle, gpu_device, n, spread, equal):
     np.testing.assert_array_equal(w["gauss_sorted"], o["gauss_sorted"])
     amb = o["ambig"].astype(bool)
     assert np.abs(res[0]["color"].cpu().numpy() - o["color"])[:, ~amb].max() <= 1e-4
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_hostile_inputs_do_not_fault_and_match_oracle(oracle, gpu_device, seed):
+    """NaN / Inf positions, huge and vanishing scales, opacity exactly 0 and 1, zero and unnormalised quaternions,
+    splats behind / on the near plane: no fault, no hang, the same radii and lists as the oracle, equal images
+    wherever the oracle's are finite."""
+    from helpers import gpu_forward
+    rng = np.random.default_rng(900 + seed)
+    n = 3000
+    cloud, views = scenes.scene_c1(seed=30 + seed, n=n)
+    v = scenes.make_view(views[0].R_c2w.T, views[0].t_w2c, 160, 112, fovx=views[0].fovx, fovy=views[0].fovy)
+    act = cloud.activated()
+    pick = lambda frac: rng.random(n) < frac
+    act["means3d"][pick(0.01)] = np.nan
+    act["means3d"][pick(0.01), 0] = np.inf
+    act["means3d"][pick(0.01), 2] = -np.inf
+    act["means3d"][pick(0.02), 2] = np.float32(-3.0 + 0.2)            # exactly on the near plane (camera at z = -3)
+    act["scales"][pick(0.02)] = np.float32(1e3)
+    act["scales"][pick(0.02)] = np.float32(1e-8)
+    act["scales"][pick(0.01), 1] = 0.0
+    act["opacities"][pick(0.03)] = 0.0
+    act["opacities"][pick(0.03)] = 1.0
+    act["rotations"][pick(0.01)] = 0.0
+    act["rotations"][pick(0.02)] *= np.float32(37.0)
+    act["shs"][pick(0.01)] = np.float32(1e6)
+    o = oracle.forward(**act, sh_degree=3, **v.raster_kwargs((0.3, 0.2, 0.1)), num_threads=8, cull_mode=1)
+    g = gpu_forward(act, v, sh_degree=3, bg=(0.3, 0.2, 0.1), device=str(gpu_device))
+    np.testing.assert_array_equal(g["radii"], o["radii"])
+    assert g["num_instances"] == o["num_instances"]
+    np.testing.assert_array_equal(g["gauss_sorted"], o["gauss_sorted"])
+    ok = np.isfinite(o["color"]).all(axis=0) & np.isfinite(o["out_depth"][0]) & ~o["ambig"].astype(bool)
+    assert ok.mean() > 0.5
+    scale = np.maximum(1.0, np.abs(o["color"]))
+    assert (np.abs(g["color"] - o["color"]) / scale)[:, ok].max() <= 1e-4
+    assert np.array_equal(np.isfinite(g["color"]).all(axis=0)[~o["ambig"].astype(bool)],
+                          np.isfinite(o["color"]).all(axis=0)[~o["ambig"].astype(bool)])
