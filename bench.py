@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--separate-semantic", action="store_true",
                     help="semantic image by a second full pass over the objects (default: fused into the scene pass)")
     ap.add_argument("--sync-steps", action="store_true", help="one blocking render_batch per step (no pipelining)")
+    ap.add_argument("--serialize-slots", action="store_true",
+                    help="A/B: make the two pipeline slots execute one after the other on the GPU (round-1 behaviour)")
     ap.add_argument("--input-order", action="store_true",
                     help="keep the scene in its input order (default: one-time Morton layout per object, outside the timed region)")
     ap.add_argument("--dynamic", action="store_true",
@@ -117,6 +119,7 @@ def main():
     act = cloud.activated()
     fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"],
                          cloud.object_id, sh_degree=3, device=dev, spatial_order=not args.input_order)
+    fr.serialize_slots = args.serialize_slots
     specs = [fr.view_spec(v) for v in my_views]
     W, H = my_views[0].width, my_views[0].height
     P = W * H

@@ -82,7 +82,8 @@ typedef struct PgrOutputs {
     int32_t *radii;              /* [n]      required */
     float *final_T;              /* [H,W]    optional (NULL) */
     uint32_t *n_contrib;         /* [H,W]    optional (NULL) */
-    float *sem_color;            /* [3,H,W]  optional: the objects-only semantic render (PgrSemantic), else NULL */
+    float *sem_color;            /* [3,H,W]  the objects-only semantic render: REQUIRED on every view of a call that
+                                    passes a PgrSemantic (PGR_ERR_INVALID_ARGUMENT otherwise), ignored without one */
     float *sem_depth;            /* [1,H,W]  optional, only with sem_color */
 } PgrOutputs;
 
@@ -96,7 +97,8 @@ typedef struct PgrSemantic {
                                     max(C0 * RGB2SH(c_k) + 0.5, 0), evaluated in fp32 in that order */
     int32_t n_env;               /* Gaussians [0, n_env) are the environment */
     int32_t k_objects;
-} PgrSemantic;
+} PgrSemantic;                   /* checked before anything is enqueued: object_id, colors non-NULL, n_env >= 0,
+                                    k_objects > 0, outs[v].sem_color non-NULL for every view */
 
 /* Device pointers into one view's slice of a workspace, for stage-level parity tests and for backward. */
 typedef struct PgrWorkspaceView {

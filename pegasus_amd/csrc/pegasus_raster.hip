@@ -181,7 +181,11 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
                                   void* host_scratch = nullptr, const PgrSemantic* semantic = nullptr,
                                   const PgrPosedObjects* posed = nullptr) {
     auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], stream); };
+    // every argument check happens here, before the first enqueue: an early return below this block would leave work
+    // on the stream that still reads the (pageable) table staging of the synchronous path
     if (posed && (!posed->object_id || !posed->poses || posed->k_objects <= 0 || (scene && scene->cov3d_precomp)))
+        return PGR_ERR_INVALID_ARGUMENT;
+    if (semantic && (!semantic->object_id || !semantic->colors || semantic->n_env < 0 || semantic->k_objects <= 0))
         return PGR_ERR_INVALID_ARGUMENT;
     if (n_views <= 0 || !cams || !outs) return PGR_ERR_INVALID_ARGUMENT;
     if (num_instances) for (int v = 0; v < n_views; ++v) num_instances[v] = 0;
@@ -191,8 +195,15 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     for (int v = 0; v < n_views; ++v) {
         if (int rc = check_camera(&cams[v], &outs[v])) return rc;
         if (cams[v].image_width != W || cams[v].image_height != H) return PGR_ERR_INVALID_ARGUMENT;
+        // a semantic descriptor asks for the objects-only image of EVERY view of the batch
+        if (semantic && !outs[v].sem_color) return PGR_ERR_INVALID_ARGUMENT;
     }
     const size_t P = (size_t)W * H;
+    // failure after the first enqueue: the synchronous path drains the stream before its staging memory goes away
+    auto fail = [&](int32_t rc) {
+        if (!host_scratch) (void)hipStreamSynchronize(stream);
+        return rc;
+    };
 
     // N == 0: outputs stay zero-filled, no background (SURVEY.md section 8a "Edge cases")
     if (N == 0) {
@@ -252,7 +263,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         pres[v] = PreOut{vw[v].splats, outs[v].radii ? vw[v].rects : nullptr, vw[v].crects, outs[v].radii};
     }
     if (!hip_ok(hipMemcpyAsync(ws + B.tables, hs, B.tables_bytes, hipMemcpyHostToDevice, stream), "memcpy tables"))
-        return PGR_ERR_LAUNCH_FAILURE;
+        return fail(PGR_ERR_LAUNCH_FAILURE);
 
     // ---- stage 0: camera pack + per-Gaussian preprocess
     mark(0);
@@ -286,7 +297,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     const int grid_x = (W + TILE - 1) / TILE;
     const size_t lds = bin_lds_bytes(L.tiles);
     if (!hip_ok(hipMemsetAsync(ws + B.tile_counts, 0, (size_t)n_views * L.tiles * 8, stream), "memset tile counts"))
-        return PGR_ERR_LAUNCH_FAILURE;
+        return fail(PGR_ERR_LAUNCH_FAILURE);
     bin_kernel<false><<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(bin_table, N, grid_x, L.tiles, W, H);
     tile_scan_kernel<<<n_views, 1024, 0, stream>>>(bin_table, L.tiles, (uint32_t)max_instances);
     mark(2);
@@ -296,7 +307,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     // ---- stage 3: work order (XCD streams, longest lists first) + per-tile (depth, index) sort
     if (!hip_ok(hipMemsetAsync(order_state, 0, ORDER_STATE_WORDS * 4, stream), "memset order state") ||
         !hip_ok(hipMemsetAsync(work_order, 0xff, B.order_slots * 4, stream), "memset work order"))
-        return PGR_ERR_LAUNCH_FAILURE;
+        return fail(PGR_ERR_LAUNCH_FAILURE);
     const dim3 og((L.tiles + 255) / 256, n_views);
     order_count_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, L.grid_x, order_state);
     order_scan_kernel<<<1, 64, 0, stream>>>(order_state);
@@ -314,11 +325,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     const uint32_t items_per_view = ITEMS_PER_TILE * (uint32_t)L.tiles;
     const uint32_t slots = (uint32_t)B.order_slots;
     SemanticDev sd{nullptr, nullptr, 0, 0};
-    if (want_sem) {
-        if (!semantic->object_id || !semantic->colors || semantic->n_env < 0 || semantic->k_objects <= 0)
-            return PGR_ERR_INVALID_ARGUMENT;
-        sd = SemanticDev{semantic->object_id, semantic->colors, semantic->n_env, semantic->k_objects};
-    }
+    if (want_sem) sd = SemanticDev{semantic->object_id, semantic->colors, semantic->n_env, semantic->k_objects};
     if (want_aux && want_sem)
         launch_composite<true, true>(slots, stream, view_table, items_per_view, work_order, sd);
     else if (want_aux)
@@ -328,11 +335,11 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     else
         launch_composite<false, false>(slots, stream, view_table, items_per_view, work_order, sd);
     mark(5);
-    if (!hip_ok(hipGetLastError(), "kernel launch")) return PGR_ERR_LAUNCH_FAILURE;
+    if (!hip_ok(hipGetLastError(), "kernel launch")) return fail(PGR_ERR_LAUNCH_FAILURE);
 
     // the only host read of the batch: instance counts + overflow flags, after everything is enqueued
     if (!hip_ok(hipMemcpyAsync(h_status, status_dev, (size_t)n_views * 8, hipMemcpyDeviceToHost, stream), "memcpy status"))
-        return PGR_ERR_LAUNCH_FAILURE;
+        return fail(PGR_ERR_LAUNCH_FAILURE);
     if (host_scratch) return PGR_OK;       // asynchronous: the caller synchronises and calls pgr_batch_status
     if (!hip_ok(hipStreamSynchronize(stream), "sync at batch end")) return PGR_ERR_LAUNCH_FAILURE;
     bool overflow = false;

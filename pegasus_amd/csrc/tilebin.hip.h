@@ -209,38 +209,42 @@ __global__ void invert_tie_index_kernel(int n, const int32_t* __restrict__ tie_i
     if ((unsigned)k < (unsigned)n) tie_inv[k] = (uint32_t)i;
 }
 
-// one workgroup per view
+// one workgroup per view.  The running total is kept in 64 bits: a view's instance count can pass 2^32 (millions of
+// screen-filling splats x thousands of tiles), and a wrapped 32-bit sum could land below max_instances and let the
+// scatter pass write through wrapped ranges.  Ranges are clamped to max_instances (no cursor can pass the buffers
+// even if a later stage ignored the flag); counters[0] saturates at 0xffffffff.
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const BinView* __restrict__ views, int tiles,
                                                          uint32_t max_instances) {
-    __shared__ uint32_t wave_tot[1024 / WAVE];
-    __shared__ uint32_t carry_s;
+    __shared__ unsigned long long wave_tot[1024 / WAVE];
+    __shared__ unsigned long long carry_s;
     const BinView& bv = views[blockIdx.x];
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     for (int base = 0; base < tiles; base += 1024) {
         const int idx = base + threadIdx.x;
-        const uint32_t v = idx < tiles ? bv.tile_count[idx] : 0u;
-        uint32_t s = v;
+        const unsigned long long v = idx < tiles ? (unsigned long long)bv.tile_count[idx] : 0ull;
+        unsigned long long s = v;
 #pragma unroll
         for (int d = 1; d < WAVE; d <<= 1) {
-            const uint32_t t = __shfl_up(s, d, WAVE);
+            const unsigned long long t = __shfl_up(s, d, WAVE);
             if (lane >= d) s += t;
         }
         if (lane == WAVE - 1) wave_tot[wid] = s;
         __syncthreads();
-        uint32_t wave_prefix = 0;
+        unsigned long long wave_prefix = 0;
         for (int w = 0; w < wid; ++w) wave_prefix += wave_tot[w];
-        const uint32_t carry = carry_s;
-        const uint32_t excl = carry + wave_prefix + s - v;
-        if (idx < tiles) bv.ranges[idx] = make_uint2(excl, excl + v);
+        const unsigned long long carry = carry_s;
+        const unsigned long long excl = carry + wave_prefix + s - v;
+        const unsigned long long cap = max_instances;
+        if (idx < tiles) bv.ranges[idx] = make_uint2((uint32_t)min(excl, cap), (uint32_t)min(excl + v, cap));
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = carry + wave_prefix + s;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        bv.counters[0] = carry_s;
-        bv.counters[1] = carry_s > max_instances ? 1u : 0u;
+        bv.counters[0] = (uint32_t)min(carry_s, 0xffffffffull);
+        bv.counters[1] = carry_s > (unsigned long long)max_instances ? 1u : 0u;
     }
 }
 

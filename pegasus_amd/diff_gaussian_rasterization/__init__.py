@@ -63,9 +63,16 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     return r["color"], r["radii"], r["depth"]
 
 
+_TENSOR_KEYS = ("means3D", "sh", "colors", "op", "scales", "rot", "cov", "bg", "view", "proj", "campos")
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     """Differentiable single-view rasterization (training path).  The forward keeps its own workspace (the
-    backward walks the same per-tile lists), so it does not share the pooled scratch of the no-grad path."""
+    backward walks the same per-tile lists), so it does not share the pooled scratch of the no-grad path.
+
+    Every tensor the backward re-reads goes through ``ctx.save_for_backward``: an in-place update of means, scales,
+    rotations, opacities or SH between forward and backward trips autograd's version-counter check instead of
+    silently pairing new parameter values with the forward's lists, final_T and n_contrib."""
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -105,19 +112,25 @@ class _RasterizeGaussians(torch.autograd.Function):
                                        ws.numel(), max_inst, C.byref(need), stream)
                 if status != _lib.PGR_ERR_INSTANCE_OVERFLOW:
                     break
-                max_inst = int(need.value * 1.25) + 1024
+                max_inst = rasterizer._grown_capacity(need.value, 1.25)
             _lib.check(status, "pgr_forward")
         ctx.rs, ctx.max_inst, ctx.n = rs, max_inst, n
-        ctx.t = t
-        ctx.state = (ws, radii, final_T, n_contrib)
+        # non-tensor state stays on ctx; tensors (inputs as the kernels read them + the forward's own buffers) are saved
+        ctx.present = tuple(k for k in _TENSOR_KEYS if t[k] is not None)
+        ctx.op_shape = tuple(opacities.shape)
+        ctx.save_for_backward(*(t[k] for k in ctx.present), ws, radii, final_T, n_contrib)
         ctx.mark_non_differentiable(radii)
         return color, radii, depth
 
     @staticmethod
     def backward(ctx, grad_color, _grad_radii, grad_depth):
         L = _lib.lib()
-        rs, t, n = ctx.rs, ctx.t, ctx.n
-        ws, radii, final_T, n_contrib = ctx.state
+        rs, n = ctx.rs, ctx.n
+        saved = ctx.saved_tensors          # raises if an input was modified in place since the forward
+        k = len(ctx.present)
+        t = dict.fromkeys(_TENSOR_KEYS)
+        t.update(zip(ctx.present, saved[:k]))
+        ws, radii, final_T, n_contrib = saved[k:]
         device = ws.device
         H, W = int(rs.image_height), int(rs.image_width)
         z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=device)
@@ -148,8 +161,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                       C.byref(grads), _ptr(rows),
                                       C.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "pgr_backward")
         # means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings
-        return (g["means3d"], g["means2d"], g.get("shs"), g.get("colors"), g["opacities"], g.get("scales"),
-                g.get("rotations"), g.get("cov3d"), None)
+        return (g["means3d"], g["means2d"], g.get("shs"), g.get("colors"), g["opacities"].view(ctx.op_shape),
+                g.get("scales"), g.get("rotations"), g.get("cov3d"), None)
 
 
 class GaussianRasterizer(nn.Module):

@@ -110,7 +110,9 @@ class FrameRenderer:
                             poses=None):
         """The fast path: ONE batch call renders the scene (color, depth) and -- from the same per-tile lists --
         the objects-only semantic image (seg), then one mask launch; enqueued on side stream ``slot`` (2 slots =
-        two batches in flight on two streams).  Returns a ``wait()``-able handle; nothing synchronises the host.
+        two batches in flight on two streams; the streams are independent of each other and of the caller's stream
+        after their start, so the batches overlap on the GPU).  Returns a ``wait()``-able handle; nothing
+        synchronises the host.  Keep at most one batch in flight per slot.
         ``poses`` [B, K, 20]: dynamic scene -- frame i shows object k at poses[i, k-1] (time steps as a batch)."""
         B = len(specs)
         dev = self.device
@@ -133,17 +135,19 @@ class FrameRenderer:
                 M.color_masks(frames["seg"][:B], self.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])
             ev = torch.cuda.Event()
             ev.record(st)
-        cur.wait_stream(st)
+        # The caller's stream does NOT wait here: the two slots' streams then really overlap on the GPU (batch i+1's
+        # HBM-bound preprocess / LDS-bound sort beside batch i's VALU-bound compositor).  Consumers are ordered by
+        # wait() (host-side event synchronisation) or by making their own stream wait on ``pending.event``.
+        if getattr(self, "serialize_slots", False):      # A/B switch for measurements: round 1's behaviour
+            cur.wait_stream(st)
         renderer = self
 
         class _Pending:
+            event = ev
+
             def wait(self_inner):
-                before = h.results
-                redone = h._event is not None
                 h.wait()
                 ev.synchronize()
-                if fused and redone and h.num_instances is not None and h._redo is None and h.results is not before:
-                    pass
                 if fused and getattr(h, "_was_redone", False):
                     M.color_masks(frames["seg"][:B], renderer.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])
                     torch.cuda.current_stream(dev).synchronize()
@@ -178,15 +182,13 @@ class FrameRenderer:
                 M.color_masks(frames["seg"][:B], self.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])
                 ev_masks = torch.cuda.Event()
                 ev_masks.record(s_sem)
-            cur.wait_stream(s_sem)
-        cur.wait_stream(s_scene)
+        # no cur.wait_stream here either (see render_frames_async): wait() orders the consumers
         renderer = self
 
         class _Pending:
             def wait(self_inner):
                 h1.wait()
                 if h2 is not None:
-                    redone = h2._event is not None and False
                     before = h2.results
                     h2.wait()
                     ev_masks.synchronize()

@@ -17,8 +17,14 @@ from .sh_utils import eval_sh
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
     """Render the scene ``pc`` (a GaussianModel) from ``viewpoint_camera``.  ``bg_color`` must be on the GPU."""
-    # kept for interface parity: upstream returns the (zero) screen-space points so training can read their grad
-    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, device=pc.get_xyz.device)
+    # upstream's idiom: a zero tensor whose .grad receives the screen-space (NDC-scaled) gradient of the 2D means, which
+    # training-style callers read for densification (render_pkg["viewspace_points"].grad)
+    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True,
+                                          device=pc.get_xyz.device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
 
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)

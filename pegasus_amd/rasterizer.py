@@ -58,6 +58,17 @@ class _Workspace:
 _WS = _Workspace()
 _LAST_INFO: dict = {}
 
+MAX_INSTANCES = 0x7FFFFFFF      # per view: list positions are 32-bit (include/pegasus_raster.h)
+
+
+def _grown_capacity(need: int, factor: float) -> int:
+    """Instance capacity for a retry after PGR_ERR_INSTANCE_OVERFLOW.  The device reports the count saturated at
+    2^32 - 1; a view that needs more than MAX_INSTANCES list entries cannot be rendered and the retry gives up."""
+    if need > MAX_INSTANCES:
+        raise RuntimeError(f"a view lists {'>= ' if need >= 0xFFFFFFFF else ''}{need} (Gaussian, tile) instances; the "
+                           f"rasterizer's per-view limit is {MAX_INSTANCES}")
+    return min(MAX_INSTANCES, int(need * factor) + 1024)
+
 
 def last_forward_info() -> dict:
     """Bookkeeping of the most recent forward: num_instances per view, capacities, workspace tensor."""
@@ -95,8 +106,8 @@ class PendingBatch:
             status = _lib.lib().pgr_batch_status(C.c_void_p(self._scratch.data_ptr()), self._nv, need)
             self.num_instances = [int(x) for x in need]
             peak = max(self.num_instances)
-            if peak > 0.8 * self._max_inst:
-                _WS.capacity_hint[self._key] = max(_WS.capacity_hint.get(self._key, 0), int(peak * 1.6) + 1024)   # few, large steps:
+            if peak > 0.8 * self._max_inst and peak <= MAX_INSTANCES:
+                _WS.capacity_hint[self._key] = max(_WS.capacity_hint.get(self._key, 0), _grown_capacity(peak, 1.6))   # few, large steps:
                 # every growth reallocates the multi-GB workspace (tens of ms)
             self._event = None
             if status == _lib.PGR_ERR_INSTANCE_OVERFLOW:
@@ -209,7 +220,7 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
                 if status != _lib.PGR_ERR_INSTANCE_OVERFLOW:
                     _lib.check(status, "pgr_forward_frames_async")
                     return results
-                _WS.capacity_hint[key] = int(max(need) * 1.6) + 1024
+                _WS.capacity_hint[key] = _grown_capacity(max(need), 1.6)
             raise RuntimeError("instance capacity did not converge")
     if async_slot is not None:
         with torch.cuda.device(device):
@@ -249,12 +260,12 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
                                              max_inst, need, stream)
             if status != _lib.PGR_ERR_INSTANCE_OVERFLOW:
                 break
-            max_inst = int(max(need) * 1.25) + 1024   # grow to what the largest view needs, then retry
+            max_inst = _grown_capacity(max(need), 1.25)   # grow to what the largest view needs, then retry
         _lib.check(status, "pgr_forward_batch")
     used_max_inst = max_inst
     peak = max(need) if nv else 0
     if peak > 0.8 * max_inst:
-        max_inst = int(peak * 1.6) + 1024
+        max_inst = _grown_capacity(peak, 1.6)
     _WS.capacity_hint[key] = max_inst
     if stage_ms is not None:
         stage_ms[:] = list(ms)

@@ -104,3 +104,59 @@ def test_hip_backward_matches_oracle(oracle, gpu_device, case):
         scale = max(1e-4, np.abs(ref).max())
         assert err / scale < 2e-3, (k, err, scale)
     assert np.abs(g["means3d"]).max() > 0
+
+
+@pytest.mark.gpu
+def test_autograd_contract_in_place_update_flat_opacity_viewspace_grad(gpu_device):
+    """(a) an in-place update of an input between forward and backward trips autograd's version check (the saved
+    tensors are the ones the kernels re-read) instead of pairing new values with the forward's lists;
+    (b) an opacity tensor of shape [n] gets a gradient of shape [n];
+    (c) gaussian_renderer.render() hands back viewspace_points whose .grad carries the screen-space gradient, as the
+    upstream training loop reads it (/root/reference/src/gs/gs_training.py -> train.training: densification stats)."""
+    import torch
+    from pegasus_amd import diff_gaussian_rasterization as dgr
+    P, v = tiny_scene(3, n=40, W=80, H=64)
+    P = {k: np.asarray(a, np.float32) for k, a in P.items()}
+    dev = gpu_device
+    tt = lambda arr, rg=True: torch.from_numpy(np.ascontiguousarray(arr)).to(dev).requires_grad_(rg)
+    kw = v.raster_kwargs((0.2, 0.4, 0.1))
+    s = dgr.GaussianRasterizationSettings(v.height, v.width, v.tanfovx, v.tanfovy, tt(kw["bg"], False), 1.0,
+                                          tt(v.world_view_transform, False), tt(v.full_proj_transform, False), 3,
+                                          tt(v.camera_center, False), False, False)
+    # (a)
+    means, op, sc, rot, shs = tt(P["means3d"]), tt(P["opacities"].reshape(-1, 1)), tt(P["scales"]), tt(P["rotations"]), tt(P["shs"])
+    color, _, depth = dgr.GaussianRasterizer(s)(means, None, op, shs=shs, scales=sc, rotations=rot)
+    with torch.no_grad():
+        sc.mul_(1.5)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        (color.sum() + depth.sum()).backward()
+    # (b)
+    means, op, sc, rot, shs = tt(P["means3d"]), tt(P["opacities"].reshape(-1)), tt(P["scales"]), tt(P["rotations"]), tt(P["shs"])
+    color, _, depth = dgr.GaussianRasterizer(s)(means, None, op, shs=shs, scales=sc, rotations=rot)
+    (color.sum() + depth.sum()).backward()
+    assert op.grad.shape == op.shape and float(op.grad.abs().max()) > 0
+    ref_op = op.grad.clone()
+    op2 = tt(P["opacities"].reshape(-1, 1))
+    color, _, depth = dgr.GaussianRasterizer(s)(tt(P["means3d"]), None, op2, shs=tt(P["shs"]), scales=tt(P["scales"]),
+                                                rotations=tt(P["rotations"]))
+    (color.sum() + depth.sum()).backward()
+    torch.testing.assert_close(op2.grad.reshape(-1), ref_op, rtol=1e-4, atol=1e-6)
+    # (c)
+    from pegasus_amd import gaussian_renderer, scenes
+    from pegasus_amd.cameras import Camera
+    from pegasus_amd.gaussian_model import GaussianModel
+    c, views = scenes.scene_c1(seed=4, n=2000)
+    v = views[0]
+    gm = GaussianModel.from_arrays(c.xyz, c.features_dc, c.features_rest, c.opacity, c.scaling, c.rotation, device=dev)
+    gm._xyz.requires_grad_(True)
+    cam = Camera(colmap_id=0, R=v.R_c2w, T=v.t_w2c, FoVx=v.fovx, FoVy=v.fovy, image=torch.empty((3, v.height, v.width)),
+                 gt_alpha_mask=None, image_name="0", uid=0, data_device=str(dev))
+    pipe = type("Pipe", (), dict(debug=False, compute_cov3D_python=False, convert_SHs_python=False))()
+    pkg = gaussian_renderer.render(cam, gm, pipe, torch.zeros(3, device=dev))
+    pkg["render"].sum().backward()
+    vg = pkg["viewspace_points"].grad
+    assert vg is not None and vg.shape == gm.get_xyz.shape and float(vg[:, :2].abs().max()) > 0
+    assert gm._xyz.grad is not None and float(gm._xyz.grad.abs().max()) > 0
+    with torch.no_grad():      # render loops run under no_grad (pegasus.py:248): no grad machinery, same keys
+        pkg = gaussian_renderer.render(cam, gm, pipe, torch.zeros(3, device=dev))
+        assert not pkg["render"].requires_grad and pkg["viewspace_points"].shape == gm.get_xyz.shape

@@ -1,0 +1,84 @@
+"""Edges of the C-ABI contract that the parity scenes never reach: a view whose instance total passes 2^32, and a
+semantic descriptor that is rejected before anything is enqueued.  (The reference extension sizes its buffers on the
+host after a device->host read of the instance total -- SURVEY.md section 2a -- and simply fails to allocate; here the
+total is computed on the device, so the device must not wrap.)"""
+import numpy as np
+import pytest
+
+from pegasus_amd import scenes
+
+
+def test_capacity_growth_gives_up_beyond_the_per_view_limit():
+    from pegasus_amd import rasterizer as R
+    assert R._grown_capacity(1_000_000, 1.25) == 1_251_024
+    assert R._grown_capacity(R.MAX_INSTANCES, 1.6) == R.MAX_INSTANCES           # clamped, still renderable
+    with pytest.raises(RuntimeError, match="per-view limit"):
+        R._grown_capacity(R.MAX_INSTANCES + 1, 1.25)
+    with pytest.raises(RuntimeError, match=">= 4294967295"):                       # the device's saturated count
+        R._grown_capacity(0xFFFFFFFF, 1.25)
+
+
+@pytest.mark.gpu
+def test_instance_total_just_beyond_32_bits_reports_overflow(gpu_device):
+    """1.72 M opaque splats that each cover all 2500 tiles of an 800x800 view: 4.3e9 instances = 2^32 + 5 M.  A 32-bit
+    running total would wrap to 5 M -- below the 10 M capacity -- and the scatter pass would write through wrapped
+    ranges.  The device total is 64-bit: overflow is flagged, nothing is scattered, the host gives up cleanly, and the
+    library keeps working afterwards."""
+    import torch
+    from pegasus_amd import rasterizer as R
+    n, W, H = 1_720_000, 800, 800
+    assert n * ((W + 15) // 16) * ((H + 15) // 16) - (1 << 32) < 6 * n      # wrapped total < initial capacity
+    dev = gpu_device
+    g = torch.Generator(device="cpu").manual_seed(0)
+    means = (torch.rand((n, 3), generator=g) - 0.5).mul_(0.2).to(dev)
+    op = torch.full((n,), 0.99, device=dev)
+    scales = torch.full((n, 3), 100.0, device=dev)
+    rot = torch.zeros((n, 4), device=dev); rot[:, 0] = 1.0
+    col = torch.rand((n, 3), generator=g).to(dev)
+    _, views = scenes.scene_c1()
+    v = scenes.make_view(views[0].R_c2w.T, views[0].t_w2c, W, H, fovx=views[0].fovx, fovy=views[0].fovy)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    spec = R.ViewSpec(H, W, v.tanfovx, v.tanfovy, t(np.zeros(3)), t(v.world_view_transform), t(v.full_proj_transform),
+                      t(v.camera_center))
+    R._WS.capacity_hint.pop((dev, n, W, H), None)
+    with pytest.raises(RuntimeError, match="per-view limit"):
+        R.forward_views(means, op, [spec], colors_precomp=col, scales=scales, rotations=rot, want_radii=False)
+    torch.cuda.synchronize()
+    # still alive: a small well-behaved subset renders, and to the same image twice
+    k = 20_000
+    small = torch.full((k, 3), 0.02, device=dev)
+    a = R.forward_views(means[:k], op[:k], [spec], colors_precomp=col[:k], scales=small, rotations=rot[:k])[0]["color"].clone()
+    b = R.forward_views(means[:k], op[:k], [spec], colors_precomp=col[:k], scales=small, rotations=rot[:k])[0]["color"]
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all() and torch.equal(a, b) and float(a.max()) > 0
+
+
+@pytest.mark.gpu
+def test_semantic_descriptor_is_checked_before_any_enqueue(gpu_device):
+    """NULL colours / object ids, or a view without a sem_color target, are PGR_ERR_INVALID_ARGUMENT up front -- in
+    round 1 they were found at stage 4, with the tables copy and three stages already on the stream."""
+    import torch
+    from pegasus_amd import rasterizer as R
+    dev = gpu_device
+    cloud, views = scenes.scene_c1(n=2000)
+    act = {k: torch.from_numpy(np.ascontiguousarray(a)).to(dev) for k, a in cloud.activated().items()}
+    v = views[0]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+    spec = R.ViewSpec(v.height, v.width, v.tanfovx, v.tanfovy, t(np.zeros(3)), t(v.world_view_transform),
+                      t(v.full_proj_transform), t(v.camera_center))
+    oid = torch.zeros(cloud.n, dtype=torch.int32, device=dev); oid[1000:] = 1
+    good = dict(object_id=oid, colors=torch.tensor([[0.2, 0.7, 0.4]], device=dev), n_env=1000, k=1)
+    kw = dict(shs=act["shs"], scales=act["scales"], rotations=act["rotations"], sh_degree=3, want_radii=False)
+    ok = R.forward_views(act["means3d"], act["opacities"], [spec], semantic=good, **kw)[0]
+    assert float(ok["sem_color"].abs().max()) > 0
+    for bad in (dict(good, colors=None), dict(good, object_id=None), dict(good, k=0), dict(good, n_env=-1)):
+        with pytest.raises(ValueError, match="invalid argument"):
+            R.forward_views(act["means3d"], act["opacities"], [spec], semantic=bad, **kw)
+    outs = [dict(color=torch.empty((3, v.height, v.width), device=dev), depth=torch.empty((1, v.height, v.width), device=dev),
+                 radii=None)]                                   # no sem_color target
+    with pytest.raises(ValueError, match="invalid argument"):
+        R.forward_views(act["means3d"], act["opacities"], [spec], semantic=good, outputs=outs, **kw)
+    torch.cuda.synchronize()
+    again = R.forward_views(act["means3d"], act["opacities"], [spec], semantic=good, **kw)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(again["sem_color"], ok["sem_color"])
