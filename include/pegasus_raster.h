@@ -197,6 +197,16 @@ int32_t pgr_forward_batch_profiled(const PgrScene *scene, const PgrSemantic *sem
                                    size_t workspace_bytes, int64_t max_instances_per_view,
                                    int64_t *num_instances, void *stream, float *stage_ms);
 
+/* Conservative block visibility (pegasus_amd/csrc/blockcull.hip.h): bit (v % 32) of
+ * vis_words[g * ceil(n_views / 32) + v / 32] is CLEAR only if none of the Gaussians [64 g, 64 g + 64) can get a
+ * non-zero radius in view v (all behind the near plane, or all tile rectangles empty) -- the test the batch entry
+ * points run internally to skip whole waves in the per-Gaussian stages (switch: environment PGR_BLOCK_CULL=0; outputs
+ * never depend on it).  A block-granular, many-view relative of markVisible; exposed for the parity tests.
+ * vis_words: device [ceil(n / 64) * ceil(n_views / 32)]. */
+size_t pgr_block_visibility_workspace_bytes(int32_t n, int32_t n_views);
+int32_t pgr_block_visibility(const PgrScene *scene, int32_t n_views, const PgrCamera *cameras, void *workspace,
+                             size_t workspace_bytes, uint32_t *vis_words, void *stream);
+
 /* Fill `view` with device pointers into view `view_index` of a workspace laid out for
  * (n,width,height,max_instances,n_views). */
 int32_t pgr_workspace_view(void *workspace, size_t workspace_bytes, int32_t n, int32_t width, int32_t height,

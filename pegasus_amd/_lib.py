@@ -101,6 +101,9 @@ SYMBOLS = {
     "pgr_compose_object": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                        C.POINTER(PgrObjectPose), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                        C.c_void_p]),
+    "pgr_block_visibility_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "pgr_block_visibility": (C.c_int32, [C.POINTER(PgrScene), C.c_int32, C.POINTER(PgrCamera), C.c_void_p, C.c_size_t,
+                                         C.c_void_p, C.c_void_p]),
     "pgr_mark_visible": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgr_color_masks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
                                     C.c_void_p, C.c_void_p]),

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "backward.hip.h"
+#include "blockcull.hip.h"
 #include "knn.hip.h"
 #include "compose.hip.h"
 #include "composite.hip.h"
@@ -33,6 +34,12 @@ static bool hip_ok(hipError_t e, const char* what) {
 }
 
 static size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// A/B switch for tests and measurements (read per call; results never depend on it)
+static bool block_cull_enabled() {
+    const char* e = getenv("PGR_BLOCK_CULL");
+    return !(e && e[0] == '0');
+}
 
 
 static Layout make_layout(int32_t n, int32_t width, int32_t height, int64_t max_instances) {
@@ -108,7 +115,8 @@ static ViewWs carve(char* ws, const Layout& L) {
 
 // Batch header placed in front of the per-view slices.
 struct BatchLayout {
-    size_t tables, cams, status, tile_counts, order_state, work_order, long_list, tie_inv, views, total;
+    size_t tables, cams, status, tile_counts, order_state, work_order, long_list, tie_inv, vis, views, total;
+    int n_groups, vis_words;
     size_t view_table_off, bin_table_off, pre_table_off, tables_bytes;   // inside `tables` (one H2D copy)
     size_t order_slots;
     size_t per_view;
@@ -138,6 +146,9 @@ static BatchLayout make_batch_layout(const Layout& L, int n_views, size_t n_scen
     B.work_order = take(B.order_slots * 4);
     B.long_list = take((size_t)n_views * L.tiles * 4);
     B.tie_inv = take((size_t)n_scene * 4);     // inverse of PgrScene::tie_index (filled only when one is given)
+    B.n_groups = (int)((n_scene + WAVE - 1) / WAVE);
+    B.vis_words = (n_views + 31) / 32;
+    B.vis = take((size_t)B.n_groups * B.vis_words * 4);
     B.views = off;
     B.per_view = align_up(L.total);
     B.total = off + (size_t)n_views * B.per_view;
@@ -280,10 +291,13 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         }
         pack_camera_kernel<<<cnt, 64, 0, stream>>>(cp, W, H, cams_dev + v0);
     }
+    // which 64-Gaussian blocks can show up in which view: decided by the preprocess waves themselves (conservative;
+    // PGR_BLOCK_CULL=0 switches the test off), left in `vis` for the binning walks
+    uint32_t* vis = block_cull_enabled() ? reinterpret_cast<uint32_t*>(ws + B.vis) : nullptr;
     // one pass over the Gaussians for the whole batch (scene data read once, per-view outputs written)
     const PosedDev pd{posed ? posed->object_id : nullptr, posed ? posed->poses : nullptr, posed ? posed->k_objects : 0};
     const int deg = scene->shs ? scene->sh_degree : 0;
-#define PGR_PRE(D, Pz) preprocess_batch_kernel<D, Pz><<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, cams_dev, pre_table, n_views, pd)
+#define PGR_PRE(D, Pz) preprocess_batch_kernel<D, Pz><<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, cams_dev, pre_table, n_views, pd, vis, B.vis_words)
     if (posed) {
         switch (deg) { case 0: PGR_PRE(0, true); break; case 1: PGR_PRE(1, true); break; case 2: PGR_PRE(2, true); break;
                        default: PGR_PRE(3, true); break; }
@@ -298,11 +312,13 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     const size_t lds = bin_lds_bytes(L.tiles);
     if (!hip_ok(hipMemsetAsync(ws + B.tile_counts, 0, (size_t)n_views * L.tiles * 8, stream), "memset tile counts"))
         return fail(PGR_ERR_LAUNCH_FAILURE);
-    bin_kernel<false><<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(bin_table, N, grid_x, L.tiles, W, H);
+    bin_kernel<false><<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(bin_table, N, grid_x, L.tiles, W, H, vis,
+                                                                               B.vis_words);
     tile_scan_kernel<<<n_views, 1024, 0, stream>>>(bin_table, L.tiles, (uint32_t)max_instances);
     mark(2);
     // ---- stage 2: scatter (depth bits, index) into the tiles' slices
-    bin_kernel<true><<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(bin_table, N, grid_x, L.tiles, W, H);
+    bin_kernel<true><<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(bin_table, N, grid_x, L.tiles, W, H, vis,
+                                                                              B.vis_words);
     mark(3);
     // ---- stage 3: work order (XCD streams, longest lists first) + per-tile (depth, index) sort
     if (!hip_ok(hipMemsetAsync(order_state, 0, ORDER_STATE_WORDS * 4, stream), "memset order state") ||
@@ -524,6 +540,43 @@ int32_t pgr_compose_object(int32_t n, const float* xyz, const float* rot, const 
     compose_object_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream_v)>>>(
         n, xyz, rot, f_rest, n_rest, in_rest_stride, P, out_xyz, out_rot, out_rest, out_rest_stride);
     return hip_ok(hipGetLastError(), "compose_object launch") ? PGR_OK : PGR_ERR_LAUNCH_FAILURE;
+}
+
+size_t pgr_block_visibility_workspace_bytes(int32_t n, int32_t n_views) {
+    if (n < 0 || n_views <= 0) return 0;
+    return align_up((size_t)n_views * sizeof(CameraDev)) + align_up((size_t)((n + WAVE - 1) / WAVE) * sizeof(BlockBounds) + 1);
+}
+
+int32_t pgr_block_visibility(const PgrScene* scene, int32_t n_views, const PgrCamera* cams, void* workspace,
+                             size_t workspace_bytes, uint32_t* vis_words, void* stream_v) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    if (int rc = check_scene(scene)) return rc;
+    if (n_views <= 0 || !cams) return PGR_ERR_INVALID_ARGUMENT;
+    if (scene->n == 0) return PGR_OK;
+    if (!workspace || !vis_words) return PGR_ERR_INVALID_ARGUMENT;
+    if (workspace_bytes < pgr_block_visibility_workspace_bytes(scene->n, n_views)) return PGR_ERR_WORKSPACE_TOO_SMALL;
+    const int W = cams[0].image_width, H = cams[0].image_height;
+    for (int v = 0; v < n_views; ++v)
+        if (cams[v].image_width != W || cams[v].image_height != H || W <= 0 || H <= 0 || !cams[v].viewmatrix ||
+            !cams[v].projmatrix || !cams[v].campos || !cams[v].bg || !(cams[v].tanfovx > 0.f) || !(cams[v].tanfovy > 0.f))
+            return PGR_ERR_INVALID_ARGUMENT;
+    char* ws = static_cast<char*>(workspace);
+    auto* cams_dev = reinterpret_cast<CameraDev*>(ws);
+    auto* bounds = reinterpret_cast<BlockBounds*>(ws + align_up((size_t)n_views * sizeof(CameraDev)));
+    for (int v0 = 0; v0 < n_views; v0 += CAM_PACK_MAX) {
+        CamPack cp;
+        const int cnt = std::min(CAM_PACK_MAX, n_views - v0);
+        for (int k = 0; k < cnt; ++k) {
+            const PgrCamera& c = cams[v0 + k];
+            cp.view[k] = c.viewmatrix; cp.proj[k] = c.projmatrix; cp.campos[k] = c.campos; cp.bg[k] = c.bg;
+            cp.tanfovx[k] = c.tanfovx; cp.tanfovy[k] = c.tanfovy;
+        }
+        pack_camera_kernel<<<cnt, 64, 0, stream>>>(cp, W, H, cams_dev + v0);
+    }
+    const int groups = (scene->n + WAVE - 1) / WAVE, words = (n_views + 31) / 32;
+    block_bounds_kernel<<<(groups + 3) / 4, 256, 0, stream>>>(*scene, nullptr, bounds, groups);
+    block_cull_kernel<<<dim3((groups + 7) / 8, words), 256, 0, stream>>>(bounds, groups, cams_dev, n_views, words, vis_words);
+    return hip_ok(hipGetLastError(), "block_visibility launch") ? PGR_OK : PGR_ERR_LAUNCH_FAILURE;
 }
 
 int32_t pgr_mark_visible(int32_t n, const float* means3d, const float* viewmatrix, uint8_t* present, void* stream_v) {

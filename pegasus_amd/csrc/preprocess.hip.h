@@ -10,6 +10,7 @@
 // the near plane, +196 B (opacity, 48 SH floats) for the ones whose tile rectangle is non-empty;
 // writes 4+8 B (radius, packed rectangle) for every Gaussian and 44 B for survivors.
 #pragma once
+#include "blockcull.hip.h"
 #include "pgr_common.h"
 
 namespace pgr {
@@ -212,14 +213,26 @@ struct PosedDev {
     int32_t k;
 };
 
+// vis_out != NULL: hierarchical culling (blockcull.hip.h).  The wave first bounds its 64 Gaussians, then lane l decides
+// for view 64 c + l whether the whole block is certainly culled there (one ballot = 64 views): such views are skipped by
+// the whole wave (radii / rectangles, where the caller wants them, are zero; the candidate rectangle is not written:
+// the binning walk consults the same bits, stored as vis_out[group * vis_words + view / 32]).
 template <int DEG, bool POSED>
 __global__ __launch_bounds__(PRE_BLOCK) void preprocess_batch_kernel(PgrScene sc, const CameraDev* __restrict__ cams,
                                                                      const PreOut* __restrict__ outs, int n_views,
-                                                                     PosedDev posed) {
+                                                                     PosedDev posed, uint32_t* __restrict__ vis_out,
+                                                                     int vis_words) {
     const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
-    if (i >= sc.n) return;
-    const float bx = sc.means3d[3 * i + 0], by = sc.means3d[3 * i + 1], bz = sc.means3d[3 * i + 2];
-    const int oid = POSED ? posed.object_id[i] : 0;
+    const int lane = threadIdx.x & (WAVE - 1);
+    if (i - lane >= sc.n) return;            // the whole wave is past the end
+    const bool real = i < sc.n;              // lanes past the end stay for the wave-wide steps and do nothing else
+    const int group = __builtin_amdgcn_readfirstlane(i / WAVE);
+    BlockBounds bounds;
+    if (vis_out) bounds = wave_block_bounds(sc, i, real, POSED ? posed.object_id : nullptr);
+    unsigned long long vis_mask = ~0ull;
+    const float bx = real ? sc.means3d[3 * i + 0] : 0.f, by = real ? sc.means3d[3 * i + 1] : 0.f,
+                bz = real ? sc.means3d[3 * i + 2] : 0.f;
+    const int oid = POSED && real ? posed.object_id[i] : 0;
     float cov[6];
     bool have_cov = false, have_sh = false;
     ShRegs sh;
@@ -228,6 +241,22 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_batch_kernel(PgrScene sc
     for (int v = 0; v < n_views; ++v) {
         const CameraDev& cam = cams[v];
         const PreOut& o = outs[v];
+        if (vis_out) {
+            if ((v & (WAVE - 1)) == 0) {
+                const int view = v + lane;
+                vis_mask = __ballot(view < n_views && !block_is_culled(bounds, cams[view]));
+                if (lane == 0) {
+                    vis_out[(size_t)group * vis_words + (v >> 5)] = (uint32_t)vis_mask;
+                    if ((v >> 5) + 1 < vis_words) vis_out[(size_t)group * vis_words + (v >> 5) + 1] = (uint32_t)(vis_mask >> 32);
+                }
+            }
+            if (!((vis_mask >> (v & (WAVE - 1))) & 1ull)) {
+                if (real && o.radii) o.radii[i] = 0;
+                if (real && o.rects) o.rects[i] = make_uint2(0u, 0u);
+                continue;
+            }
+        }
+        if (!real) continue;                 // (rejoins the wave at the next view's ballot)
         int radius = 0;
         uint2 rect = make_uint2(0u, 0u), crect = make_uint2(0u, 0u);
         const float* vm = cam.view;

@@ -112,9 +112,12 @@ __host__ __device__ inline size_t bin_lds_bytes(int tiles) {
     return ((size_t)(tiles < BIN_LDS_TILES ? tiles : BIN_LDS_TILES) + 3) / 4 * 16 + (size_t)BIN_WAVES * BIN_STAGE_WORDS * 4;
 }
 
+// vis: blockcull.hip.h's visibility words (NULL = all visible); a 64-Gaussian group whose bit is clear has no rectangle
+// to read (the preprocess did not write one).
 template <bool SCATTER>
 __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restrict__ views, int n, int grid_x,
-                                                          int tiles, int W, int H) {
+                                                          int tiles, int W, int H, const uint32_t* __restrict__ vis,
+                                                          int vis_words) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const BinView& bv = views[blockIdx.y];
     if (SCATTER && bv.counters[1]) return;   // overflow: reported by the host, nothing may be written past the buffers
@@ -136,6 +139,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restr
             const int i = base + lane;
             uint32_t area = 0;
             float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
+            if (vis && !((vis[(size_t)(base / WAVE) * vis_words + (blockIdx.y >> 5)] >> (blockIdx.y & 31)) & 1u)) continue;
             if (i < end) {
                 const uint2 r = bv.rects[i];
                 const int w = (int)(r.y & 0xffff) - (int)(r.x & 0xffff), h = (int)(r.y >> 16) - (int)(r.x >> 16);

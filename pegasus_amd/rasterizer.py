@@ -287,3 +287,36 @@ def workspace_view(view_index: int = 0) -> dict:
                                     info["used_max_instances"], info["n_views"], view_index, C.byref(v)),
                "pgr_workspace_view")
     return {k: getattr(v, k) for k, _ in _lib.PgrWorkspaceView._fields_}
+
+
+def block_visibility(means3D, views: Sequence[ViewSpec], *, scales=None, rotations=None, cov3D_precomp=None,
+                     scale_modifier=1.0) -> torch.Tensor:
+    """bool[ceil(n / 64), len(views)]: False = none of the 64 Gaussians of that block can have a non-zero radius in
+    that view (pgr_block_visibility: the conservative test the batch calls use internally to skip whole waves)."""
+    L = _lib.lib()
+    device = means3D.device
+    if device.type != "cuda":
+        raise RuntimeError("block_visibility needs tensors on a HIP device")
+    n, nv = int(means3D.shape[0]), len(views)
+    means3D, scales, rotations, cov3D_precomp = (dev_f32(t, device) for t in (means3D, scales, rotations, cov3D_precomp))
+    ones = torch.ones((max(n, 1),), dtype=torch.float32, device=device)          # opacities / colours are not looked at
+    scene = _lib.PgrScene(n=n, means3d=_ptr(means3D), opacities=_ptr(ones), scales=_ptr(scales), rotations=_ptr(rotations),
+                          cov3d_precomp=_ptr(cov3D_precomp), shs=None, colors_precomp=_ptr(ones), sh_degree=0, sh_stride=0,
+                          scale_modifier=float(scale_modifier), tie_index=None)
+    cams = (_lib.PgrCamera * nv)()
+    keep = []
+    for i, v in enumerate(views):
+        bg, vm, pm, cp = (dev_f32(t, device) for t in (v.bg, v.viewmatrix, v.projmatrix, v.campos))
+        keep.append((bg, vm, pm, cp))
+        cams[i] = _lib.PgrCamera(image_width=int(v.image_width), image_height=int(v.image_height), tanfovx=float(v.tanfovx),
+                                 tanfovy=float(v.tanfovy), viewmatrix=_ptr(vm), projmatrix=_ptr(pm), campos=_ptr(cp), bg=_ptr(bg))
+    groups, words = (n + 63) // 64, (nv + 31) // 32
+    out = torch.zeros((groups, words), dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        ws = torch.empty(L.pgr_block_visibility_workspace_bytes(n, nv) + 256, dtype=torch.uint8, device=device)
+        _lib.check(L.pgr_block_visibility(C.byref(scene), nv, cams, C.c_void_p(ws.data_ptr()), ws.numel(),
+                                          C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(device).cuda_stream)),
+                   "pgr_block_visibility")
+        torch.cuda.current_stream(device).synchronize()
+    bits = (out.unsqueeze(2) >> torch.arange(32, device=device, dtype=torch.int32)) & 1
+    return bits.reshape(groups, words * 32)[:, :nv].bool()

@@ -24,6 +24,10 @@ def test_render_facade_and_mask_wrappers(oracle, gpu_device):
         from helpers import assert_images_match
 
         dev = gpu_device
+        # the reference's render loop runs under torch.no_grad() (/root/reference/pegasus.py:248); outside it render()
+        # hands back graph-attached tensors, exactly like upstream (viewspace_points requires grad)
+        grad_was = torch.is_grad_enabled()
+        torch.set_grad_enabled(False)
         rng = np.random.default_rng(2)
         env_c = scenes.ground_plane(rng, 15000, 1.0, np.log(0.006), 0.4, 0.1, 0.005)
         obj_c = [scenes.rigid_transform(scenes.box_object(rng, 5000, (0.1, 0.12, 0.16), np.log(0.004), 0.3, 0.2, k + 1),
@@ -91,8 +95,15 @@ def test_render_facade_and_mask_wrappers(oracle, gpu_device):
         sem = prender.render_semanticsegmentation_mask(cam, env, objs, colors, H, W, pipe, bg, False)
         assert sem.dtype == np.uint8 and sem.shape == (H, W, 3)
         np.testing.assert_array_equal(sem, (np.ascontiguousarray(seg.numpy()) * 255).astype("uint8"))
+        torch.set_grad_enabled(grad_was)
+        pkg = render(cam, scene, pipe, bg)                       # outside no_grad: upstream's training-style contract
+        assert pkg["render"].requires_grad and pkg["viewspace_points"].requires_grad
     finally:
         sys.path.remove(str(ROOT / "compat"))
+        try:
+            torch.set_grad_enabled(True)
+        except NameError:
+            pass
 
 
 @pytest.mark.gpu
