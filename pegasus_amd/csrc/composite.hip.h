@@ -48,6 +48,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int HALF_ROWS = 8;     // rows per half tile (backward.hip.h's work unit)
 constexpr int WAVE_BATCH = 64;   // list entries staged per round
 constexpr uint32_t ITEMS_PER_TILE = 4;   // work items per 16x16 tile: its four 8x8 quarters
+#ifndef PGR_PAIR_UNROLL
+#define PGR_PAIR_UNROLL 4
+#endif
+constexpr int PAIR_UNROLL = PGR_PAIR_UNROLL;   // entry pairs per trip of the compositing loop
 
 #ifndef PGR_COMP_WAVES
 #define PGR_COMP_WAVES 0         // 0: let the compiler pick; k: cap VGPRs for k waves/SIMD (tuning builds)
@@ -215,8 +219,19 @@ __global__ __launch_bounds__(WAVE) PGR_COMP_OCC void composite_quarter_kernel(co
         if (FUSED && sem_alive != 0ull) objbits = __builtin_amdgcn_ballot_w64(lane < cnt && s_s[lane].w != 0.0f);
         gather(base + WAVE_BATCH);                // lands while this batch is composited
         const int pairs = __builtin_amdgcn_readfirstlane((cnt + 1) >> 1);
-        for (int k = 0; k < pairs; ++k) {
-            const float4 g0 = s_g[3 * k], g1 = s_g[3 * k + 1], g2 = s_g[3 * k + 2];
+        // PAIR_UNROLL pairs per trip.  The LDS byte offsets of the trip live in VGPRs the compiler cannot see through
+        // (it would otherwise keep them on the scalar unit and pay a v_mov per ds_read: 3-4 of the ~36 VALU instructions
+        // of a pair); inside a trip every address is one of them + an immediate.
+        uint32_t og = 0, oc = 0;
+        asm volatile("" : "+v"(og), "+v"(oc));
+        for (int k0 = 0; k0 < pairs; k0 += PAIR_UNROLL, og += PAIR_UNROLL * 48u, oc += PAIR_UNROLL * 32u) {
+#pragma unroll
+            for (int ku = 0; ku < PAIR_UNROLL; ++ku) {
+            const int k = k0 + ku;
+            if (ku > 0 && k >= pairs) break;
+            const char* pg = reinterpret_cast<const char*>(s_g) + og + ku * 48;
+            const float4 g0 = *reinterpret_cast<const float4*>(pg), g1 = *reinterpret_cast<const float4*>(pg + 16),
+                         g2 = *reinterpret_cast<const float4*>(pg + 32);
             // geometry of entries 2k and 2k+1 side by side; per entry this is the oracle's operation order
             const f32x2 dx = (f32x2){g0.x, g0.y} - pxf;
             const f32x2 dy = (f32x2){g0.z, g0.w} - pyf;
@@ -231,12 +246,15 @@ __global__ __launch_bounds__(WAVE) PGR_COMP_OCC void composite_quarter_kernel(co
                                                 __builtin_amdgcn_ballot_w64(!(power.y > 0.0f))};
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const float alpha = fminf(ALPHA_MAX, u ? araw.y : araw.x);
+                // min(0.99, .) as the bare instruction: fminf() on the unpacked high half costs a canonicalising v_max first
+                // (the product is already canonical); v_min_f32 returns the other operand for a NaN, like fminf
+                float alpha;
+                asm("v_min_f32 %0, %1, %2" : "=v"(alpha) : "s"(ALPHA_MAX), "v"(u ? araw.y : araw.x));
                 // power <= 0 and alpha >= 1/255: the entry counts for this pixel (in either image)
                 const unsigned long long hit = m_pw[u] & __builtin_amdgcn_ballot_w64(!(alpha < ALPHA_MIN));
                 // (scalar branch) about a fifth of the parked entries reach no pixel that is still alive
                 if (const unsigned long long valid = alive & hit; valid != 0ull) {
-                    const float4 c = s_c[2 * k + u];
+                    const float4 c = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_c) + oc + (2 * ku + u) * 16);
                     const float test_T = fmaf(-alpha, T, T);
                     const unsigned long long stop = valid & __builtin_amdgcn_ballot_w64(test_T < T_EPS);
                     alive &= ~stop;
@@ -256,8 +274,8 @@ __global__ __launch_bounds__(WAVE) PGR_COMP_OCC void composite_quarter_kernel(co
                 if (FUSED) {
                     // wave-uniform (scalar) test: is this entry an object's?
                     if (const unsigned long long valid = sem_alive & hit; ((objbits >> (2 * k + u)) & 1ull) && valid != 0ull) {
-                        const float4 sc = s_s[2 * k + u];
-                        const float depth = s_c[2 * k + u].w;
+                        const float4 sc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_s) + oc + (2 * ku + u) * 16);
+                        const float depth = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(s_c) + oc + (2 * ku + u) * 16 + 12);
 #ifdef PGR_COMP_STATS
                         st_sem++;
 #endif
@@ -274,6 +292,7 @@ __global__ __launch_bounds__(WAVE) PGR_COMP_OCC void composite_quarter_kernel(co
                 }
             }
             if ((alive | sem_alive) == 0ull) goto finished;
+            }
         }
         __syncthreads();
     }

@@ -630,6 +630,20 @@ extern "C" int32_t pgr_debug_sort_stats(unsigned long long* out, int32_t reset) 
 }
 #endif
 
+#ifdef PGR_SORT_TIMING
+// copies up to `cap` records (12 x u64 each) to the host and resets the recorder; returns the number recorded
+extern "C" int32_t pgr_debug_sort_timing(unsigned long long* out, int32_t cap) {
+    if (hipDeviceSynchronize() != hipSuccess) return -4;
+    unsigned int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(pgr::g_sort_rec_n), 4) != hipSuccess) return -4;
+    const unsigned int take = std::min<unsigned int>(std::min<unsigned int>(n, (unsigned)cap), (unsigned)pgr::SORT_REC_MAX);
+    if (take && hipMemcpyFromSymbol(out, HIP_SYMBOL(pgr::g_sort_rec), (size_t)take * 96) != hipSuccess) return -4;
+    const unsigned int zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(pgr::g_sort_rec_n), &zero, 4) != hipSuccess) return -4;
+    return (int32_t)take;
+}
+#endif
+
 // ---- 3-nearest-neighbour mean squared distance (simple_knn.distCUDA2) ---------------------------------------------
 namespace {
 struct KnnLayout { size_t grid, count, start, sorted, total; int target; size_t cells; };

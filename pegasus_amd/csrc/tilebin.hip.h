@@ -396,6 +396,22 @@ __device__ unsigned long long g_sort_stats[8];   // [0] lists, [1] keys, [2] sum
 
 constexpr uint32_t BUCKET_SQ_LIMIT = 8;
 
+#ifdef PGR_SORT_TIMING
+// debug build only: shader-clock stamps of wave 0 at the phase boundaries of bucket_sort_tile, one record per list
+// (no atomics on shared words while the kernel runs: one slot claim at the end).  scripts/sort_timing.py
+constexpr int SORT_REC_MAX = 1 << 18;
+__device__ unsigned long long g_sort_rec[SORT_REC_MAX][12];    // [0..8] phase cycles, [9] tier, [10] keys, [11] start stamp
+__device__ unsigned int g_sort_rec_n;
+#define SORT_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
+    ts_[k] = now_ - t_prev_; t_prev_ = now_; } } while (0)
+#define SORT_FLUSH() do { if (threadIdx.x == 0) { const unsigned int slot_ = atomicAdd(&g_sort_rec_n, 1u); \
+    if (slot_ < (unsigned)SORT_REC_MAX) { for (int k_ = 0; k_ < 9; ++k_) g_sort_rec[slot_][k_] = ts_[k_]; \
+    g_sort_rec[slot_][9] = TIER_; g_sort_rec[slot_][10] = (unsigned long long)n; g_sort_rec[slot_][11] = t_start_; } } } while (0)
+#else
+#define SORT_STAMP(k) do { } while (0)
+#define SORT_FLUSH() do { } while (0)
+#endif
+
 // Sorts n <= THREADS*E keys of `bucket` into out[] (indices) -- same contract as merge_sort_tile without keys_out.
 // NB = number of buckets (multiple of THREADS; THREADS*E = one per key of capacity).  DIRECT: sorted indices go
 // straight to global memory (4-B scattered stores into an L2-resident list) instead of through an LDS image -- the
@@ -414,6 +430,11 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(lds + (size_t)CAP * 8);     // [NB], later the sorted indices
     uint32_t* s_misc = s_hist + NB;                                            // [0] min [1] max [2] sum k^2 [4..] wave totals
     const int t = threadIdx.x, lane = t & (WAVE - 1), wave = t / WAVE;
+#ifdef PGR_SORT_TIMING
+    constexpr int TIER_ = THREADS == 256 ? 0 : (THREADS == 512 ? 1 : 2);
+    unsigned long long t_prev_ = __builtin_readcyclecounter(), ts_[9] = {};
+    const unsigned long long t_start_ = t_prev_;
+#endif
 
     uint32_t d[E], id[E];
     uint32_t dmin = 0xffffffffu, dmax = 0u;
@@ -430,14 +451,14 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
     for (int i = t; i < NB; i += THREADS) s_hist[i] = 0u;
     if (t < 4 + WAVES) s_misc[t] = t == 0 ? 0xffffffffu : 0u;
     __syncthreads();
-    // block min / max of the depth bits: butterfly inside the wave, one LDS atomic per wave
-#pragma unroll
-    for (int m = 1; m < WAVE; m <<= 1) {
-        dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, m));
-        dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, m));
-    }
-    if (lane == 0) { atomicMin(&s_misc[0], dmin); atomicMax(&s_misc[1], dmax); }
+    SORT_STAMP(0);      // key load + zero fill
+    // block min / max of the depth bits: DPP prefix inside the wave (VALU only: a ds_bpermute butterfly pays six LDS
+    // round trips), one LDS atomic per wave.  min as max of the complement (0 is the prefix-max identity).
+    dmin = ~wave_inclusive_max(~dmin);
+    dmax = wave_inclusive_max(dmax);
+    if (lane == WAVE - 1) { atomicMin(&s_misc[0], dmin); atomicMax(&s_misc[1], dmax); }
     __syncthreads();
+    SORT_STAMP(1);      // min / max
     const uint32_t mn = s_misc[0];
     const float scale = (float)NB / ((float)(s_misc[1] - mn) + 1.0f);
     // monotone in d: uint->float conversion, multiplication by a positive constant, truncation and clamp all are
@@ -451,6 +472,7 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
         }
     }
     __syncthreads();
+    SORT_STAMP(2);      // histogram atomics
     // pass A: every wave owns NB / WAVES consecutive buckets (CH chunks of 64): totals and sum of squares
     const int wbase = wave * (WAVE * CH);
     uint32_t tot = 0, sq = 0;
@@ -459,10 +481,11 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
         const uint32_t h = s_hist[wbase + c * WAVE + lane];
         tot += h; sq += h * h;
     }
-#pragma unroll
-    for (int m = 1; m < WAVE; m <<= 1) { tot += (uint32_t)__shfl_xor((int)tot, m); sq += (uint32_t)__shfl_xor((int)sq, m); }
-    if (lane == 0) { s_misc[4 + wave] = tot; atomicAdd(&s_misc[2], sq); }
+    tot = wave_inclusive_scan(tot);
+    sq = wave_inclusive_scan(sq);
+    if (lane == WAVE - 1) { s_misc[4 + wave] = tot; atomicAdd(&s_misc[2], sq); }
     __syncthreads();
+    SORT_STAMP(3);      // totals + squares
     // average occupancy is n / NB by construction: reject when the squares exceed what an even spread would cost
     const bool reject = s_misc[2] > BUCKET_SQ_LIMIT * (uint32_t)n * (uint32_t)((CAP + NB - 1) / NB);
 #ifdef PGR_SORT_STATS
@@ -480,43 +503,57 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
     for (int c = 0; c < CH; ++c) {
         const uint32_t h = s_hist[wbase + c * WAVE + lane];
         const uint32_t incl = wave_inclusive_scan(h);
-        s_hist[wbase + c * WAVE + lane] = carry + incl - h;
+        // bucket start | members << 16 (both < 2^16: n <= 16384): the key scatter below then knows its bucket's
+        // extent from the one word it reads anyway, and the ranking needs no further look-up
+        s_hist[wbase + c * WAVE + lane] = (carry + incl - h) | (h << 16);
         carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
     }
     __syncthreads();
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-        if (e * THREADS + t < n) s_keys[s_hist[br[e] >> 16] + (br[e] & 0xffffu)] = ((uint64_t)d[e] << 32) | id[e];
-    __syncthreads();
-    // exact place inside the bucket: number of smaller keys among its members
-    uint32_t fin[E];
+    SORT_STAMP(4);      // scan
+    uint32_t fin[E];     // here: bucket start | members << 16
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         fin[e] = 0u;
         if (e * THREADS + t < n) {
-            const uint32_t b = br[e] >> 16;
-            const uint32_t s0 = s_hist[b], s1 = b + 1 < (uint32_t)NB ? s_hist[b + 1] : (uint32_t)n;
-            const uint64_t key = ((uint64_t)d[e] << 32) | id[e];
-            uint32_t rank = 0, same = 0;             // same: members with this key's depth bits (itself included)
-            for (uint32_t j = s0; j < s1; ++j) {
-                const uint64_t kj = s_keys[j];
-                rank += kj < key ? 1u : 0u;
-                same += (uint32_t)(kj >> 32) == d[e] ? 1u : 0u;
-            }
-            if (tie && same > 1u) {
-                // exact depth tie between different Gaussians: the CALLER's index decides (a few keys per list;
-                // measured: cheaper than carrying the tie index in the bucket entries or in the LDS keys)
-                const int32_t mine = tie[id[e]];
-                rank = 0;
-                for (uint32_t j = s0; j < s1; ++j) {
+            fin[e] = s_hist[br[e] >> 16];
+            s_keys[(fin[e] & 0xffffu) + (br[e] & 0xffffu)] = ((uint64_t)d[e] << 32) | id[e];
+        }
+    }
+    __syncthreads();
+    SORT_STAMP(5);      // keys to their buckets
+    // exact place inside the bucket: number of smaller keys among its members.  A key alone in its bucket (about half
+    // of them at one bucket per key) is in place already: no LDS access at all.  (Tried and measured slower: advancing
+    // the keys of a thread in lockstep, member m of every key's bucket per round -- the predicated reads did not
+    // overlap and the bookkeeping cost more than the round trips it saved.)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (e * THREADS + t < n) {
+            const uint32_t s0 = fin[e] & 0xffffu, cnt = fin[e] >> 16;
+            uint32_t rank = 0;
+            if (cnt > 1u) {
+                const uint64_t key = ((uint64_t)d[e] << 32) | id[e];
+                uint32_t same = 0;                       // members with this key's depth bits (itself included)
+                for (uint32_t j = s0; j < s0 + cnt; ++j) {
                     const uint64_t kj = s_keys[j];
-                    const uint32_t dj = (uint32_t)(kj >> 32);
-                    rank += (dj < d[e] || (dj == d[e] && (uint32_t)kj != id[e] && tie[(uint32_t)kj] < mine)) ? 1u : 0u;
+                    rank += kj < key ? 1u : 0u;
+                    same += (uint32_t)(kj >> 32) == d[e] ? 1u : 0u;
+                }
+                if (tie && same > 1u) {
+                    // exact depth tie between different Gaussians: the CALLER's index decides (a few keys per list;
+                    // measured: cheaper than carrying the tie index in the bucket entries or in the LDS keys)
+                    const int32_t mine = tie[id[e]];
+                    rank = 0;
+                    for (uint32_t j = s0; j < s0 + cnt; ++j) {
+                        const uint64_t kj = s_keys[j];
+                        const uint32_t dj = (uint32_t)(kj >> 32);
+                        rank += (dj < d[e] || (dj == d[e] && (uint32_t)kj != id[e] && tie[(uint32_t)kj] < mine)) ? 1u : 0u;
+                    }
                 }
             }
             fin[e] = s0 + rank;
         }
     }
+    SORT_STAMP(6);      // rank inside the bucket
     if (DIRECT) {
         uint32_t best = 0;
 #pragma unroll
@@ -530,6 +567,8 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
             for (int m = 1; m < WAVE; m <<= 1) best = max(best, (uint32_t)__shfl_xor((int)best, m));
             if (lane == 0 && best) atomicMax(obj_last, best);
         }
+        SORT_STAMP(7);  // direct output
+        SORT_FLUSH();
         return true;
     }
     __syncthreads();
@@ -539,7 +578,10 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
         if (e * THREADS + t < n) s_idx[fin[e]] = id[e];
     __syncthreads();
     for (int i = t; i < n; i += THREADS) out[i] = s_idx[i];
+    SORT_STAMP(7);      // index image + output
     if (n_env >= 0) mark_last_object<THREADS>([&](int i) { return s_idx[i]; }, n, n_env, obj_last, pos_offset);
+    SORT_STAMP(8);      // last object marker
+    SORT_FLUSH();
     return true;
 }
 
