@@ -291,6 +291,18 @@ def main():
             roofline["traffic_source"] = pmc["source"]
     except (OSError, ValueError, KeyError):
         pass
+    # the compositor is not bound by either roofline the schema names (HBM / MFMA): report beside them how busy the unit
+    # that does bound it is -- VALU issue slots from the SQ counters (profiles/pmc_busy.json, scripts/pmc_busy.py)
+    try:
+        busy = json.loads((ROOT / "profiles" / "pmc_busy.json").read_text())
+        k = next((v for name, v in busy["kernels"].items() if dom_name == "composite" and "composite_quarter_kernel<false, false>" in name), None)
+        if k:
+            roofline["valu_issue"] = {"busy_frac": k["valu_busy"], "lds_busy_frac": k["lds_busy"],
+                                      "kernel": "composite_quarter_kernel<false, false> (raster-only twin of the fused kernel)",
+                                      "definition": "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles); SQ_LDS_IDX_ACTIVE / (256 CUs x kernel cycles)",
+                                      "source": busy["source"]}
+    except (OSError, ValueError, KeyError):
+        pass
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:

@@ -149,3 +149,23 @@ def test_frames_are_bit_identical_with_and_without_block_culling(gpu_device):
     off = _with_cull(False, lambda: snap(fr.render_frames(specs, poses=poses)))
     for k in keys:
         assert torch.equal(on[k], off[k]), ("posed", k)
+
+
+def test_more_than_64_views_per_batch(gpu_device):
+    """The visibility words of a batch are built 64 views per ballot: 70 views cross a ballot and a word boundary."""
+    import torch
+    from pegasus_amd import rasterizer as R
+    from pegasus_amd.scene_order import spatial_order
+    cloud, views = scenes.scene_c3(scale=0.01, n_views=70, width=160, height=112)
+    act = cloud.activated()
+    perm = spatial_order(act["means3d"], cloud.object_id)
+    act_t = {k: torch.from_numpy(np.ascontiguousarray(a[perm])).to(gpu_device) for k, a in act.items()}
+    specs = _specs(views, gpu_device)
+    on = _with_cull(True, lambda: _render(act_t, specs))
+    off = _with_cull(False, lambda: _render(act_t, specs))
+    vis = R.block_visibility(act_t["means3d"], specs, scales=act_t["scales"], rotations=act_t["rotations"])
+    assert vis.shape[1] == 70 and 0.05 < 1.0 - float(vis.float().mean()) < 0.95
+    for v in range(70):
+        assert torch.equal(on[v]["radii"], off[v]["radii"]), v
+        assert torch.equal(on[v]["n_contrib"], off[v]["n_contrib"]), v
+        assert torch.equal(on[v]["color"], off[v]["color"]), v
