@@ -64,33 +64,68 @@ def decode_png(data: bytes) -> np.ndarray:
 
 
 class BopSceneWriter:
-    """Collects the frames of one scene; `add_batch` takes FrameRenderer output (device tensors) + pose records."""
+    """Collects the frames of one scene; `add_batch` takes FrameRenderer output (device tensors) + pose records.
 
-    def __init__(self, out_dir, scene_id: int = 0, png_level: int = 1):
+    PNG encoding is the only per-frame host work of the batch path and, on one thread, 100x slower than rendering
+    (2.9 s for 64 frames that render in 26 ms).  Like the reference, which starts a thread per frame for its writers
+    (/root/reference/pegasus.py:346-358), the encoder runs beside the renderer: `add_batch` quantises on the GPU, copies
+    the 8/16-bit images to the host once per batch and hands one task per PNG to a thread pool (zlib releases the GIL);
+    `close()` waits for them.  At most `max_pending` batches are in flight (bounded host memory)."""
+
+    def __init__(self, out_dir, scene_id: int = 0, png_level: int = 1, workers: int = None, max_pending: int = 4):
+        import os
+        from concurrent.futures import ThreadPoolExecutor
         self.scene = Path(out_dir) / "train" / f"{scene_id:06d}"
         for d in ("rgb", "depth", "mask_visib"):
             (self.scene / d).mkdir(parents=True, exist_ok=True)
         self.scene_gt, self.scene_camera = {}, {}
         self.n_frames, self.level = 0, png_level
+        self.workers = max(1, min(32, os.cpu_count() or 1) if workers is None else int(workers))
+        self._pool = ThreadPoolExecutor(max_workers=self.workers) if self.workers > 1 else None
+        self._pending, self._max_pending = [], max(1, int(max_pending))
+
+    def _write(self, path, image):
+        path.write_bytes(encode_png(image, self.level))
+
+    def _submit(self, path, image, batch_futures):
+        if self._pool is None:
+            self._write(path, image)
+        else:
+            batch_futures.append(self._pool.submit(self._write, path, image))
 
     def add_batch(self, frames: dict, scene_gt: dict, scene_camera: dict, n: int = None):
+        import torch
         from . import masks as M
         n = frames["color"].shape[0] if n is None else n
+        # GPU: uint8 HWC / uint16 millimetres per frame, then ONE device->host copy per kind and batch
+        q = [M.quantize_frame(frames["color"][i], frames["depth"][i, 0]) for i in range(n)]
+        rgb8 = torch.stack([a for a, _ in q]).cpu().numpy()
+        mm = torch.stack([b for _, b in q]).cpu().numpy().view(np.uint16)
+        mk = (frames["masks"][:n] * 255).cpu().numpy() if "masks" in frames else None
+        futures = []
         for i in range(n):
-            rgb8, mm = M.quantize_frame(frames["color"][i], frames["depth"][i, 0])          # GPU: uint8 HWC, uint16 mm
             fid = self.n_frames
-            (self.scene / "rgb" / f"{fid:06d}.png").write_bytes(encode_png(rgb8.cpu().numpy(), self.level))
-            (self.scene / "depth" / f"{fid:06d}.png").write_bytes(
-                encode_png(mm.cpu().numpy().view(np.uint16), self.level))
-            if "masks" in frames:
-                mk = (frames["masks"][i] * 255).cpu().numpy()
-                for k in range(mk.shape[0]):
-                    (self.scene / "mask_visib" / f"{fid:06d}_{k:06d}.png").write_bytes(encode_png(mk[k], self.level))
+            self._submit(self.scene / "rgb" / f"{fid:06d}.png", rgb8[i], futures)
+            self._submit(self.scene / "depth" / f"{fid:06d}.png", mm[i], futures)
+            if mk is not None:
+                for k in range(mk.shape[1]):
+                    self._submit(self.scene / "mask_visib" / f"{fid:06d}_{k:06d}.png", mk[i, k], futures)
             self.scene_gt[str(fid)] = scene_gt[str(i)]
             self.scene_camera[str(fid)] = scene_camera[str(i)]
             self.n_frames += 1
+        if futures:
+            self._pending.append(futures)
+            while len(self._pending) > self._max_pending:
+                for f in self._pending.pop(0):
+                    f.result()                       # re-raises a writer's exception here
 
     def close(self):
+        for batch in self._pending:
+            for f in batch:
+                f.result()
+        self._pending = []
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
         (self.scene / "scene_gt.json").write_text(json.dumps(self.scene_gt))
         (self.scene / "scene_camera.json").write_text(json.dumps(self.scene_camera))
         return self.scene

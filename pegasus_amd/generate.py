@@ -3,7 +3,8 @@
     python -m pegasus_amd.generate --out /tmp/pegasus_ds --frames 64 [--workload c3 --scale 0.1] [--dynamic]
 
 What PEGASUS's generate_dataset loop does per frame (/root/reference/pegasus.py:247-395: merge, 3+K renders, numpy
-masks, PNG + JSON writers), in batches of cameras on the GPU; PNG encoding is the only per-frame host work."""
+masks, PNG + JSON writers), in batches of cameras on the GPU; PNG encoding is the only per-frame host work and runs on
+a thread pool beside the renderer (the reference starts a writer thread per frame, pegasus.py:346-358)."""
 from __future__ import annotations
 
 import argparse
@@ -21,6 +22,7 @@ def main():
     ap.add_argument("--scale", type=float, default=0.1, help="fraction of the workload's Gaussian counts")
     ap.add_argument("--size", type=int, default=800)
     ap.add_argument("--dynamic", action="store_true", help="every frame a time step with its own object poses")
+    ap.add_argument("--writers", type=int, default=None, help="PNG encoder threads (default: host cores, at most 32)")
     args = ap.parse_args()
 
     import torch
@@ -38,7 +40,7 @@ def main():
     fr = FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"], cloud.object_id,
                        device="cuda:0")
     centers = [act["means3d"][cloud.object_id == k].mean(0) for k in range(1, fr.K + 1)]
-    w = BopSceneWriter(args.out)
+    w = BopSceneWriter(args.out, workers=args.writers)
     t0 = time.perf_counter()
     t_gpu = 0.0
     for b0 in range(0, args.frames, args.batch):
@@ -69,7 +71,7 @@ def main():
     scene = w.close()
     dt = time.perf_counter() - t0
     print(f"{w.n_frames} frames ({cloud.n} Gaussians, {fr.K} objects) -> {scene}: rendering {t_gpu * 1e3:.1f} ms, "
-          f"total {dt:.2f} s ({w.n_frames / dt:.1f} frames/s with PNG encoding on one host thread)")
+          f"total {dt:.2f} s ({w.n_frames / dt:.1f} frames/s with PNG encoding on {w.workers} host thread(s))")
 
 
 if __name__ == "__main__":
