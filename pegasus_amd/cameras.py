@@ -15,7 +15,9 @@ from . import graphics as G
 
 class Camera(nn.Module):
     def __init__(self, colmap_id, R, T, FoVx, FoVy, image, gt_alpha_mask, image_name, uid,
-                 trans=np.array([0.0, 0.0, 0.0]), scale=1.0, data_device="cuda"):
+                 trans=np.array([0.0, 0.0, 0.0]), scale=1.0, data_device="cuda", image_width=None, image_height=None):
+        """``image=None`` with ``image_width`` / ``image_height``: a render-only camera (no ground-truth image is kept:
+        the reference's own cameras are built around ``torch.empty((3, H, W))`` placeholders, pegasus_setup.py:130-140)."""
         super().__init__()
         self.uid = uid
         self.colmap_id = colmap_id
@@ -30,11 +32,17 @@ class Camera(nn.Module):
             print(e)
             print(f"[Warning] Custom device {data_device} failed, fallback to default cuda device")
             self.data_device = torch.device("cuda")
-        self.original_image = image.clamp(0.0, 1.0).to(self.data_device)
-        self.image_width = self.original_image.shape[2]
-        self.image_height = self.original_image.shape[1]
-        if gt_alpha_mask is not None:
-            self.original_image *= gt_alpha_mask.to(self.data_device)
+        if image is None:
+            if image_width is None or image_height is None:
+                raise ValueError("Camera needs an image or image_width / image_height")
+            self.original_image = None
+            self.image_width, self.image_height = int(image_width), int(image_height)
+        else:
+            self.original_image = image.clamp(0.0, 1.0).to(self.data_device)
+            self.image_width = self.original_image.shape[2]
+            self.image_height = self.original_image.shape[1]
+            if gt_alpha_mask is not None:
+                self.original_image *= gt_alpha_mask.to(self.data_device)
         self.zfar = G.ZFAR
         self.znear = G.ZNEAR
         self.trans = trans

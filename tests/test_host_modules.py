@@ -2,6 +2,7 @@
 from pathlib import Path
 
 import numpy as np
+import pytest
 
 GOLD = Path(__file__).resolve().parent / "golden"
 
@@ -129,3 +130,46 @@ def test_png_round_trip():
     import pytest
     with pytest.raises(ValueError):
         encode_png(np.zeros((4, 4), np.float32))
+
+
+def test_scene_directory_round_trip(tmp_path):
+    """compat `from scene import Scene`: a model directory (point_cloud/iteration_N/point_cloud.ply + cameras.json, the
+    layout upstream's training writes and /root/reference/src/gs/gs_object_rotation.py:79 opens) written through
+    Scene.save / camera_to_JSON and read back: same Gaussians, same camera matrices."""
+    import json
+    import sys
+    import torch
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "compat"))
+    try:
+        from scene import Scene, GaussianModel
+        from scene.cameras import Camera
+    finally:
+        sys.path.pop(0)
+    from pegasus_amd import scenes
+    from pegasus_amd.scene import camera_to_JSON
+    cloud, _ = scenes.scene_c1(n=500)
+    _, views = scenes.scene_c2(n=10, n_views=5, width=320, height=240)
+    gm = GaussianModel.from_arrays(cloud.xyz, cloud.features_dc, cloud.features_rest, cloud.opacity, cloud.scaling,
+                                   cloud.rotation, device="cpu")
+    cams = [Camera(colmap_id=i, R=v.R_c2w, T=v.t_w2c, FoVx=v.fovx, FoVy=v.fovy, image=None, gt_alpha_mask=None,
+                   image_name=f"im{i}", uid=i, data_device="cpu", image_width=v.width, image_height=v.height)
+            for i, v in enumerate(views)]
+    args = type("Args", (), dict(model_path=str(tmp_path), data_device="cpu"))()
+    (tmp_path / "cameras.json").write_text(json.dumps([camera_to_JSON(i, c) for i, c in enumerate(cams)]))
+    Scene(args, gm, shuffle=False).save(7000)
+    Scene(args, gm, shuffle=False).save(30000)
+    gm2 = GaussianModel(3, device="cpu")
+    sc = Scene(args, gm2, load_iteration=-1, shuffle=False)
+    assert sc.loaded_iter == 30000 and len(sc.getTrainCameras()) == 5 and sc.getTestCameras() == []
+    for a, b in ((gm._xyz, gm2._xyz), (gm._features_rest, gm2._features_rest), (gm._rotation, gm2._rotation),
+                 (gm._opacity, gm2._opacity), (gm._scaling, gm2._scaling), (gm._features_dc, gm2._features_dc)):
+        assert torch.equal(a, b)
+    for c, d in zip(cams, sc.getTrainCameras()):
+        assert (d.image_width, d.image_height, d.image_name) == (c.image_width, c.image_height, c.image_name)
+        np.testing.assert_allclose(d.world_view_transform.numpy(), c.world_view_transform.numpy(), atol=2e-6)
+        np.testing.assert_allclose(d.full_proj_transform.numpy(), c.full_proj_transform.numpy(), atol=2e-5)
+        np.testing.assert_allclose(d.camera_center.numpy(), c.camera_center.numpy(), atol=2e-6)
+    with pytest.raises(ValueError):
+        Camera(colmap_id=0, R=views[0].R_c2w, T=views[0].t_w2c, FoVx=1.0, FoVy=1.0, image=None, gt_alpha_mask=None,
+               image_name="x", uid=0, data_device="cpu")
