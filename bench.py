@@ -54,6 +54,10 @@ def parse():
                     help="dynamic sequence: every frame is a TIME STEP with its own object poses (posed inside the "
                          "preprocess) and one camera, plus its BOP pose records")
     ap.add_argument("--raster-only", action="store_true", help="time only the full-scene RGB+depth pass (R), no masks")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: also gather every batch's finished frames to rank 0 inside the timed region, in the "
+                         "reference's on-disk precision (uint8 RGB, uint16 depth, uint8 masks; pegasus.py:347,355) -- the "
+                         "one RCCL exchange of the path (SURVEY.md section 8e); asynchronous, overlapping the next batch")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--profile-steps", type=int, default=0,
                     help="batches measured per-stage with HIP events (0 = the same batches as the timed steps)")
@@ -177,12 +181,33 @@ def main():
             return fr.render_frames(batch_views(i), frames, masks=with_masks, poses=batch_poses(i), **kw)
         return fr.render_frames(batch_views(i), frames, masks=with_masks, **kw)
 
+    gather_state = {"inflight": None, "bytes": 0}
+
+    def gather_finished(fr_set):
+        """Quantise a finished batch on the GPU and start its gather to rank 0 (grouped send/recv on RCCL: the peers
+        stream over their own xGMI links); the previous batch's gather is completed first, so one is in flight."""
+        if not (args.gather and world > 1):
+            return
+        from pegasus_amd import masks as M
+        from pegasus_amd import view_shard as VS
+        if gather_state["inflight"] is not None:
+            finish, works = gather_state["inflight"]
+            for w_ in works:
+                w_.wait()
+            finish()
+        q = [M.quantize_frame(fr_set["color"][k], fr_set["depth"][k, 0]) for k in range(B)]
+        local = {"rgb": torch.stack([a for a, _ in q]), "depth_mm": torch.stack([b for _, b in q])}
+        if "masks" in fr_set:
+            local["masks"] = fr_set["masks"][:B]
+        gather_state["bytes"] = sum(t.numel() * t.element_size() for t in local.values())
+        gather_state["inflight"] = VS.gather_frames(local, B * world, dst=0, async_op=True)
+
     def run_steps(first, count):
         """`count` steps as a 2-deep software pipeline: batch i is enqueued (scene pass and semantic pass on two
         streams, no host sync) while batch i-1 finishes; every batch's overflow status is checked."""
         if args.sync_steps:
             for i in range(first, first + count):
-                step(i)
+                gather_finished(step(i))
             return
         pending = None
         for i in range(first, first + count):
@@ -194,10 +219,16 @@ def main():
             else:
                 h = render(batch_views(i), frames if i % 2 == 0 else frames2, masks=with_masks, slot=i % 2)
             if pending is not None:
-                pending.wait()
+                gather_finished(pending.wait())
             pending = h
         if pending is not None:
-            pending.wait()
+            gather_finished(pending.wait())
+        if gather_state["inflight"] is not None:
+            finish, works = gather_state["inflight"]
+            for w_ in works:
+                w_.wait()
+            finish()
+            gather_state["inflight"] = None
 
     run_steps(0, args.warmup)
     torch.cuda.synchronize()
@@ -346,7 +377,10 @@ def main():
                                     "Morton order per object (one-time, at scene load, outside the timed region)"),
                    "outputs": ("color[3,H,W] f32 + depth[1,H,W] f32 + semantic image[3,H,W] f32 + masks[K,H,W] u8"
                                if with_masks else "color[3,H,W] f32 + depth[1,H,W] f32"),
-                   "parallelism": f"view-shard x{world}"},
+                   "parallelism": f"view-shard x{world}",
+                   "gather": (f"every batch's quantised frames gathered to rank 0 inside the timed region "
+                              f"({gather_state['bytes'] / 1e6:.0f} MB per rank and batch)" if args.gather and world > 1 else
+                              "off (frames stay on the rank that rendered them)")},
         "roofline": roofline,
         "cpu_baseline": cpu,
     }

@@ -31,8 +31,13 @@ def gather_frames(local: Dict[str, torch.Tensor], n_items: int, dst: int = 0, gr
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     cap = max_local(n_items, world)
-    works, staging = [], {}
+    works, staging, wire_dtype = [], {}, {}
     for k, t in local.items():
+        # neither RCCL/NCCL nor gloo carry 16-bit integers (the uint16-millimetre depth images travel as int16 storage):
+        # such tensors go over the wire as bytes and are viewed back on arrival
+        wire_dtype[k] = t.dtype
+        if t.dtype in (torch.int16, getattr(torch, "uint16", torch.int16)):
+            t = t.contiguous().view(torch.uint8)
         pad = t
         if t.shape[0] < cap:   # ranks with one view fewer pad so every rank contributes equal-sized chunks
             pad = torch.cat([t, t.new_zeros((cap - t.shape[0],) + tuple(t.shape[1:]))], 0)
@@ -53,7 +58,7 @@ def gather_frames(local: Dict[str, torch.Tensor], n_items: int, dst: int = 0, gr
                 idx = shard_indices(n_items, r, world)
                 if idx:
                     full[idx] = bufs[r][: len(idx)]
-            out[k] = full
+            out[k] = full if full.dtype == wire_dtype[k] else full.view(wire_dtype[k])
         return out
 
     if async_op:

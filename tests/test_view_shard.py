@@ -72,3 +72,53 @@ def test_shard_indices_partition():
             parts = [vs.shard_indices(n, r, world) for r in range(world)]
             assert sorted(i for p in parts for i in p) == list(range(n))
             assert max(len(p) for p in parts) == (vs.max_local(n, world) if n else 0)
+
+
+def _async_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pegasus_amd import view_shard as vs
+        B = 3                                   # views per rank and batch (bench.py --gather: one gather per batch)
+        ok = True
+        inflight = None
+        for step in range(3):
+            mine = [step * 100 + rank + world * k for k in range(B)]       # global order inside the batch: rank::world
+            local = {"rgb": torch.tensor(mine, dtype=torch.uint8).view(-1, 1, 1, 1).expand(B, 4, 5, 3).contiguous(),
+                     "depth_mm": (torch.tensor(mine, dtype=torch.int16) * 7 - 300).view(-1, 1, 1).expand(B, 4, 5).contiguous()}
+            if inflight is not None:
+                finish, works, expect_step = inflight
+                for w in works:
+                    w.wait()
+                got = finish()
+                if rank == 0:
+                    want = torch.tensor([expect_step * 100 + i for i in range(B * world)])
+                    ok = ok and torch.equal(got["rgb"][:, 0, 0, 0].long(), want % 256) \
+                        and torch.equal(got["depth_mm"][:, 0, 0].long(), want * 7 - 300) \
+                        and got["rgb"].dtype == torch.uint8 and got["depth_mm"].dtype == torch.int16
+                else:
+                    ok = ok and got is None
+            finish, works = vs.gather_frames(local, B * world, dst=0, async_op=True)
+            inflight = (finish, works, step)
+        for w in inflight[1]:
+            w.wait()
+        inflight[0]()
+        q.put(("ok" if ok else "mismatch", rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_async_gather_of_quantised_batches():
+    """What bench.py --gather does per batch: uint8 / int16 frames, one asynchronous gather in flight."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_async_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [("ok", 0), ("ok", 1)]
