@@ -299,7 +299,7 @@ def block_visibility(means3D, views: Sequence[ViewSpec], *, scales=None, rotatio
         raise RuntimeError("block_visibility needs tensors on a HIP device")
     n, nv = int(means3D.shape[0]), len(views)
     means3D, scales, rotations, cov3D_precomp = (dev_f32(t, device) for t in (means3D, scales, rotations, cov3D_precomp))
-    ones = torch.ones((max(n, 1),), dtype=torch.float32, device=device)          # opacities / colours are not looked at
+    ones = torch.ones((max(n, 1), 3), dtype=torch.float32, device=device)       # opacities / colours are not looked at
     scene = _lib.PgrScene(n=n, means3d=_ptr(means3D), opacities=_ptr(ones), scales=_ptr(scales), rotations=_ptr(rotations),
                           cov3d_precomp=_ptr(cov3D_precomp), shs=None, colors_precomp=_ptr(ones), sh_degree=0, sh_stride=0,
                           scale_modifier=float(scale_modifier), tie_index=None)
