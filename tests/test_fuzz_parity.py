@@ -64,3 +64,35 @@ def test_random_scenes_match_the_oracle(oracle, gpu_device, block):
         assert (np.abs(g["color"] - o["color"]) / scale)[:, ok].max(initial=0) <= 1e-4, tag
         assert (np.abs(g["out_depth"][0] - o["out_depth"][0]) / np.maximum(1.0, np.abs(o["out_depth"][0])))[ok].max(initial=0) <= 1e-4, tag
         assert np.array_equal(np.isfinite(g["color"]).all(axis=0)[~amb], np.isfinite(o["color"]).all(axis=0)[~amb]), tag
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_merged_scenes_fused_frames_equal_separate_passes(gpu_device, seed):
+    """FrameRenderer on random small merged scenes (random object count, densities, image size, background, objects in
+    front of / behind / inside the environment's splats): the fused frames (semantic image as a second accumulator of the
+    scene's walk, Morton layout, block culling) equal two separate passes, bit for bit -- asynchronous slots included."""
+    import torch
+    from pegasus_amd import frames as F
+    rng = np.random.default_rng(300 + seed)
+    k_obj = int(rng.integers(1, 6))
+    n_env, n_obj = int(rng.choice([500, 4000, 30000])), int(rng.choice([200, 2000, 9000]))
+    W, H = int(rng.choice([96, 200, 333])), int(rng.choice([64, 150, 240]))
+    cloud, views, _ = scenes.merged_scene(40 + seed, n_env, k_obj, n_obj, 5, W, H, plane_size=float(rng.choice([0.6, 2.0])))
+    act = cloud.activated()
+    if seed % 2:                                  # translucent environment: semantic and scene walks diverge late
+        act["opacities"][cloud.object_id == 0] *= np.float32(0.15)
+    if seed % 3 == 0:                             # fat object splats
+        act["scales"][cloud.object_id > 0] *= np.float32(6.0)
+    fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"], cloud.object_id,
+                         sh_degree=3, device=gpu_device, bg=tuple(rng.random(3).astype(np.float32)))
+    specs = [fr.view_spec(v) for v in views]
+    ref = {k: v.clone() for k, v in fr.render_batch(specs).items()}
+    torch.cuda.synchronize()
+    fa, fb = fr.alloc_frames(3, H, W), fr.alloc_frames(2, H, W)
+    ha = fr.render_frames_async(specs[:3], fa, slot=0)
+    hb = fr.render_frames_async(specs[3:], fb, slot=1)
+    ha.wait(); hb.wait()
+    for k in ("color", "depth", "seg", "seg_depth", "masks"):
+        got = torch.cat([fa[k], fb[k]])
+        assert torch.equal(got, ref[k]), (seed, k)
+    assert int(ref["masks"].sum()) > 0
