@@ -218,6 +218,73 @@ class FrameRenderer:
             M.color_masks(frames["seg"][:B], self.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])
         return frames
 
+    def render_silhouettes(self, specs: Sequence[R.ViewSpec], out: torch.Tensor = None, poses=None) -> torch.Tensor:
+        """Silhouette masks [B, K, H, W] uint8: object k rendered ALONE in its semantic colour and thresholded, i.e. its
+        full outline whatever occludes it in the scene (/root/reference/src/gs/render.py:36-65 does this with one
+        deepcopy + merge + render per object and camera).  Here: one batch call per object over its slice of the
+        resident scene and one mask launch each, two passes in flight.  Measured on C3 (8 objects of 80 k Gaussians, 32
+        views of 800x800): 0.22 ms per view -- as much as the whole RGB + depth + visible-mask frame, because every pass
+        pays the fixed per-batch costs (tile launches over mostly empty tiles, full-image writes and mask reads); it is
+        an optional data point of the reference ('seg_sil'), not part of the measured frame.  ``poses`` as in
+        render_frames."""
+        B = len(specs)
+        H, W = int(specs[0].image_height), int(specs[0].image_width)
+        if out is None:
+            out = torch.empty((B, max(self.K, 1), H, W), dtype=torch.uint8, device=self.device)
+        if self.K == 0:
+            return out[:, :0]
+        if not hasattr(self, "_obj_slices"):
+            oid = self.semantic["object_id"].cpu().numpy()
+            self._obj_slices = [(int(np.searchsorted(oid, k, "left")), int(np.searchsorted(oid, k, "right")))
+                                for k in range(1, self.K + 1)]
+        posed_all = self._posed(poses, B)
+        # two object passes in flight (two workspaces, two image buffers): the host prepares pass k + 1 while the GPU runs
+        # pass k; a slot is reused only after its previous pass has been waited for (its pinned tables are then free)
+        if getattr(self, "_sil_img", None) is None or self._sil_img[0].shape != (B, 3, H, W):
+            self._sil_img = [torch.empty((B, 3, H, W), device=self.device) for _ in range(2)]
+        pending = [None, None]
+        for k, (a, b) in enumerate(self._obj_slices):
+            if b <= a:
+                out[:, k] = 0
+                continue
+            s = slice(a, b)
+            posed = None
+            if posed_all is not None:
+                posed = dict(object_id=torch.ones(b - a, dtype=torch.int32, device=self.device),
+                             poses=posed_all["poses"][:, k:k + 1].contiguous())
+            tie = None if self.tie_index is None else self._dense_rank(self.tie_index[s])
+            slot = k % 2
+            if pending[slot] is not None:
+                pending[slot].wait()
+            img = self._sil_img[slot]
+            outs = [dict(color=img[i], depth=self._sil_depth(B, H, W)[i], radii=None) for i in range(B)]
+            pending[slot] = R.forward_views(self.means3d[s], self.opacities[s], specs,
+                                            shs=self.sem_shs[a - self.n_env:b - self.n_env], scales=self.scales[s],
+                                            rotations=self.rotations[s], sh_degree=0, want_radii=False, posed=posed,
+                                            tie_index=tie, outputs=outs, async_slot=("silhouette", slot))
+            out[:, k:k + 1] = M.color_masks(img, self.colors[k:k + 1], M.MASK_THRESHOLD)      # (kernel output is contiguous)
+        redo = False
+        for p in pending:
+            if p is not None:
+                p.wait()
+                redo = redo or getattr(p, "_was_redone", False)
+        if redo:            # an instance overflow re-rendered a pass after its masks were taken: start over (sized now)
+            return self.render_silhouettes(specs, out, poses)
+        return out[:, :self.K]
+
+    def _sil_depth(self, B, H, W):
+        if getattr(self, "_sil_d", None) is None or self._sil_d.shape != (B, 1, H, W):
+            self._sil_d = torch.empty((B, 1, H, W), device=self.device)      # depth of the object passes: not kept
+        return self._sil_d
+
+    @staticmethod
+    def _dense_rank(t: torch.Tensor) -> torch.Tensor:
+        """A slice of a permutation -> the permutation of 0..len-1 with the same order (what PgrScene.tie_index wants)."""
+        order = torch.argsort(t)
+        rank = torch.empty_like(order)
+        rank[order] = torch.arange(t.numel(), device=t.device)
+        return rank.to(torch.int32)
+
     def render_batch(self, specs: Sequence[R.ViewSpec], frames: dict = None, masks: bool = True,
                      stage_ms: list = None, sem_stage_ms: list = None):
         """Renders len(specs) frames into ``frames`` (allocated if None).  Returns the dict of batched

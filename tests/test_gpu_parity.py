@@ -467,3 +467,31 @@ def test_hostile_inputs_do_not_fault_and_match_oracle(oracle, gpu_device, seed):
     assert (np.abs(g["color"] - o["color"]) / scale)[:, ok].max() <= 1e-4
     assert np.array_equal(np.isfinite(g["color"]).all(axis=0)[~o["ambig"].astype(bool)],
                           np.isfinite(o["color"]).all(axis=0)[~o["ambig"].astype(bool)])
+
+
+def test_frame_renderer_silhouette_masks(oracle, gpu_device):
+    """FrameRenderer.render_silhouettes: object k alone in its semantic colour, thresholded (/root/reference/src/gs/
+    render.py:36-65), against the oracle's single-object renders; a silhouette contains the object's visible mask."""
+    import torch
+    from pegasus_amd import frames as F
+    from pegasus_amd.sh_utils import RGB2SH
+    cloud, views = scenes.scene_c3(scale=0.03, n_views=3, width=320, height=240)
+    act = cloud.activated()
+    fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"], cloud.object_id,
+                         sh_degree=3, device=gpu_device)
+    specs = [fr.view_spec(v) for v in views]
+    sil = fr.render_silhouettes(specs).cpu().numpy()
+    vis = fr.render_frames(specs)["masks"].cpu().numpy()
+    assert sil.shape == vis.shape == (3, fr.K, 240, 320)
+    assert ((sil | vis) == sil).mean() > 0.9995 and sil.sum() > vis.sum()       # occluded parts are silhouette only
+    oid = cloud.object_id
+    for k in (1, fr.K):
+        m = oid == k
+        shs = np.zeros((int(m.sum()), 16, 3), np.float32)
+        shs[:, 0] = RGB2SH(fr.colors_np[k - 1])
+        for vi, v in enumerate(views):
+            o = oracle.forward(act["means3d"][m], act["opacities"][m], scales=act["scales"][m], rotations=act["rotations"][m],
+                               shs=shs, sh_degree=0, num_threads=8, **v.raster_kwargs())
+            dist = np.linalg.norm(o["color"].transpose(1, 2, 0) - fr.colors_np[k - 1], axis=2)
+            decided = (np.abs(dist - 0.1) > 2e-4) & ~o["ambig"].astype(bool)
+            np.testing.assert_array_equal(sil[vi, k - 1][decided], (dist <= 0.1)[decided].astype(np.uint8))
