@@ -33,8 +33,8 @@ masks = len(sys.argv) > 2 and sys.argv[2] == "frames"
 fr.render_frames(specs, None, masks=masks)
 handle.pgr_debug_comp_stats(out, 1)
 walk, live, ev, alive, blend, waves, batches = [out[i] / B for i in range(7)]
-print(f"fused semantic: {masks}; semantic wave-entries {(out[7] & 0xffffffff) / B / 1e6:.2f} M; "
-      f"scene entries with no valid pixel {(out[7] >> 32) / B / 1e6:.2f} M; pairs evaluated ~{live / 2e6:.2f} M")
+print(f"fused semantic: {masks}; semantic wave-entries with their own blend {(out[7] & 0xffffffff) / B / 1e6:.2f} M, "
+      f"riding the scene blend (quarter still object-only) {(out[7] >> 32) / B / 1e6:.2f} M; pairs evaluated ~{live / 2e6:.2f} M")
 print(f"{label}: per view: waves {waves:.0f}  batches {batches:.0f}  entries walked {walk/1e6:.2f} M  live after skip {live/1e6:.2f} M "
       f"({live/walk:.2%})  wave-entries evaluated {ev/1e6:.2f} M  pixel-entries: alive {alive/1e6:.1f} M "
       f"({alive/(ev*64):.2%} of lanes)  blended {blend/1e6:.1f} M ({blend/(ev*64):.2%})  live/batch {live/batches:.1f}")
