@@ -54,6 +54,7 @@ def parse():
                     help="dynamic sequence: every frame is a TIME STEP with its own object poses (posed inside the "
                          "preprocess) and one camera, plus its BOP pose records")
     ap.add_argument("--raster-only", action="store_true", help="time only the full-scene RGB+depth pass (R), no masks")
+    ap.add_argument("--step-log", action="store_true", help="per-step (enqueue, wait) host milliseconds on stderr")
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: also gather every batch's finished frames to rank 0 inside the timed region, in the "
                          "reference's on-disk precision (uint8 RGB, uint16 depth, uint8 masks; pegasus.py:347,355) -- the "
@@ -217,9 +218,13 @@ def main():
                                            slot=i % 2, poses=batch_poses(i))
                 batch_records(i)                  # BOP scene_gt / scene_camera entries of the batch (host, overlapped)
             else:
+                t_e = time.perf_counter()
                 h = render(batch_views(i), frames if i % 2 == 0 else frames2, masks=with_masks, slot=i % 2)
+            t_w = time.perf_counter()
             if pending is not None:
                 gather_finished(pending.wait())
+            if args.step_log and pose_seq is None:
+                print(f"step {i}: enqueue {(t_w - t_e) * 1e3:.2f} ms, wait {(time.perf_counter() - t_w) * 1e3:.2f} ms", file=sys.stderr)
             pending = h
         if pending is not None:
             gather_finished(pending.wait())
@@ -230,6 +235,15 @@ def main():
             finish()
             gather_state["inflight"] = None
 
+    # set-up, not warm-up: let the workspaces reach their size.  The instance capacity is a hint that grows when a batch
+    # comes close to it (a multi-GB reallocation, tens of ms, once per scene and pipeline slot); small scenes start below
+    # their need (C2: 1 M for views that list 1.4 M) and would otherwise pay that inside the timed region.
+    for _ in range(3):
+        before = dict(rasterizer._WS.capacity_hint)
+        run_steps(0, 2)
+        torch.cuda.synchronize()
+        if dict(rasterizer._WS.capacity_hint) == before:
+            break
     run_steps(0, args.warmup)
     torch.cuda.synchronize()
     if world > 1:
