@@ -94,16 +94,9 @@ __device__ unsigned long long g_comp_stats[8];
 // the tile's last object entry (ViewEntry::obj_last, a by-product of the tile sort).  Pixel arithmetic is the
 // sequence a separate objects-only pass executes: bit-identical (tests/test_gpu_parity.py).
 template <bool AUX, bool FUSED>
-__global__ __launch_bounds__(WAVE) PGR_COMP_OCC void composite_quarter_kernel(const ViewEntry* __restrict__ views,
-                                                                              uint32_t items_per_view,
-                                                                              const uint32_t* __restrict__ work_order,
-                                                                              SemanticDev sem) {
-    uint32_t item = work_order ? work_order[blockIdx.x] : blockIdx.x;
-    if (item == INVALID_ITEM) return;
-    const uint32_t view = item / items_per_view;
-    item -= view * items_per_view;
-    const ViewEntry& ve = views[view];
-    if (ve.counters[1] || !ve.out.color) return;
+__device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t item, const SemanticDev& sem, int n_sem,
+                                                  bool sem_background, float4* __restrict__ s_g, float4* __restrict__ s_c,
+                                                  float4* __restrict__ s_s, uint32_t* __restrict__ s_i) {
     const CameraDev& cam = *ve.cam;
     const uint32_t* __restrict__ gauss_sorted = ve.gauss_sorted;
     const float4* __restrict__ splats = ve.splats;
@@ -120,19 +113,12 @@ __global__ __launch_bounds__(WAVE) PGR_COMP_OCC void composite_quarter_kernel(co
 
     const uint2 range = ve.ranges[tile];
     const int n = (int)(range.y - range.x);
-    const bool want_sem = FUSED && ve.sem_color != nullptr;
-    // object entries live in [0, n_sem).  readfirstlane: the value arrives through a vector load; everything derived
-    // from it (the semantic masks, the loop exits) must stay on the scalar unit
-    const int n_sem = want_sem ? __builtin_amdgcn_readfirstlane((int)ve.obj_last[tile]) : 0;
+    const bool want_sem = FUSED;                  // (the kernel sends only quarters with object entries down this path)
 
-    // LDS image of a compacted batch, pair-major:
+    // LDS image of a compacted batch, pair-major (arrays of the kernel):
     //   s_g[3k+0] = (x0, x1, y0, y1)   s_g[3k+1] = (hx0, hx1, ny0, ny1)   s_g[3k+2] = (hz0, hz1, op0, op1)
     //   s_c[j] = (r, g, b, depth) of entry j      s_s[j] = (sem r, sem g, sem b, depth) for object entries, 0 otherwise
-    constexpr int PAIRS = WAVE_BATCH / 2 + 1;     // +1: a null entry pads an odd batch
-    __shared__ float4 s_g[3 * PAIRS];
-    __shared__ float4 s_c[2 * PAIRS];
-    __shared__ float4 s_s[FUSED ? 2 * PAIRS : 1];
-    __shared__ uint32_t s_i[AUX ? 2 * PAIRS : 1];   // 1-based list position (n_contrib bookkeeping)
+    //   s_i[j] = 1-based list position (n_contrib bookkeeping)
     float* const s_gf = reinterpret_cast<float*>(s_g);
 
     float T = 1.0f, Ts = 1.0f;
@@ -340,7 +326,46 @@ finished:
             ve.sem_color[1 * P + pix] = fmaf(Ts, cam.bg[1], Srg.y);
             ve.sem_color[2 * P + pix] = fmaf(Ts, cam.bg[2], Sbd.x);
             if (ve.sem_depth) ve.sem_depth[pix] = Sbd.y;
+        } else if (sem_background) {             // no object entry in this tile: the objects-only image is the background
+            ve.sem_color[0 * P + pix] = cam.bg[0];       // (= fmaf(1, bg, 0) of the general form, bit for bit)
+            ve.sem_color[1 * P + pix] = cam.bg[1];
+            ve.sem_color[2 * P + pix] = cam.bg[2];
+            if (ve.sem_depth) ve.sem_depth[pix] = 0.0f;
         }
+    }
+}
+
+// The kernel: one wave per (view, tile, quarter) work item.  In the FUSED form a quarter whose tile holds no object entry
+// at all (most of the image) runs the plain loop and only copies the background into the semantic image: the fused
+// loop's per-entry bookkeeping (object bit, second set of masks, their branches) was costing EVERY entry of EVERY quarter
+// -- of the 27 us per view the semantic image cost on C3, 11 were this.  (Tried on top, slower: routing the environment
+// entries of fused quarters through a copy of the plain blend -- three inlined copies of the blend cost more than the
+// scalar tests they saved.)
+template <bool AUX, bool FUSED>
+__global__ __launch_bounds__(WAVE) PGR_COMP_OCC void composite_quarter_kernel(const ViewEntry* __restrict__ views,
+                                                                              uint32_t items_per_view,
+                                                                              const uint32_t* __restrict__ work_order,
+                                                                              SemanticDev sem) {
+    uint32_t item = work_order ? work_order[blockIdx.x] : blockIdx.x;
+    if (item == INVALID_ITEM) return;
+    const uint32_t view = item / items_per_view;
+    item -= view * items_per_view;
+    const ViewEntry& ve = views[view];
+    if (ve.counters[1] || !ve.out.color) return;
+    constexpr int PAIRS = WAVE_BATCH / 2 + 1;     // +1: a null entry pads an odd batch
+    __shared__ float4 s_g[3 * PAIRS];
+    __shared__ float4 s_c[2 * PAIRS];
+    __shared__ float4 s_s[FUSED ? 2 * PAIRS : 1];
+    __shared__ uint32_t s_i[AUX ? 2 * PAIRS : 1];
+    if constexpr (FUSED) {
+        const bool want_sem = ve.sem_color != nullptr;
+        // object entries live in [0, n_sem).  readfirstlane: the value arrives through a vector load; everything derived
+        // from it (the semantic masks, the loop exits) must stay on the scalar unit
+        const int n_sem = want_sem ? __builtin_amdgcn_readfirstlane((int)ve.obj_last[item >> 2]) : 0;
+        if (n_sem > 0) composite_quarter<AUX, true>(ve, item, sem, n_sem, false, s_g, s_c, s_s, s_i);
+        else composite_quarter<AUX, false>(ve, item, sem, 0, want_sem, s_g, s_c, s_s, s_i);
+    } else {
+        composite_quarter<AUX, false>(ve, item, sem, 0, false, s_g, s_c, s_s, s_i);
     }
 }
 
