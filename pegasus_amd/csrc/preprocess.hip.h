@@ -218,7 +218,7 @@ struct PosedDev {
 // the whole wave (radii / rectangles, where the caller wants them, are zero; the candidate rectangle is not written:
 // the binning walk consults the same bits, stored as vis_out[group * vis_words + view / 32]).
 template <int DEG, bool POSED>
-__global__ __launch_bounds__(PRE_BLOCK) void preprocess_batch_kernel(PgrScene sc, const CameraDev* __restrict__ cams,
+__global__ __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void preprocess_batch_kernel(PgrScene sc, const CameraDev* __restrict__ cams,
                                                                      const PreOut* __restrict__ outs, int n_views,
                                                                      PosedDev posed, uint32_t* __restrict__ vis_out,
                                                                      int vis_words) {
@@ -259,8 +259,27 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_batch_kernel(PgrScene sc
         if (!real) continue;                 // (rejoins the wave at the next view's ballot)
         int radius = 0;
         uint2 rect = make_uint2(0u, 0u), crect = make_uint2(0u, 0u);
-        const float* vm = cam.view;
+        // The view matrix and the camera scalars are fetched ONCE per iteration, here: left to the compiler, every field
+        // is loaded where it is first used -- five groups of s_load, each followed by a full s_waitcnt, i.e. five exposed
+        // scalar-cache round trips per view and wave in a kernel that runs 4 waves per SIMD (VALU busy 74 %).  The empty
+        // asm statements pin the loads (the optimiser would sink them back into the branches).  The projection matrix
+        // stays where it is used (one more group, survivors of the near cull only): pinning it too needs more SGPRs than
+        // a wave has, and the spills cost a wave of occupancy.
+        float vm[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) vm[k] = cam.view[k];
         const float* pm = cam.proj;
+        float cam_cx = cam.campos[0], cam_cy = cam.campos[1], cam_cz = cam.campos[2];
+        float cam_tanx = cam.tanfovx, cam_tany = cam.tanfovy, cam_fx = cam.focal_x, cam_fy = cam.focal_y;
+        int cam_w = cam.width, cam_h = cam.height, cam_gx = cam.grid_x, cam_gy = cam.grid_y;
+        float4* out_splats = o.splats;           // (the view's output pointers ride along in the same round trip)
+        uint2* out_crects = o.crects;
+        asm volatile("" : "+s"(out_splats), "+s"(out_crects));
+#pragma unroll
+        for (int k = 0; k < 15; ++k)
+            if ((k & 3) != 3) asm volatile("" : "+s"(vm[k]));
+        asm volatile("" : "+s"(cam_cx), "+s"(cam_cy), "+s"(cam_cz), "+s"(cam_tanx), "+s"(cam_tany), "+s"(cam_fx), "+s"(cam_fy));
+        asm volatile("" : "+s"(cam_w), "+s"(cam_h), "+s"(cam_gx), "+s"(cam_gy));
         float px = bx, py = by, pz = bz;
         const float* P = nullptr;
         if (POSED && oid > 0) {
@@ -299,14 +318,14 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_batch_kernel(PgrScene sc
                 }
                 have_cov = true;
             }
-            const float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
+            const float limx = 1.3f * cam_tanx, limy = 1.3f * cam_tany;
             const float txtz = tx / tz, tytz = ty / tz;
             tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
             ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
-            const float j00 = cam.focal_x / tz;
-            const float j02 = -(cam.focal_x * tx) / (tz * tz);
-            const float j11 = cam.focal_y / tz;
-            const float j12 = -(cam.focal_y * ty) / (tz * tz);
+            const float j00 = cam_fx / tz;
+            const float j02 = -(cam_fx * tx) / (tz * tz);
+            const float j11 = cam_fy / tz;
+            const float j12 = -(cam_fy * ty) / (tz * tz);
             float T0[3], T1[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -332,9 +351,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_batch_kernel(PgrScene sc
                 const float lambda1 = mid + disc, lambda2 = mid - disc;
                 const float rad_f = ceilf(3.0f * sqrtf(fmaxf(lambda1, lambda2)));
                 const int rad = rad_f >= 2147483520.0f ? 2147483520 : (int)rad_f;
-                const float pix_x = ((ndc_x + 1.0f) * (float)cam.width - 1.0f) * 0.5f;
-                const float pix_y = ((ndc_y + 1.0f) * (float)cam.height - 1.0f) * 0.5f;
-                const TileRect r = tile_rect(pix_x, pix_y, rad, cam.grid_x, cam.grid_y);
+                const float pix_x = ((ndc_x + 1.0f) * (float)cam_w - 1.0f) * 0.5f;
+                const float pix_y = ((ndc_y + 1.0f) * (float)cam_h - 1.0f) * 0.5f;
+                const TileRect r = tile_rect(pix_x, pix_y, rad, cam_gx, cam_gy);
                 const int w = r.maxx - r.minx, h = r.maxy - r.miny;
                 if (w > 0 && h > 0) {
                     float3 rgb;
@@ -346,7 +365,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_batch_kernel(PgrScene sc
                             load_sh<DEG>(sh, sc.shs + (size_t)i * sc.sh_stride * 3, vec4);
                             have_sh = true;
                         }
-                        float dx = px - cam.campos[0], dy = py - cam.campos[1], dz = pz - cam.campos[2];
+                        float dx = px - cam_cx, dy = py - cam_cy, dz = pz - cam_cz;
                         const float len = sqrtf(dx * dx + dy * dy + dz * dz);
                         dx = dx / len; dy = dy / len; dz = dz / len;
                         if (POSED && P) {        // the object's own frame: R^T d
@@ -362,7 +381,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_batch_kernel(PgrScene sc
                                       (uint32_t)r.maxx | ((uint32_t)r.maxy << 16));
                     const float op = sc.opacities[i];
                     crect = candidate_rect(r, pix_x, pix_y, c_xx, c_yy, con_x, con_y, con_z, op, rad);
-                    float4* rec = o.splats + (size_t)i * SPLAT_F4;
+                    float4* rec = out_splats + (size_t)i * SPLAT_F4;
                     rec[0] = make_float4(pix_x, pix_y, con_x, con_y);
                     rec[1] = make_float4(con_z, op, rgb.x, rgb.y);
                     rec[2] = make_float4(rgb.z, tz, 0.0f, 0.0f);
@@ -371,7 +390,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void preprocess_batch_kernel(PgrScene sc
         }
         if (o.radii) o.radii[i] = radius;
         if (o.rects) o.rects[i] = rect;
-        o.crects[i] = crect;
+        out_crects[i] = crect;
     }
 }
 
