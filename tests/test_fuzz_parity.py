@@ -96,3 +96,27 @@ def test_random_merged_scenes_fused_frames_equal_separate_passes(gpu_device, see
         got = torch.cat([fa[k], fb[k]])
         assert torch.equal(got, ref[k]), (seed, k)
     assert int(ref["masks"].sum()) > 0
+
+
+def test_fused_semantic_with_aux_outputs(gpu_device):
+    """The AUX + FUSED compositor instance (n_contrib / final_T together with the semantic image): scene outputs equal the
+    plain AUX render, semantic outputs equal the fused frames path -- including quarters that take the plain loop because
+    their tile holds no object entry."""
+    import torch
+    from pegasus_amd import frames as F, rasterizer as R
+    cloud, views, _ = scenes.merged_scene(77, 20000, 3, 3000, 3, 200, 150, plane_size=2.0)
+    act = cloud.activated()
+    fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"], cloud.object_id,
+                         sh_degree=3, device=gpu_device, bg=(0.2, 0.1, 0.3))
+    specs = [fr.view_spec(v) for v in views]
+    kw = dict(shs=fr.shs, scales=fr.scales, rotations=fr.rotations, sh_degree=3, tie_index=fr.tie_index, want_radii=False)
+    plain = R.forward_views(fr.means3d, fr.opacities, specs, want_aux=True, **kw)
+    plain = [{k: v.clone() for k, v in r.items() if v is not None} for r in plain]
+    both = R.forward_views(fr.means3d, fr.opacities, specs, want_aux=True, semantic=fr.semantic, **kw)
+    frames = fr.render_frames(specs)
+    torch.cuda.synchronize()
+    for i in range(len(specs)):
+        for k in ("color", "depth", "final_T", "n_contrib"):
+            assert torch.equal(both[i][k], plain[i][k]), (i, k)
+        assert torch.equal(both[i]["sem_color"], frames["seg"][i]) and torch.equal(both[i]["sem_depth"], frames["seg_depth"][i])
+    assert float(frames["seg"].std()) > 0
