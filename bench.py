@@ -54,6 +54,7 @@ def parse():
                     help="dynamic sequence: every frame is a TIME STEP with its own object poses (posed inside the "
                          "preprocess) and one camera, plus its BOP pose records")
     ap.add_argument("--raster-only", action="store_true", help="time only the full-scene RGB+depth pass (R), no masks")
+    ap.add_argument("--slots", type=int, default=3, help="batches in flight (pipeline slots: streams, workspaces, frame sets)")
     ap.add_argument("--step-log", action="store_true", help="per-step (enqueue, wait) host milliseconds on stderr")
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: also gather every batch's finished frames to rank 0 inside the timed region, in the "
@@ -130,7 +131,8 @@ def main():
     P = W * H
     with_masks = not args.raster_only and fr.K > 0
     frames = fr.alloc_frames(B, H, W, masks=with_masks)      # frame buffers, reused (two sets: 2-deep pipeline)
-    frames2 = fr.alloc_frames(B, H, W, masks=with_masks)
+    n_slots = max(1, args.slots)
+    frame_sets = [frames] + [fr.alloc_frames(B, H, W, masks=with_masks) for _ in range(n_slots - 1)]
 
     def batch_views(i):
         return [specs[(i * B + k) % len(specs)] for k in range(B)]
@@ -210,24 +212,24 @@ def main():
             for i in range(first, first + count):
                 gather_finished(step(i))
             return
-        pending = None
+        pending = []                                  # at most n_slots - 1 older batches in flight
         for i in range(first, first + count):
             render = fr.render_batch_async if args.separate_semantic else fr.render_frames_async
             if pose_seq is not None:
-                h = fr.render_frames_async(batch_views(i), frames if i % 2 == 0 else frames2, masks=with_masks,
-                                           slot=i % 2, poses=batch_poses(i))
+                h = fr.render_frames_async(batch_views(i), frame_sets[i % n_slots], masks=with_masks,
+                                           slot=i % n_slots, poses=batch_poses(i))
                 batch_records(i)                  # BOP scene_gt / scene_camera entries of the batch (host, overlapped)
             else:
                 t_e = time.perf_counter()
-                h = render(batch_views(i), frames if i % 2 == 0 else frames2, masks=with_masks, slot=i % 2)
+                h = render(batch_views(i), frame_sets[i % n_slots], masks=with_masks, slot=i % n_slots)
             t_w = time.perf_counter()
-            if pending is not None:
-                gather_finished(pending.wait())
+            pending.append(h)
+            while len(pending) >= n_slots:
+                gather_finished(pending.pop(0).wait())
             if args.step_log and pose_seq is None:
                 print(f"step {i}: enqueue {(t_w - t_e) * 1e3:.2f} ms, wait {(time.perf_counter() - t_w) * 1e3:.2f} ms", file=sys.stderr)
-            pending = h
-        if pending is not None:
-            gather_finished(pending.wait())
+        while pending:
+            gather_finished(pending.pop(0).wait())
         if gather_state["inflight"] is not None:
             finish, works = gather_state["inflight"]
             for w_ in works:

@@ -117,9 +117,11 @@ class FrameRenderer:
         B = len(specs)
         dev = self.device
         cur = torch.cuda.current_stream(dev)
-        if not hasattr(self, "_streams"):
-            self._streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
-        st = self._streams[slot % 2]
+        if not hasattr(self, "_slot_streams"):
+            self._slot_streams = {}
+        st = self._slot_streams.get(slot)
+        if st is None:
+            st = self._slot_streams[slot] = torch.cuda.Stream(dev)
         fused = masks and self.K > 0
         outs = [dict(color=frames["color"][i], depth=frames["depth"][i], radii=None) for i in range(B)]
         if fused:
