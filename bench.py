@@ -206,7 +206,7 @@ def main():
         gather_state["inflight"] = VS.gather_frames(local, B * world, dst=0, async_op=True)
 
     def run_steps(first, count):
-        """`count` steps as a 2-deep software pipeline: batch i is enqueued (scene pass and semantic pass on two
+        """`count` steps as an `n_slots`-deep software pipeline: batch i is enqueued (scene pass and semantic pass on two
         streams, no host sync) while batch i-1 finishes; every batch's overflow status is checked."""
         if args.sync_steps:
             for i in range(first, first + count):
@@ -242,7 +242,7 @@ def main():
     # their need (C2: 1 M for views that list 1.4 M) and would otherwise pay that inside the timed region.
     for _ in range(3):
         before = dict(rasterizer._WS.capacity_hint)
-        run_steps(0, 2)
+        run_steps(0, max(2, n_slots))                 # every slot: its stream, workspace and frame set exist after this
         torch.cuda.synchronize()
         if dict(rasterizer._WS.capacity_hint) == before:
             break
