@@ -390,8 +390,11 @@ constexpr int ORDER_BAND_ROWS = 1;
 constexpr int ORDER_CLASSES_USED = 3;            // > 4096, > 1024, rest
 constexpr int ORDER_BINS = NUM_XCD * ORDER_CLASSES_USED;
 
-// order_state layout (uint32): [ORDER_BINS] counters -> cursors, then [1] number of long lists
-constexpr int ORDER_STATE_WORDS = ORDER_BINS + 1;
+// order_state layout (uint32): [ORDER_BINS] counters -> cursors, then [LONG_TIERS] lengths of the long-list queues
+constexpr int LONG_TIERS = 3;                    // 2049..4096, 4097..8192, longer: one queue and one sort launch each
+constexpr int ORDER_STATE_WORDS = ORDER_BINS + LONG_TIERS;
+
+__device__ __forceinline__ int long_tier(uint32_t len) { return len > 8192u ? 2 : (len > 4096u ? 1 : 0); }
 
 __device__ __forceinline__ int xcd_of_tile(int tile, int grid_x) { return (tile / grid_x / ORDER_BAND_ROWS) % NUM_XCD; }
 
@@ -432,26 +435,26 @@ __global__ void order_scan_kernel(uint32_t* __restrict__ state) {
 // grid = (ceil(tiles/256), n_views), 256 threads.  work_order is pre-filled with INVALID_ITEM.  Ranks inside a
 // workgroup follow the tile order (ballot prefix per bin), so row-major neighbours stay adjacent in their
 // stream; one global atomic per non-empty (workgroup, bin) claims the slots.  Tiles whose list exceeds
-// `long_threshold` are also appended to long_list for the long sort tiers.
+// `long_threshold` are also appended to the queue of their sort tier: long_list[tier * long_stride + ...].
 __global__ __launch_bounds__(256) void order_scatter_kernel(const ViewEntry* __restrict__ views, int tiles, int grid_x,
                                                             uint32_t* __restrict__ state,
                                                             uint32_t* __restrict__ work_order, uint32_t long_threshold,
-                                                            uint32_t* __restrict__ long_list) {
+                                                            uint32_t* __restrict__ long_list, uint32_t long_stride) {
     __shared__ uint32_t wave_cnt[4][ORDER_BINS];
     __shared__ uint32_t base[ORDER_BINS];
-    __shared__ uint32_t n_long_s, long_base_s;
+    __shared__ uint32_t n_long_s[LONG_TIERS], long_base_s[LONG_TIERS];
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-    if (threadIdx.x == 0) n_long_s = 0;
+    if (threadIdx.x < LONG_TIERS) n_long_s[threadIdx.x] = 0;
     __syncthreads();
     const int t = blockIdx.x * 256 + threadIdx.x;
-    int bin = -1, x = 0;
+    int bin = -1, x = 0, tier = 0;
     uint32_t long_rank = INVALID_ITEM;
     if (t < tiles) {
         const uint2 r = views[blockIdx.y].ranges[t];
         const uint32_t len = r.y - r.x;
         x = xcd_of_tile(t, grid_x);
         bin = x * ORDER_CLASSES_USED + coarse_class(len);
-        if (len > long_threshold) long_rank = atomicAdd(&n_long_s, 1u);
+        if (len > long_threshold) { tier = long_tier(len); long_rank = atomicAdd(&n_long_s[tier], 1u); }
     }
     // ordered rank inside the wave, per bin
     uint32_t rank = 0;
@@ -466,7 +469,8 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const ViewEntry* __r
                              wave_cnt[3][threadIdx.x];
         base[threadIdx.x] = tot ? atomicAdd(&state[threadIdx.x], ITEMS_PER_TILE * tot) : 0u;
     }
-    if (threadIdx.x == 0 && n_long_s) long_base_s = atomicAdd(&state[ORDER_BINS], n_long_s);
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + LONG_TIERS && n_long_s[threadIdx.x - 64])
+        long_base_s[threadIdx.x - 64] = atomicAdd(&state[ORDER_BINS + threadIdx.x - 64], n_long_s[threadIdx.x - 64]);
     __syncthreads();
     if (t < tiles) {
         uint32_t before = 0;
@@ -474,7 +478,8 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const ViewEntry* __r
         const uint32_t r0 = base[bin] + ITEMS_PER_TILE * (before + rank);     // position inside stream x
         const uint32_t item = ITEMS_PER_TILE * ((uint32_t)blockIdx.y * (uint32_t)tiles + (uint32_t)t);
         for (uint32_t k = 0; k < ITEMS_PER_TILE; ++k) work_order[(size_t)(r0 + k) * NUM_XCD + x] = item + k;
-        if (long_rank != INVALID_ITEM) long_list[long_base_s + long_rank] = (uint32_t)blockIdx.y * (uint32_t)tiles + (uint32_t)t;
+        if (long_rank != INVALID_ITEM)
+            long_list[(size_t)tier * long_stride + long_base_s[tier] + long_rank] = (uint32_t)blockIdx.y * (uint32_t)tiles + (uint32_t)t;
     }
 }
 

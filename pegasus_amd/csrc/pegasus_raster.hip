@@ -144,7 +144,7 @@ static BatchLayout make_batch_layout(const Layout& L, int n_views, size_t n_scen
     // NUM_XCD interleaved streams; each holds the items of its band of tile rows for every view
     B.order_slots = (size_t)NUM_XCD * max_band_rows(L.grid_y) * L.grid_x * ITEMS_PER_TILE * n_views;
     B.work_order = take(B.order_slots * 4);
-    B.long_list = take((size_t)n_views * L.tiles * 4);
+    B.long_list = take((size_t)n_views * L.tiles * 4 * LONG_TIERS);
     B.tie_inv = take((size_t)n_scene * 4);     // inverse of PgrScene::tie_index (filled only when one is given)
     B.n_groups = (int)((n_scene + WAVE - 1) / WAVE);
     B.vis_words = (n_views + 31) / 32;
@@ -327,12 +327,16 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     const dim3 og((L.tiles + 255) / 256, n_views);
     order_count_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, L.grid_x, order_state);
     order_scan_kernel<<<1, 64, 0, stream>>>(order_state);
+    const uint32_t long_stride = (uint32_t)n_views * (uint32_t)L.tiles;
     order_scatter_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, L.grid_x, order_state, work_order,
-                                                 (uint32_t)SORT_SMALL_MAX, long_list);
+                                                 (uint32_t)SORT_SMALL_MAX, long_list, long_stride);
     const uint32_t* n_long = order_state + ORDER_BINS;
-    tile_sort_long_kernel<1024, 16, 4096><<<std::min(n_views * L.tiles, 1024), 1024, 0, stream>>>(
-        bin_table, L.tiles, long_list, n_long);
-    tile_sort_long_kernel<512, 8, SORT_SMALL_MAX><<<std::min(n_views * L.tiles, 2048), 512, 0, stream>>>(
+    const int items = n_views * L.tiles;
+    tile_sort_long_kernel<1024, 16, true><<<std::min(items, 512), 1024, 0, stream>>>(
+        bin_table, L.tiles, long_list + 2 * (size_t)long_stride, n_long + 2);
+    tile_sort_long_kernel<1024, 8, false><<<std::min(items, 1024), 1024, 0, stream>>>(
+        bin_table, L.tiles, long_list + (size_t)long_stride, n_long + 1);
+    tile_sort_long_kernel<512, 8, false><<<std::min(items, 2048), 512, 0, stream>>>(
         bin_table, L.tiles, long_list, n_long);
     tile_sort_kernel<<<n_views * L.tiles, SORT_THREADS, 0, stream>>>(bin_table, L.tiles);
     mark(4);

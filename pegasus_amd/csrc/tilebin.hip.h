@@ -436,16 +436,20 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
     const unsigned long long t_start_ = t_prev_;
 #endif
 
+    // All E loads of a thread are issued back to back (index clamped into the list, n >= 1) and waited for once: a
+    // load inside `if (i < n)` is not hoisted by the compiler, and E branches each ending in s_waitcnt vmcnt(0) made
+    // the key load E serial round trips (20 k of the 46 k cycles of a 5 k-key list, s_memtime stamps).
     uint32_t d[E], id[E];
     uint32_t dmin = 0xffffffffu, dmax = 0u;
+    {
+        uint2 v[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int i = e * THREADS + t;
-        d[e] = 0xffffffffu; id[e] = 0xffffffffu;
-        if (i < n) {
-            const uint2 v = bucket[i];
-            d[e] = v.x; id[e] = v.y;
-            dmin = min(dmin, v.x); dmax = max(dmax, v.x);
+        for (int e = 0; e < E; ++e) v[e] = bucket[min(e * THREADS + t, n - 1)];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool in = e * THREADS + t < n;
+            d[e] = in ? v[e].x : 0xffffffffu; id[e] = in ? v[e].y : 0xffffffffu;
+            dmin = min(dmin, d[e]); dmax = max(dmax, in ? v[e].x : 0u);
         }
     }
     for (int i = t; i < NB; i += THREADS) s_hist[i] = 0u;
@@ -533,7 +537,19 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
             if (cnt > 1u) {
                 const uint64_t key = ((uint64_t)d[e] << 32) | id[e];
                 uint32_t same = 0;                       // members with this key's depth bits (itself included)
-                for (uint32_t j = s0; j < s0 + cnt; ++j) {
+                // the first RANK_BATCH members in ONE LDS round trip (independent reads, index clamped into the bucket);
+                // a serial read-compare loop pays the LDS latency per member, and most buckets hold 2..4 keys
+                constexpr uint32_t RANK_BATCH = 4;
+                uint64_t kb[RANK_BATCH];
+#pragma unroll
+                for (uint32_t m = 0; m < RANK_BATCH; ++m) kb[m] = s_keys[s0 + min(m, cnt - 1u)];
+#pragma unroll
+                for (uint32_t m = 0; m < RANK_BATCH; ++m) {
+                    const bool in = m < cnt;
+                    rank += (in && kb[m] < key) ? 1u : 0u;
+                    same += (in && (uint32_t)(kb[m] >> 32) == d[e]) ? 1u : 0u;
+                }
+                for (uint32_t j = s0 + RANK_BATCH; j < s0 + cnt; ++j) {
                     const uint64_t kj = s_keys[j];
                     rank += kj < key ? 1u : 0u;
                     same += (uint32_t)(kj >> 32) == d[e] ? 1u : 0u;
@@ -720,8 +736,9 @@ __device__ __forceinline__ bool sort_item(const BinView* __restrict__ views, int
     const uint32_t view = item / (uint32_t)tiles;
     const uint32_t tile = item - view * (uint32_t)tiles;
     const BinView& bv = views[view];
-    if (bv.counters[1]) return false;
+    const uint32_t overflowed = bv.counters[1];          // both loads in flight before the test (one round trip, not two)
     const uint2 range = bv.ranges[tile];
+    if (overflowed) return false;
     n = (int)(range.y - range.x);
     bucket = bv.bucket + range.x;
     out = bv.gauss_sorted + range.x;
@@ -731,7 +748,17 @@ __device__ __forceinline__ bool sort_item(const BinView* __restrict__ views, int
 }
 
 // grid = n_views * tiles workgroups of 256; lists of 1..2048 entries
-__global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* __restrict__ views, int tiles) {
+#ifdef PGR_SORT_WAVES
+#define PGR_SORT_OCC __attribute__((amdgpu_waves_per_eu(PGR_SORT_WAVES, PGR_SORT_WAVES)))
+#else
+#define PGR_SORT_OCC
+#endif
+#ifdef PGR_SORT1_WAVES
+#define PGR_SORT1_OCC __attribute__((amdgpu_waves_per_eu(PGR_SORT1_WAVES, PGR_SORT1_WAVES)))
+#else
+#define PGR_SORT1_OCC
+#endif
+__global__ __launch_bounds__(SORT_THREADS) PGR_SORT_OCC void tile_sort_kernel(const BinView* __restrict__ views, int tiles) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[SORT_THREADS * 8 * 12 + 128];
     uint64_t* skeys = reinterpret_cast<uint64_t*>(lds);     // merge sort: SORT_THREADS * 9 keys fit as well
     const uint2* bucket; uint32_t* out; int n; ObjOut oo;
@@ -749,43 +776,37 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* 
     }
 }
 
-// Lists longer than 2048: order_scatter_kernel appends them to long_list (device counter n_long); workgroups
-// stride over the list.  Three launches share the queue (tiers below); the last one sorts 8193..16384 keys in LDS
-// (keys + 4096 buckets: 144 KiB of the CU's 160 KiB, sorted indices stored straight to global memory) and anything
-// longer as merge-sorted 16384-key chunks merged through L2 between the list and its alt buffer.
-// Queue tiers (THREADS, E): (512, 8) takes 2049..4096 keys (48 KiB of LDS: three workgroups per CU); (1024, 16)
-// takes everything longer -- 4097..8192 with one bucket per key (96 KiB image), 8193..16384 with 4096 buckets --
-// in ONE launch: both need a whole CU's LDS, and the few longest lists then overlap the many medium ones instead of
-// holding a launch of their own (measured 150 us per batch).  LO = the previous tier's capacity.
-template <int THREADS, int E, int LO>
-__global__ __launch_bounds__(THREADS) void tile_sort_long_kernel(const BinView* __restrict__ views, int tiles,
+// Lists longer than 2048: order_scatter_kernel appends them to the queue of their tier (device counters n_long[tier]);
+// workgroups stride over their own queue.  One launch per tier (THREADS, E):
+//   (512, 8)    2049..4096 keys, 48 KiB of LDS: three workgroups per CU;
+//   (1024, 8)   4097..8192 keys, one bucket per key (96 KiB image): one per CU;
+//   (1024, 16)  LAST, open-ended: 8193..16384 keys with 4096 buckets (144 KiB, sorted indices stored straight to global
+//               memory), anything longer depth-partitioned into LDS-sized segments or, failing that, merge-sorted
+//               16384-key chunks merged through L2 between the list and its alt buffer.
+// A kernel per tier keeps each one's register budget its own: with the open-ended tier's code in the same kernel the
+// 4097..8192 path (a quarter of C3's keys) ran out of the 128 VGPRs a 1024-thread workgroup gets and spilled.
+template <int THREADS, int E, bool LAST>
+__global__ __launch_bounds__(THREADS) PGR_SORT1_OCC void tile_sort_long_kernel(const BinView* __restrict__ views, int tiles,
                                                                  const uint32_t* __restrict__ long_list,
                                                                  const uint32_t* __restrict__ n_long) {
     constexpr int CAP = THREADS * E;
-    constexpr bool LAST = CAP == SORT_LARGE_MAX;      // the open-ended tier
+    static_assert(!LAST || CAP == SORT_LARGE_MAX, "the open-ended tier");
     // bucket sort image: 12 B per key, or (last tier) keys + 4096 counters = 144 KiB; the merge sort's padded keys fit
     constexpr size_t LDS_BYTES = LAST ? (size_t)CAP * 8 + SORT_LARGE_BUCKETS * 4 + 128 : (size_t)CAP * 12 + 128;
     static_assert((size_t)THREADS * (E + 1) * 8 <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "lds");
-    static_assert(!LAST || (size_t)(CAP / 2) * 12 + 128 <= LDS_BYTES, "half-capacity image");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
-    __shared__ uint32_t s_cut[PART_MAX_SEGMENTS + 3];
+    __shared__ uint32_t s_cut[LAST ? PART_MAX_SEGMENTS + 3 : 1];
     uint64_t* skeys = reinterpret_cast<uint64_t*>(lds);
     const uint32_t cand = *n_long;
     for (uint32_t k = blockIdx.x; k < cand; k += gridDim.x) {
         const uint2* bucket; uint32_t* out; int n; uint64_t* alt; ObjOut oo;
-        const bool ok = sort_item(views, tiles, long_list[k], bucket, out, n, oo, &alt);
-        const bool mine = n > LO && (LAST || n <= CAP);
-        if (ok && mine) {
-            if (LAST && n <= CAP / 2) {
-                if (!bucket_sort_tile<THREADS, E / 2>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
-                    merge_sort_tile<THREADS, E / 2>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
+        if (sort_item(views, tiles, long_list[k], bucket, out, n, oo, &alt)) {
+            if constexpr (!LAST) {
+                if (!bucket_sort_tile<THREADS, E>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+                    merge_sort_tile<THREADS, E>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
             } else if (n <= CAP) {
-                bool sorted;
-                if constexpr (LAST)
-                    sorted = bucket_sort_tile<THREADS, E, SORT_LARGE_BUCKETS, true>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie);
-                else
-                    sorted = bucket_sort_tile<THREADS, E>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie);
-                if (!sorted) merge_sort_tile<THREADS, E>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
+                if (!bucket_sort_tile<THREADS, E, SORT_LARGE_BUCKETS, true>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+                    merge_sort_tile<THREADS, E>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
             } else if (partition_sort_long<THREADS, E>(lds, s_cut, bucket, reinterpret_cast<uint2*>(alt), out, n, oo.n_env,
                                                        oo.last, oo.tie, oo.inv)) {
                 // done: depth-partitioned through the alt buffer, every segment sorted in LDS
