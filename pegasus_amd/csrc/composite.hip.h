@@ -390,11 +390,15 @@ constexpr int ORDER_BAND_ROWS = 1;
 constexpr int ORDER_CLASSES_USED = 3;            // > 4096, > 1024, rest
 constexpr int ORDER_BINS = NUM_XCD * ORDER_CLASSES_USED;
 
-// order_state layout (uint32): [ORDER_BINS] counters -> cursors, then [LONG_TIERS] lengths of the long-list queues
-constexpr int LONG_TIERS = 3;                    // 2049..4096, 4097..8192, longer: one queue and one sort launch each
-constexpr int ORDER_STATE_WORDS = ORDER_BINS + LONG_TIERS;
+// order_state layout (uint32): [ORDER_BINS] counters -> cursors, then [SORT_TIERS] lengths of the sort queues
+// Sort queues: every non-empty list of a view that did not overflow is one uint4 (item, first instance, keys, 0) in the
+// queue of its tier -- 1..2048 keys, 2049..4096, 4097..8192, longer: one queue and one sort launch each.  A sort
+// workgroup learns its list from that one word (the view's table entry arrives beside it through the scalar cache)
+// instead of chasing item -> view table -> ranges -> keys; and a launch has no workgroups for empty tiles.
+constexpr int SORT_TIERS = 4;
+constexpr int ORDER_STATE_WORDS = ORDER_BINS + SORT_TIERS;
 
-__device__ __forceinline__ int long_tier(uint32_t len) { return len > 8192u ? 2 : (len > 4096u ? 1 : 0); }
+__device__ __forceinline__ int sort_tier(uint32_t len) { return len > 8192u ? 3 : (len > 4096u ? 2 : (len > 2048u ? 1 : 0)); }
 
 __device__ __forceinline__ int xcd_of_tile(int tile, int grid_x) { return (tile / grid_x / ORDER_BAND_ROWS) % NUM_XCD; }
 
@@ -434,27 +438,30 @@ __global__ void order_scan_kernel(uint32_t* __restrict__ state) {
 
 // grid = (ceil(tiles/256), n_views), 256 threads.  work_order is pre-filled with INVALID_ITEM.  Ranks inside a
 // workgroup follow the tile order (ballot prefix per bin), so row-major neighbours stay adjacent in their
-// stream; one global atomic per non-empty (workgroup, bin) claims the slots.  Tiles whose list exceeds
-// `long_threshold` are also appended to the queue of their sort tier: long_list[tier * long_stride + ...].
+// stream; one global atomic per non-empty (workgroup, bin) claims the slots.  Non-empty lists are also appended to the
+// sort queue of their tier: sort_queue[tier * queue_stride + ...].
 __global__ __launch_bounds__(256) void order_scatter_kernel(const ViewEntry* __restrict__ views, int tiles, int grid_x,
                                                             uint32_t* __restrict__ state,
-                                                            uint32_t* __restrict__ work_order, uint32_t long_threshold,
-                                                            uint32_t* __restrict__ long_list, uint32_t long_stride) {
+                                                            uint32_t* __restrict__ work_order,
+                                                            uint4* __restrict__ sort_queue, uint32_t queue_stride) {
     __shared__ uint32_t wave_cnt[4][ORDER_BINS];
     __shared__ uint32_t base[ORDER_BINS];
-    __shared__ uint32_t n_long_s[LONG_TIERS], long_base_s[LONG_TIERS];
+    __shared__ uint32_t n_queue_s[SORT_TIERS], queue_base_s[SORT_TIERS];
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-    if (threadIdx.x < LONG_TIERS) n_long_s[threadIdx.x] = 0;
+    if (threadIdx.x < SORT_TIERS) n_queue_s[threadIdx.x] = 0;
     __syncthreads();
     const int t = blockIdx.x * 256 + threadIdx.x;
     int bin = -1, x = 0, tier = 0;
-    uint32_t long_rank = INVALID_ITEM;
+    uint32_t queue_rank = INVALID_ITEM;
+    uint2 r = make_uint2(0u, 0u);
     if (t < tiles) {
-        const uint2 r = views[blockIdx.y].ranges[t];
+        const ViewEntry& ve = views[blockIdx.y];
+        const uint32_t overflowed = ve.counters[1];
+        r = ve.ranges[t];
         const uint32_t len = r.y - r.x;
         x = xcd_of_tile(t, grid_x);
         bin = x * ORDER_CLASSES_USED + coarse_class(len);
-        if (len > long_threshold) { tier = long_tier(len); long_rank = atomicAdd(&n_long_s[tier], 1u); }
+        if (len > 0u && !overflowed) { tier = sort_tier(len); queue_rank = atomicAdd(&n_queue_s[tier], 1u); }
     }
     // ordered rank inside the wave, per bin
     uint32_t rank = 0;
@@ -469,17 +476,17 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const ViewEntry* __r
                              wave_cnt[3][threadIdx.x];
         base[threadIdx.x] = tot ? atomicAdd(&state[threadIdx.x], ITEMS_PER_TILE * tot) : 0u;
     }
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + LONG_TIERS && n_long_s[threadIdx.x - 64])
-        long_base_s[threadIdx.x - 64] = atomicAdd(&state[ORDER_BINS + threadIdx.x - 64], n_long_s[threadIdx.x - 64]);
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + SORT_TIERS && n_queue_s[threadIdx.x - 64])
+        queue_base_s[threadIdx.x - 64] = atomicAdd(&state[ORDER_BINS + threadIdx.x - 64], n_queue_s[threadIdx.x - 64]);
     __syncthreads();
     if (t < tiles) {
         uint32_t before = 0;
         for (int w = 0; w < wave; ++w) before += wave_cnt[w][bin];
         const uint32_t r0 = base[bin] + ITEMS_PER_TILE * (before + rank);     // position inside stream x
-        const uint32_t item = ITEMS_PER_TILE * ((uint32_t)blockIdx.y * (uint32_t)tiles + (uint32_t)t);
-        for (uint32_t k = 0; k < ITEMS_PER_TILE; ++k) work_order[(size_t)(r0 + k) * NUM_XCD + x] = item + k;
-        if (long_rank != INVALID_ITEM)
-            long_list[(size_t)tier * long_stride + long_base_s[tier] + long_rank] = (uint32_t)blockIdx.y * (uint32_t)tiles + (uint32_t)t;
+        const uint32_t list = (uint32_t)blockIdx.y * (uint32_t)tiles + (uint32_t)t;
+        for (uint32_t k = 0; k < ITEMS_PER_TILE; ++k) work_order[(size_t)(r0 + k) * NUM_XCD + x] = ITEMS_PER_TILE * list + k;
+        if (queue_rank != INVALID_ITEM)
+            sort_queue[(size_t)tier * queue_stride + queue_base_s[tier] + queue_rank] = make_uint4(list, r.x, r.y - r.x, 0u);
     }
 }
 

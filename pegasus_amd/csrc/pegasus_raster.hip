@@ -144,7 +144,7 @@ static BatchLayout make_batch_layout(const Layout& L, int n_views, size_t n_scen
     // NUM_XCD interleaved streams; each holds the items of its band of tile rows for every view
     B.order_slots = (size_t)NUM_XCD * max_band_rows(L.grid_y) * L.grid_x * ITEMS_PER_TILE * n_views;
     B.work_order = take(B.order_slots * 4);
-    B.long_list = take((size_t)n_views * L.tiles * 4 * LONG_TIERS);
+    B.long_list = take((size_t)n_views * L.tiles * sizeof(uint4) * SORT_TIERS);   // the sort queues
     B.tie_inv = take((size_t)n_scene * 4);     // inverse of PgrScene::tie_index (filled only when one is given)
     B.n_groups = (int)((n_scene + WAVE - 1) / WAVE);
     B.vis_words = (n_views + 31) / 32;
@@ -234,7 +234,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     auto* cams_dev = reinterpret_cast<CameraDev*>(ws + B.cams);
     auto* status_dev = reinterpret_cast<uint32_t*>(ws + B.status);
     auto* order_state = reinterpret_cast<uint32_t*>(ws + B.order_state);
-    auto* long_list = reinterpret_cast<uint32_t*>(ws + B.long_list);
+    auto* sort_queue = reinterpret_cast<uint4*>(ws + B.long_list);
     auto* work_order = reinterpret_cast<uint32_t*>(ws + B.work_order);
     std::vector<ViewWs> vw((size_t)n_views);
     std::vector<char> pageable;
@@ -327,18 +327,18 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     const dim3 og((L.tiles + 255) / 256, n_views);
     order_count_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, L.grid_x, order_state);
     order_scan_kernel<<<1, 64, 0, stream>>>(order_state);
-    const uint32_t long_stride = (uint32_t)n_views * (uint32_t)L.tiles;
-    order_scatter_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, L.grid_x, order_state, work_order,
-                                                 (uint32_t)SORT_SMALL_MAX, long_list, long_stride);
-    const uint32_t* n_long = order_state + ORDER_BINS;
     const int items = n_views * L.tiles;
+    const size_t qs = (size_t)items;              // queue stride
+    order_scatter_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, L.grid_x, order_state, work_order, sort_queue,
+                                                 (uint32_t)items);
+    const uint32_t* n_queue = order_state + ORDER_BINS;
     tile_sort_long_kernel<1024, 16, true><<<std::min(items, 512), 1024, 0, stream>>>(
-        bin_table, L.tiles, long_list + 2 * (size_t)long_stride, n_long + 2);
+        bin_table, L.tiles, sort_queue + 3 * qs, n_queue + 3);
     tile_sort_long_kernel<1024, 8, false><<<std::min(items, 1024), 1024, 0, stream>>>(
-        bin_table, L.tiles, long_list + (size_t)long_stride, n_long + 1);
+        bin_table, L.tiles, sort_queue + 2 * qs, n_queue + 2);
     tile_sort_long_kernel<512, 8, false><<<std::min(items, 2048), 512, 0, stream>>>(
-        bin_table, L.tiles, long_list, n_long);
-    tile_sort_kernel<<<n_views * L.tiles, SORT_THREADS, 0, stream>>>(bin_table, L.tiles);
+        bin_table, L.tiles, sort_queue + qs, n_queue + 1);
+    tile_sort_kernel<<<items, SORT_THREADS, 0, stream>>>(bin_table, L.tiles, sort_queue, n_queue);
     mark(4);
     // ---- stage 4: compositing of every (view, tile, quarter) work item in ONE launch; with `semantic` the same
     // walk also produces the objects-only semantic image

@@ -727,43 +727,31 @@ __device__ __forceinline__ void merge_round_global(const uint64_t* __restrict__ 
 
 constexpr int SORT_SMALL_MAX = SORT_THREADS * 8;       // 2048 keys, 24 KiB of LDS: six workgroups per CU
 
-// item = view * tiles + tile
 struct ObjOut { int n_env; uint32_t* last; const int32_t* tie; const uint32_t* inv; };
 
-__device__ __forceinline__ bool sort_item(const BinView* __restrict__ views, int tiles, uint32_t item,
+// q = sort queue entry (view * tiles + tile, first instance, keys, 0): order_scatter_kernel (composite.hip.h)
+__device__ __forceinline__ void sort_item(const BinView* __restrict__ views, int tiles, const uint4 q,
                                           const uint2*& bucket, uint32_t*& out, int& n, ObjOut& oo,
                                           uint64_t** alt = nullptr) {
-    const uint32_t view = item / (uint32_t)tiles;
-    const uint32_t tile = item - view * (uint32_t)tiles;
+    const uint32_t view = q.x / (uint32_t)tiles;
+    const uint32_t tile = q.x - view * (uint32_t)tiles;
     const BinView& bv = views[view];
-    const uint32_t overflowed = bv.counters[1];          // both loads in flight before the test (one round trip, not two)
-    const uint2 range = bv.ranges[tile];
-    if (overflowed) return false;
-    n = (int)(range.y - range.x);
-    bucket = bv.bucket + range.x;
-    out = bv.gauss_sorted + range.x;
+    n = (int)q.z;
+    bucket = bv.bucket + q.y;
+    out = bv.gauss_sorted + q.y;
     oo = ObjOut{bv.n_env, bv.obj_last + tile, bv.tie_index, bv.tie_inv};
-    if (alt) *alt = bv.alt + range.x;
-    return n > 0;
+    if (alt) *alt = bv.alt + q.y;
 }
 
-// grid = n_views * tiles workgroups of 256; lists of 1..2048 entries
-#ifdef PGR_SORT_WAVES
-#define PGR_SORT_OCC __attribute__((amdgpu_waves_per_eu(PGR_SORT_WAVES, PGR_SORT_WAVES)))
-#else
-#define PGR_SORT_OCC
-#endif
-#ifdef PGR_SORT1_WAVES
-#define PGR_SORT1_OCC __attribute__((amdgpu_waves_per_eu(PGR_SORT1_WAVES, PGR_SORT1_WAVES)))
-#else
-#define PGR_SORT1_OCC
-#endif
-__global__ __launch_bounds__(SORT_THREADS) PGR_SORT_OCC void tile_sort_kernel(const BinView* __restrict__ views, int tiles) {
+// grid = n_views * tiles workgroups of 256 (upper bound of the queue's length); lists of 1..2048 entries
+__global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* __restrict__ views, int tiles,
+                                                                 const uint4* __restrict__ queue,
+                                                                 const uint32_t* __restrict__ n_queue) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[SORT_THREADS * 8 * 12 + 128];
     uint64_t* skeys = reinterpret_cast<uint64_t*>(lds);     // merge sort: SORT_THREADS * 9 keys fit as well
+    if (blockIdx.x >= *n_queue) return;
     const uint2* bucket; uint32_t* out; int n; ObjOut oo;
-    if (!sort_item(views, tiles, blockIdx.x, bucket, out, n, oo)) return;
-    if (n > SORT_SMALL_MAX) return;                      // the long tiers'
+    sort_item(views, tiles, queue[blockIdx.x], bucket, out, n, oo);
     if (n <= SORT_THREADS * 2) {
         if (!bucket_sort_tile<SORT_THREADS, 2>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
             merge_sort_tile<SORT_THREADS, 2>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
@@ -776,8 +764,7 @@ __global__ __launch_bounds__(SORT_THREADS) PGR_SORT_OCC void tile_sort_kernel(co
     }
 }
 
-// Lists longer than 2048: order_scatter_kernel appends them to the queue of their tier (device counters n_long[tier]);
-// workgroups stride over their own queue.  One launch per tier (THREADS, E):
+// Lists longer than 2048: workgroups stride over the queue of their tier.  One launch per tier (THREADS, E):
 //   (512, 8)    2049..4096 keys, 48 KiB of LDS: three workgroups per CU;
 //   (1024, 8)   4097..8192 keys, one bucket per key (96 KiB image): one per CU;
 //   (1024, 16)  LAST, open-ended: 8193..16384 keys with 4096 buckets (144 KiB, sorted indices stored straight to global
@@ -786,9 +773,9 @@ __global__ __launch_bounds__(SORT_THREADS) PGR_SORT_OCC void tile_sort_kernel(co
 // A kernel per tier keeps each one's register budget its own: with the open-ended tier's code in the same kernel the
 // 4097..8192 path (a quarter of C3's keys) ran out of the 128 VGPRs a 1024-thread workgroup gets and spilled.
 template <int THREADS, int E, bool LAST>
-__global__ __launch_bounds__(THREADS) PGR_SORT1_OCC void tile_sort_long_kernel(const BinView* __restrict__ views, int tiles,
-                                                                 const uint32_t* __restrict__ long_list,
-                                                                 const uint32_t* __restrict__ n_long) {
+__global__ __launch_bounds__(THREADS) void tile_sort_long_kernel(const BinView* __restrict__ views, int tiles,
+                                                                 const uint4* __restrict__ queue,
+                                                                 const uint32_t* __restrict__ n_queue) {
     constexpr int CAP = THREADS * E;
     static_assert(!LAST || CAP == SORT_LARGE_MAX, "the open-ended tier");
     // bucket sort image: 12 B per key, or (last tier) keys + 4096 counters = 144 KiB; the merge sort's padded keys fit
@@ -797,10 +784,11 @@ __global__ __launch_bounds__(THREADS) PGR_SORT1_OCC void tile_sort_long_kernel(c
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     __shared__ uint32_t s_cut[LAST ? PART_MAX_SEGMENTS + 3 : 1];
     uint64_t* skeys = reinterpret_cast<uint64_t*>(lds);
-    const uint32_t cand = *n_long;
+    const uint32_t cand = *n_queue;
     for (uint32_t k = blockIdx.x; k < cand; k += gridDim.x) {
         const uint2* bucket; uint32_t* out; int n; uint64_t* alt; ObjOut oo;
-        if (sort_item(views, tiles, long_list[k], bucket, out, n, oo, &alt)) {
+        sort_item(views, tiles, queue[k], bucket, out, n, oo, &alt);
+        {
             if constexpr (!LAST) {
                 if (!bucket_sort_tile<THREADS, E>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
                     merge_sort_tile<THREADS, E>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
