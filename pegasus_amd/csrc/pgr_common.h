@@ -15,6 +15,35 @@ constexpr float ALPHA_MAX = 0.99f;
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float T_EPS = 0.0001f;
 
+// Global-memory accessors.  Pointers that reach a kernel through a table in memory (per-view slices, output images)
+// are generic, and the compiler addresses them with FLAT instructions: those also count on lgkmcnt, so every LDS wait
+// behind one stalls until the flat access has cleared the texture-address unit (a scattered 8-byte store: 64 lines).
+// These helpers say "global" (address space 1): global_load / global_store count on vmcnt only.
+#define PGR_GLOBAL __attribute__((address_space(1)))
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t gload(const uint32_t* p) { return *(const PGR_GLOBAL uint32_t*)p; }
+__device__ __forceinline__ int32_t gload(const int32_t* p) { return *(const PGR_GLOBAL int32_t*)p; }
+__device__ __forceinline__ float gload(const float* p) { return *(const PGR_GLOBAL float*)p; }
+__device__ __forceinline__ uint64_t gload(const uint64_t* p) { return *(const PGR_GLOBAL uint64_t*)p; }
+__device__ __forceinline__ uint2 gload(const uint2* p) { const u32x2_t v = *(const PGR_GLOBAL u32x2_t*)p; return make_uint2(v.x, v.y); }
+__device__ __forceinline__ uint4 gload(const uint4* p) { const u32x4_t v = *(const PGR_GLOBAL u32x4_t*)p; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float2 gload(const float2* p) { const f32x2_t v = *(const PGR_GLOBAL f32x2_t*)p; return make_float2(v.x, v.y); }
+__device__ __forceinline__ float4 gload(const float4* p) { const f32x4_t v = *(const PGR_GLOBAL f32x4_t*)p; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void gstore(uint32_t* p, uint32_t v) { *(PGR_GLOBAL uint32_t*)p = v; }
+__device__ __forceinline__ void gstore(float* p, float v) { *(PGR_GLOBAL float*)p = v; }
+__device__ __forceinline__ void gstore(uint64_t* p, uint64_t v) { *(PGR_GLOBAL uint64_t*)p = v; }
+__device__ __forceinline__ void gstore(uint2* p, uint2 v) { *(PGR_GLOBAL u32x2_t*)p = u32x2_t{v.x, v.y}; }
+__device__ __forceinline__ void gstore(float4* p, float4 v) { *(PGR_GLOBAL f32x4_t*)p = f32x4_t{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ uint32_t gatomic_add(uint32_t* p, uint32_t v) {
+    return __hip_atomic_fetch_add((PGR_GLOBAL uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t gatomic_max(uint32_t* p, uint32_t v) {
+    return __hip_atomic_fetch_max((PGR_GLOBAL uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Per-view constants, resident in HBM so that no host round trip is needed to read the
 // caller's device-side camera tensors.  256 B, read through the scalar cache.
 struct alignas(16) CameraDev {

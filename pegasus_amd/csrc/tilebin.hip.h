@@ -109,18 +109,23 @@ __device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v) {
 constexpr int BIN_WAVES = BIN_THREADS / WAVE;
 constexpr int BIN_STAGE_WORDS = WAVE * 12 + WAVE;         // per wave: 64 x 3 float4 + 64 head words
 __host__ __device__ inline size_t bin_lds_bytes(int tiles) {
-    return ((size_t)(tiles < BIN_LDS_TILES ? tiles : BIN_LDS_TILES) + 3) / 4 * 16 + (size_t)BIN_WAVES * BIN_STAGE_WORDS * 4;
+    return ((size_t)(tiles < BIN_LDS_TILES ? tiles : BIN_LDS_TILES) + 3) / 4 * 16 + (size_t)BIN_WAVES * BIN_STAGE_WORDS * 4 + 16;
 }
 
 // vis: blockcull.hip.h's visibility words (NULL = all visible); a 64-Gaussian group whose bit is clear has no rectangle
 // to read (the preprocess did not write one).
+//
+// The 64 groups of a chunk are handed out to the waves one at a time (an LDS ticket): walks last from nothing to dozens
+// of iterations, and a static split left most waves of a workgroup waiting for its slowest one.  A group's rectangles and
+// records are fetched with all loads in flight at once (a visible group's Gaussians are nearly all visible, so the
+// records do not wait for the rectangle).
 template <bool SCATTER>
 __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restrict__ views, int n, int grid_x,
                                                           int tiles, int W, int H, const uint32_t* __restrict__ vis,
                                                           int vis_words) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const BinView& bv = views[blockIdx.y];
-    if (SCATTER && bv.counters[1]) return;   // overflow: reported by the host, nothing may be written past the buffers
+    if (SCATTER && gload(bv.counters + 1)) return;   // overflow: reported by the host, nothing may be written past the buffers
     const int chunk = blockIdx.x;
     const int begin = chunk * BIN_CHUNK, end = min(n, begin + BIN_CHUNK);
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
@@ -130,28 +135,56 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restr
     // compiler memory barrier keeps the load behind the stores.  (NOT volatile: a volatile generic pointer turns the
     // three accesses into flat_store/flat_load ... sc0 sc1 with a vmcnt(0) wait each.)
     uint32_t* const heads = reinterpret_cast<uint32_t*>(stage + WAVE * 3);                           // [64]
+    // ctrl[0] = next ticket, ctrl[1..2] = visibility bits of the chunk's groups (fetched once, ahead of the walk)
+    uint32_t* const ctrl = lds + hist_words + BIN_WAVES * BIN_STAGE_WORDS;
+    constexpr int GROUPS = BIN_CHUNK / WAVE;
+    static_assert(GROUPS == WAVE, "one visibility bit per lane of a wave");
     for (int lo = 0; lo < tiles; lo += BIN_LDS_TILES) {
         const int span = min(BIN_LDS_TILES, tiles - lo);
         for (int t = threadIdx.x; t < span; t += BIN_THREADS)
-            lds[t] = SCATTER ? bv.ranges[lo + t].x + bv.rel[(size_t)chunk * tiles + lo + t] : 0u;
+            lds[t] = SCATTER ? gload(bv.ranges + lo + t).x + gload(bv.rel + (size_t)chunk * tiles + lo + t) : 0u;
+        if (wave == 0) {
+            const int b = begin + lane * WAVE;
+            bool visible = b < end;
+            if (visible && vis) visible = (vis[(size_t)(b / WAVE) * vis_words + (blockIdx.y >> 5)] >> (blockIdx.y & 31)) & 1u;
+            const uint64_t m = __ballot(visible);
+            if (lane == 0) { ctrl[0] = 0u; ctrl[1] = (uint32_t)m; ctrl[2] = (uint32_t)(m >> 32); }
+        }
         __syncthreads();
-        for (int base = begin + wave * WAVE; base < end; base += BIN_THREADS) {
-            const int i = base + lane;
-            uint32_t area = 0;
+        const uint64_t vis_bits = ((uint64_t)ctrl[2] << 32) | ctrl[1];
+        // next visible group of the chunk, or GROUPS
+        auto take_ticket = [&]() {
+            for (;;) {
+                uint32_t ticket = 0;
+                if (lane == 0) ticket = atomicAdd(&ctrl[0], 1u);
+                ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+                if (ticket >= (uint32_t)GROUPS || ((vis_bits >> ticket) & 1ull)) return ticket;
+            }
+        };
+        struct Fetched { uint2 r; float4 q0, q1; float depth; };
+        auto fetch = [&](uint32_t ticket) {
+            Fetched f;
+            const int i = begin + (int)ticket * WAVE + lane;
+            const int ic = i < end ? i : end - 1;
+            f.r = gload(bv.rects + ic);
+            f.q0 = gload(bv.splats + (size_t)ic * 3);
+            f.q1 = gload(bv.splats + (size_t)ic * 3 + 1);
+            f.depth = SCATTER ? gload(reinterpret_cast<const float*>(bv.splats + (size_t)ic * 3 + 2) + 1) : 0.0f;
+            if (i >= end) f.r = make_uint2(0u, 0u);
+            return f;
+        };
+        for (uint32_t ticket = take_ticket(); ticket < (uint32_t)GROUPS; ticket = take_ticket()) {
+            const int base = begin + (int)ticket * WAVE;
+            const Fetched cur = fetch(ticket);
+            const uint2 r = cur.r;
+            const int w = (int)(r.y & 0xffff) - (int)(r.x & 0xffff), h = (int)(r.y >> 16) - (int)(r.x >> 16);
+            const uint32_t area = (w > 0 && h > 0) ? (uint32_t)(w * h) : 0u;
             float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
-            if (vis && !((vis[(size_t)(base / WAVE) * vis_words + (blockIdx.y >> 5)] >> (blockIdx.y & 31)) & 1u)) continue;
-            if (i < end) {
-                const uint2 r = bv.rects[i];
-                const int w = (int)(r.y & 0xffff) - (int)(r.x & 0xffff), h = (int)(r.y >> 16) - (int)(r.x >> 16);
-                if (w > 0 && h > 0) {
-                    area = (uint32_t)(w * h);
-                    const float4 q0 = bv.splats[(size_t)i * 3], q1 = bv.splats[(size_t)i * 3 + 1];
-                    const CullSplat cs = make_cull_splat(make_float2(q0.x, q0.y), make_float4(q0.z, q0.w, q1.x, q1.y));
-                    s0 = make_float4(cs.mx, cs.my, cs.A, cs.B);
-                    s1 = make_float4(cs.C, cs.rBC, cs.rBA, cs.tau);
-                    s2 = make_float4(__uint_as_float(cs.flags | ((uint32_t)w << 2)), __uint_as_float(r.x), 1.0f / (float)w,
-                                     SCATTER ? bv.splats[(size_t)i * 3 + 2].y : 0.0f);
-                }
+            if (area) {
+                const CullSplat cs = make_cull_splat(make_float2(cur.q0.x, cur.q0.y), make_float4(cur.q0.z, cur.q0.w, cur.q1.x, cur.q1.y));
+                s0 = make_float4(cs.mx, cs.my, cs.A, cs.B);
+                s1 = make_float4(cs.C, cs.rBC, cs.rBA, cs.tau);
+                s2 = make_float4(__uint_as_float(cs.flags | ((uint32_t)w << 2)), __uint_as_float(r.x), 1.0f / (float)w, cur.depth);
             }
             stage[lane * 3 + 0] = s0; stage[lane * 3 + 1] = s1; stage[lane * 3 + 2] = s2;
             __builtin_amdgcn_wave_barrier();
@@ -173,11 +206,11 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restr
                 const uint32_t k = c - ((key >> 6) - 1u);
                 const float4 o2 = stage[g * 3 + 2];
                 const uint32_t fw = __float_as_uint(o2.x), rlo = __float_as_uint(o2.y);
-                const int w = (int)(fw >> 2);
+                const int ow = (int)(fw >> 2);
                 // ty = k / w: reciprocal estimate, then an exact +-1 correction
                 int ty = (int)(((float)k + 0.5f) * o2.z);
-                int tx = (int)k - ty * w;
-                if (tx < 0) { --ty; tx += w; } else if (tx >= w) { ++ty; tx -= w; }
+                int tx = (int)k - ty * ow;
+                if (tx < 0) { --ty; tx += ow; } else if (tx >= ow) { ++ty; tx -= ow; }
                 const int x = (int)(rlo & 0xffff) + tx, y = (int)(rlo >> 16) + ty;
                 const int t = y * grid_x + x - lo;
                 bool pass = c < total && (unsigned)t < (unsigned)span;
@@ -190,7 +223,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restr
                 }
                 if (pass) {
                     const uint32_t slot = atomicAdd(&lds[t], 1u);
-                    if (SCATTER) bv.bucket[slot] = make_uint2(__float_as_uint(o2.w), (uint32_t)(base + g));
+                    if (SCATTER) gstore(bv.bucket + slot, make_uint2(__float_as_uint(o2.w), (uint32_t)(base + g)));
                 }
             }
         }
@@ -198,7 +231,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restr
         if (!SCATTER) {
             for (int t = threadIdx.x; t < span; t += BIN_THREADS) {
                 const uint32_t cnt = lds[t];
-                bv.rel[(size_t)chunk * tiles + lo + t] = cnt ? atomicAdd(&bv.tile_count[lo + t], cnt) : 0u;
+                gstore(bv.rel + (size_t)chunk * tiles + lo + t, cnt ? gatomic_add(bv.tile_count + lo + t, cnt) : 0u);
             }
             __syncthreads();
         }
