@@ -111,7 +111,7 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
     const bool inside = px < W && py < H;
     const f32x2 pxf = {(float)px, (float)px}, pyf = {(float)py, (float)py};
 
-    const uint2 range = ve.ranges[tile];
+    const uint2 range = gload(ve.ranges + tile);
     const int n = (int)(range.y - range.x);
     const bool want_sem = FUSED;                  // (the kernel sends only quarters with object entries down this path)
 
@@ -147,18 +147,18 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
         have = false;
         const int i = base + lane;
         if (i < n) {
-            const uint32_t g = gauss_sorted[range.x + i];
+            const uint32_t g = gload(gauss_sorted + range.x + i);
             const bool is_obj = FUSED && i < n_sem && (int)g >= sem.n_env;
             if (alive != 0ull || is_obj) {
                 const float4* rec = splats + (size_t)g * 3;
-                const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+                const float4 q0 = gload(rec), q1 = gload(rec + 1), q2 = gload(rec + 2);
                 p = make_float2(q0.x, q0.y);
                 co = make_float4(q0.z, q0.w, q1.x, q1.y);
                 cd = make_float4(q1.z, q1.w, q2.x, q2.y);
                 have = true;
                 if (is_obj) {
-                    const float* col = sem.colors + 3 * (size_t)(sem.object_id[g] - 1);
-                    cs = make_float4(col[0], col[1], col[2], q2.y);      // .w = depth (> 0.2: doubles as "object entry")
+                    const float* col = sem.colors + 3 * (size_t)(gload(sem.object_id + g) - 1);
+                    cs = make_float4(gload(col), gload(col + 1), gload(col + 2), q2.y);      // .w = depth (> 0.2: doubles as "object entry")
                 }
             }
         }
@@ -313,24 +313,24 @@ finished:
     if (inside) {
         const size_t P = (size_t)W * H;
         const size_t pix = (size_t)py * W + px;
-        o.color[0 * P + pix] = fmaf(T, cam.bg[0], Crg.x);
-        o.color[1 * P + pix] = fmaf(T, cam.bg[1], Crg.y);
-        o.color[2 * P + pix] = fmaf(T, cam.bg[2], Cbd.x);
-        if (o.depth) o.depth[pix] = Cbd.y;
+        gstore(o.color + 0 * P + pix, fmaf(T, cam.bg[0], Crg.x));
+        gstore(o.color + 1 * P + pix, fmaf(T, cam.bg[1], Crg.y));
+        gstore(o.color + 2 * P + pix, fmaf(T, cam.bg[2], Cbd.x));
+        if (o.depth) gstore(o.depth + pix, Cbd.y);
         if (AUX) {
-            if (o.final_T) o.final_T[pix] = T;
-            if (o.n_contrib) o.n_contrib[pix] = last;
+            if (o.final_T) gstore(o.final_T + pix, T);
+            if (o.n_contrib) gstore(o.n_contrib + pix, last);
         }
         if (want_sem) {
-            ve.sem_color[0 * P + pix] = fmaf(Ts, cam.bg[0], Srg.x);
-            ve.sem_color[1 * P + pix] = fmaf(Ts, cam.bg[1], Srg.y);
-            ve.sem_color[2 * P + pix] = fmaf(Ts, cam.bg[2], Sbd.x);
-            if (ve.sem_depth) ve.sem_depth[pix] = Sbd.y;
+            gstore(ve.sem_color + 0 * P + pix, fmaf(Ts, cam.bg[0], Srg.x));
+            gstore(ve.sem_color + 1 * P + pix, fmaf(Ts, cam.bg[1], Srg.y));
+            gstore(ve.sem_color + 2 * P + pix, fmaf(Ts, cam.bg[2], Sbd.x));
+            if (ve.sem_depth) gstore(ve.sem_depth + pix, Sbd.y);
         } else if (sem_background) {             // no object entry in this tile: the objects-only image is the background
-            ve.sem_color[0 * P + pix] = cam.bg[0];       // (= fmaf(1, bg, 0) of the general form, bit for bit)
-            ve.sem_color[1 * P + pix] = cam.bg[1];
-            ve.sem_color[2 * P + pix] = cam.bg[2];
-            if (ve.sem_depth) ve.sem_depth[pix] = 0.0f;
+            gstore(ve.sem_color + 0 * P + pix, cam.bg[0]);       // (= fmaf(1, bg, 0) of the general form, bit for bit)
+            gstore(ve.sem_color + 1 * P + pix, cam.bg[1]);
+            gstore(ve.sem_color + 2 * P + pix, cam.bg[2]);
+            if (ve.sem_depth) gstore(ve.sem_depth + pix, 0.0f);
         }
     }
 }

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const BinView* __restri
 constexpr uint64_t KEY_INF = ~0ull;
 
 // low word of a sort key -> position; inv == NULL: they are the same
-__device__ __forceinline__ uint32_t key_to_pos(const uint32_t* __restrict__ inv, uint32_t tk) { return inv ? inv[tk] : tk; }
+__device__ __forceinline__ uint32_t key_to_pos(const uint32_t* __restrict__ inv, uint32_t tk) { return inv ? gload(inv + tk) : tk; }
 
 template <int E>
 __device__ __forceinline__ void register_sort(uint64_t (&r)[E]) {
@@ -348,7 +348,7 @@ __device__ __forceinline__ void mark_last_object(Get get, int n, int n_env, uint
         if ((int)get(i) >= n_env) best = pos_offset + (uint32_t)i + 1u;
 #pragma unroll
     for (int m = 1; m < WAVE; m <<= 1) best = max(best, (uint32_t)__shfl_xor((int)best, m));
-    if ((threadIdx.x & (WAVE - 1)) == 0 && best) atomicMax(obj_last, best);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && best) gatomic_max(obj_last, best);
 }
 
 // Sorts n <= THREADS*E keys of `bucket` (global, (depth,idx) pairs) into out[] (indices only).
@@ -367,8 +367,8 @@ __device__ __forceinline__ void merge_sort_tile(uint64_t* __restrict__ skeys, co
         const int i = e * THREADS + t;
         uint64_t k = KEY_INF;
         if (i < n) {
-            const uint2 v = bucket[i];
-            k = ((uint64_t)v.x << 32) | (tie ? (uint32_t)tie[v.y] : v.y);
+            const uint2 v = gload(bucket + i);
+            k = ((uint64_t)v.x << 32) | (tie ? (uint32_t)gload(tie + v.y) : v.y);
         }
         r[e] = k;
     }
@@ -406,9 +406,9 @@ __device__ __forceinline__ void merge_sort_tile(uint64_t* __restrict__ skeys, co
         __syncthreads();
     }
     if (keys_out) {
-        for (int i = t; i < n; i += THREADS) keys_out[i] = skeys[pad_idx<E>(i)];
+        for (int i = t; i < n; i += THREADS) gstore(keys_out + i, skeys[pad_idx<E>(i)]);
     } else {
-        for (int i = t; i < n; i += THREADS) out[i] = key_to_pos(inv, (uint32_t)skeys[pad_idx<E>(i)]);
+        for (int i = t; i < n; i += THREADS) gstore(out + i, key_to_pos(inv, (uint32_t)skeys[pad_idx<E>(i)]));
         if (n_env >= 0)
             mark_last_object<THREADS>([&](int i) { return key_to_pos(inv, (uint32_t)skeys[pad_idx<E>(i)]); }, n, n_env, obj_last,
                                       pos_offset);
@@ -477,7 +477,7 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
     {
         uint2 v[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) v[e] = bucket[min(e * THREADS + t, n - 1)];
+        for (int e = 0; e < E; ++e) v[e] = gload(bucket + min(e * THREADS + t, n - 1));
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const bool in = e * THREADS + t < n;
@@ -590,12 +590,12 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
                 if (tie && same > 1u) {
                     // exact depth tie between different Gaussians: the CALLER's index decides (a few keys per list;
                     // measured: cheaper than carrying the tie index in the bucket entries or in the LDS keys)
-                    const int32_t mine = tie[id[e]];
+                    const int32_t mine = gload(tie + id[e]);
                     rank = 0;
                     for (uint32_t j = s0; j < s0 + cnt; ++j) {
                         const uint64_t kj = s_keys[j];
                         const uint32_t dj = (uint32_t)(kj >> 32);
-                        rank += (dj < d[e] || (dj == d[e] && (uint32_t)kj != id[e] && tie[(uint32_t)kj] < mine)) ? 1u : 0u;
+                        rank += (dj < d[e] || (dj == d[e] && (uint32_t)kj != id[e] && gload(tie + (uint32_t)kj) < mine)) ? 1u : 0u;
                     }
                 }
             }
@@ -608,13 +608,13 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
 #pragma unroll
         for (int e = 0; e < E; ++e)
             if (e * THREADS + t < n) {
-                out[fin[e]] = id[e];
+                gstore(out + fin[e], id[e]);
                 if (n_env >= 0 && (int)id[e] >= n_env) best = max(best, pos_offset + fin[e] + 1u);
             }
         if (n_env >= 0) {
 #pragma unroll
             for (int m = 1; m < WAVE; m <<= 1) best = max(best, (uint32_t)__shfl_xor((int)best, m));
-            if (lane == 0 && best) atomicMax(obj_last, best);
+            if (lane == 0 && best) gatomic_max(obj_last, best);
         }
         SORT_STAMP(7);  // direct output
         SORT_FLUSH();
@@ -626,7 +626,7 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
     for (int e = 0; e < E; ++e)
         if (e * THREADS + t < n) s_idx[fin[e]] = id[e];
     __syncthreads();
-    for (int i = t; i < n; i += THREADS) out[i] = s_idx[i];
+    for (int i = t; i < n; i += THREADS) gstore(out + i, s_idx[i]);
     SORT_STAMP(7);      // index image + output
     if (n_env >= 0) mark_last_object<THREADS>([&](int i) { return s_idx[i]; }, n, n_env, obj_last, pos_offset);
     SORT_STAMP(8);      // last object marker
@@ -659,7 +659,7 @@ __device__ __forceinline__ bool partition_sort_long(unsigned char* __restrict__ 
     const int t = threadIdx.x, lane = t & (WAVE - 1), wave = t / WAVE;
     if ((n + HALF - 1) / HALF > PART_MAX_SEGMENTS) return false;
     uint32_t dmin = 0xffffffffu, dmax = 0u;
-    for (int i = t; i < n; i += THREADS) { const uint32_t d = bucket[i].x; dmin = min(dmin, d); dmax = max(dmax, d); }
+    for (int i = t; i < n; i += THREADS) { const uint32_t d = gload(bucket + i).x; dmin = min(dmin, d); dmax = max(dmax, d); }
     for (int i = t; i < PART_BUCKETS; i += THREADS) s_hist[i] = 0u;
     if (t < 4 + WAVES) s_misc[t] = t == 0 ? 0xffffffffu : 0u;
     if (t < PART_MAX_SEGMENTS + 2) s_cut[t] = (uint32_t)n;      // segment g starts at s_cut[g]; n = not opened
@@ -674,7 +674,7 @@ __device__ __forceinline__ bool partition_sort_long(unsigned char* __restrict__ 
     const uint32_t mn = s_misc[0];
     const float scale = (float)PART_BUCKETS / ((float)(s_misc[1] - mn) + 1.0f);
     auto coarse = [&](uint32_t d) { return min((uint32_t)((float)(d - mn) * scale), (uint32_t)(PART_BUCKETS - 1)); };
-    for (int i = t; i < n; i += THREADS) atomicAdd(&s_hist[coarse(bucket[i].x)], 1u);
+    for (int i = t; i < n; i += THREADS) atomicAdd(&s_hist[coarse(gload(bucket + i).x)], 1u);
     __syncthreads();
     const int wbase = wave * (WAVE * CH);
     uint32_t tot = 0, big = 0;
@@ -712,8 +712,8 @@ __device__ __forceinline__ bool partition_sort_long(unsigned char* __restrict__ 
     __syncthreads();
     // counting-sort scatter through the alt buffer (the starts become the cursors)
     for (int i = t; i < n; i += THREADS) {
-        const uint2 v = bucket[i];
-        alt[atomicAdd(&s_hist[coarse(v.x)], 1u)] = v;
+        const uint2 v = gload(bucket + i);
+        gstore(alt + atomicAdd(&s_hist[coarse(v.x)], 1u), v);
     }
     __threadfence_block();
     __syncthreads();
