@@ -17,6 +17,9 @@ for line in open(sys.argv[1]):
     if m:
         kernel = m.group(1)
         continue
+    if "dispatches=" in line:        # some other kernel's block: its counters are not ours
+        kernel = None
+        continue
     m = re.match(r"\s+(\w+)\s+\d+\s+per-dispatch\s+(\d+)", line)
     if m and kernel:
         acc[kernel][m.group(1)] = float(m.group(2))
