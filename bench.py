@@ -54,7 +54,8 @@ def parse():
                     help="dynamic sequence: every frame is a TIME STEP with its own object poses (posed inside the "
                          "preprocess) and one camera, plus its BOP pose records")
     ap.add_argument("--raster-only", action="store_true", help="time only the full-scene RGB+depth pass (R), no masks")
-    ap.add_argument("--slots", type=int, default=3, help="batches in flight (pipeline slots: streams, workspaces, frame sets)")
+    ap.add_argument("--slots", type=int, default=3, help="batches in flight (pipeline slots: workspaces, frame sets)")
+    ap.add_argument("--streams", type=int, default=0, help="streams the slots share round-robin (0 = one per slot)")
     ap.add_argument("--step-log", action="store_true", help="per-step (enqueue, wait) host milliseconds on stderr")
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: also gather every batch's finished frames to rank 0 inside the timed region, in the "
@@ -126,6 +127,7 @@ def main():
     fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"],
                          cloud.object_id, sh_degree=3, device=dev, spatial_order=not args.input_order)
     fr.serialize_slots = args.serialize_slots
+    fr.n_streams = args.streams or None
     specs = [fr.view_spec(v) for v in my_views]
     W, H = my_views[0].width, my_views[0].height
     P = W * H

@@ -119,9 +119,13 @@ class FrameRenderer:
         cur = torch.cuda.current_stream(dev)
         if not hasattr(self, "_slot_streams"):
             self._slot_streams = {}
-        st = self._slot_streams.get(slot)
+        # `slot` selects the workspace (and the caller's frame set); slots share `n_streams` streams round-robin when that
+        # is set: two batches queued behind each other on a stream keep it from draining when one of them completes
+        n_streams = getattr(self, "n_streams", None)
+        skey = slot if not n_streams else slot % int(n_streams)
+        st = self._slot_streams.get(skey)
         if st is None:
-            st = self._slot_streams[slot] = torch.cuda.Stream(dev)
+            st = self._slot_streams[skey] = torch.cuda.Stream(dev)
         fused = masks and self.K > 0
         outs = [dict(color=frames["color"][i], depth=frames["depth"][i], radii=None) for i in range(B)]
         if fused:
