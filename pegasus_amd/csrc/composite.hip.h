@@ -26,7 +26,7 @@ struct alignas(16) ViewEntry {
     const CameraDev* cam;
     const uint2* ranges;
     const uint32_t* gauss_sorted;
-    const float4* splats;        // [n, 3] records: q0 = (x,y,A,B), q1 = (C,op,r,g), q2 = (b,depth,..)
+    const float4* splats;        // [n, 3] records: q0 = (x,y,A,B), q1 = (C,op,r,g), q2 = (b,depth,B/C,B/A)
     CompOut out;
     const uint32_t* counters;    // [1] != 0: instance overflow, the view must not be composited
     float* sem_color;            // fused semantic pass: [3,H,W] objects-only image in semantic colours (or NULL)
@@ -136,11 +136,12 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
     bool pure = FUSED && n_sem > 0;
 
     // register-staged gather of one batch: this lane's entry
-    float2 p;
+    float2 p, rr;        // rr = (B/C, B/A) of the record: the skip test's cull record needs no division
     float4 co, cd, cs;
     bool have;            // the record was gathered (entries nobody needs any more are not)
     auto gather = [&](int base) {
         p = make_float2(0.f, 0.f);
+        rr = make_float2(0.f, 0.f);
         co = make_float4(0.f, 0.f, 0.f, 0.f);
         cd = make_float4(0.f, 0.f, 0.f, 0.f);
         cs = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -155,6 +156,7 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
                 p = make_float2(q0.x, q0.y);
                 co = make_float4(q0.z, q0.w, q1.x, q1.y);
                 cd = make_float4(q1.z, q1.w, q2.x, q2.y);
+                rr = make_float2(q2.z, q2.w);
                 have = true;
                 if (is_obj) {
                     const float* col = sem.colors + 3 * (size_t)(gload(sem.object_id + g) - 1);
@@ -183,7 +185,7 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
         const float bx1 = fminf(rx0 + (float)ax1, rx1), by1 = fminf(ry0 + (float)ay1, ry1);
         // with the scene pixels saturated only object entries are still of interest
         const bool live = have && (alive != 0ull || cs.w != 0.0f) &&
-                          rect_may_contribute(make_cull_splat(p, co), bx0, by0, bx1, by1);
+                          rect_may_contribute(make_cull_splat(p, co, rr.x, rr.y), bx0, by0, bx1, by1);
         const unsigned long long mask = __ballot(live);
         const int cnt = __popcll(mask);
         const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),

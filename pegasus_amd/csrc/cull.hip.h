@@ -25,19 +25,26 @@ __device__ __forceinline__ float edge_min_q(float A, float B, float C, float r, 
 
 struct CullSplat { float mx, my, A, B, C, rBC, rBA, tau; uint32_t flags; };   // flags: 1 = never, 2 = always
 
-__device__ __forceinline__ CullSplat make_cull_splat(float2 xy, float4 co) {
+// rBC = B / C and rBA = B / A are computed once per Gaussian and view by the preprocess (IEEE divisions, the same
+// expressions as here) and ride in the record's last two floats: the binning walks and every quarter-tile walk of the
+// compositor rebuild this record per use.
+__device__ __forceinline__ CullSplat make_cull_splat(float2 xy, float4 co, float rBC, float rBA) {
     CullSplat s;
     s.mx = xy.x; s.my = xy.y; s.A = co.x; s.B = co.y; s.C = co.z;
     s.flags = (co.w < ALPHA_MIN ? 1u : 0u)                      // alpha <= op < 1/255 at every pixel, exactly
             | ((!(co.x > 0.0f) || !(co.z > 0.0f)) ? 2u : 0u);   // degenerate conic: no claim
-    s.rBC = co.y / co.z;
-    s.rBA = co.y / co.x;
+    s.rBC = rBC;
+    s.rBA = rBA;
     const float t = 255.0f * co.w;
     const uint32_t bits = __float_as_uint(t);
     const float e = (float)((int)((bits >> 23) & 0xffu) - 127);
     const float m = __uint_as_float((bits & 0x007fffffu) | 0x3f800000u);
     s.tau = 1.3862944f * (e + (m - 1.0f) + 0.0861f);
     return s;
+}
+
+__device__ __forceinline__ CullSplat make_cull_splat(float2 xy, float4 co) {
+    return make_cull_splat(xy, co, co.y / co.z, co.y / co.x);
 }
 
 // rectangle of pixel CENTRES [x0,x1] x [y0,y1] (inclusive)

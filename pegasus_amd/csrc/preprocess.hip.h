@@ -150,7 +150,7 @@ __device__ __forceinline__ uint2 candidate_rect(const TileRect& r, float mx, flo
 
 // Per-Gaussian, per-view record the later stages gather: ONE 48-byte row instead of four arrays, so a gather
 // touches 1-2 64-byte sectors instead of 3-4 (PMC: the compositor fetched 2.3x its algorithmic bytes with the
-// split layout).  q0 = (x, y, A, B), q1 = (C, opacity, r, g), q2 = (b, depth, 0, 0).
+// split layout).  q0 = (x, y, A, B), q1 = (C, opacity, r, g), q2 = (b, depth, B/C, B/A).
 constexpr int SPLAT_F4 = 3;
 
 struct PreOut {
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                     float4* rec = out_splats + (size_t)i * SPLAT_F4;
                     rec[0] = make_float4(pix_x, pix_y, con_x, con_y);
                     rec[1] = make_float4(con_z, op, rgb.x, rgb.y);
-                    rec[2] = make_float4(rgb.z, tz, 0.0f, 0.0f);
+                    rec[2] = make_float4(rgb.z, tz, con_y / con_z, con_y / con_x);     // + the cull record's B/C, B/A (cull.hip.h)
                 }
             }
         }
