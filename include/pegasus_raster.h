@@ -102,7 +102,7 @@ typedef struct PgrSemantic {
 
 /* Device pointers into one view's slice of a workspace, for stage-level parity tests and for backward. */
 typedef struct PgrWorkspaceView {
-    const float *splats;         /* [n,12] per-Gaussian record: x, y, conic A, B, C, opacity, r, g, b, depth, B/C, B/A
+    const float *splats;         /* [n,12] per-Gaussian record: x, y, conic A, B, C, opacity, B/C, B/A, r, g, b, depth
                                     (defined only for Gaussians with a non-empty rectangle) */
     const uint16_t *rects;       /* [n,4] tile rectangle minx,miny,maxx,maxy (max exclusive); zeros = culled.
                                     Written only for views rendered WITH a radii output. */

@@ -86,8 +86,8 @@ __global__ __launch_bounds__(WAVE) void composite_backward_wave_kernel(
             const uint32_t idx = (uint32_t)(base + j);
             const float4 q0 = s_q0[j], q1 = s_q1[j], q2 = s_q2[j];
             const float A = q0.z, B = q0.w, Cc = q1.x, op = q1.y;
-            const float col[3] = {q1.z, q1.w, q2.x};
-            const float z = q2.y;
+            const float col[3] = {q2.x, q2.y, q2.z};
+            const float z = q2.w;
             float acc[10];
 #pragma unroll
             for (int k = 0; k < 10; ++k) acc[k] = 0.0f;

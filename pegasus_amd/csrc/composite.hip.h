@@ -26,7 +26,7 @@ struct alignas(16) ViewEntry {
     const CameraDev* cam;
     const uint2* ranges;
     const uint32_t* gauss_sorted;
-    const float4* splats;        // [n, 3] records: q0 = (x,y,A,B), q1 = (C,op,r,g), q2 = (b,depth,B/C,B/A)
+    const float4* splats;        // [n, 3] records: q0 = (x,y,A,B), q1 = (C,op,B/C,B/A), q2 = (r,g,b,depth)
     CompOut out;
     const uint32_t* counters;    // [1] != 0: instance overflow, the view must not be composited
     float* sem_color;            // fused semantic pass: [3,H,W] objects-only image in semantic colours (or NULL)
@@ -135,37 +135,35 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
     // 1.23 to 0.9 ms per 32 views.
     bool pure = FUSED && n_sem > 0;
 
-    // register-staged gather of one batch: this lane's entry
-    float2 p, rr;        // rr = (B/C, B/A) of the record: the skip test's cull record needs no division
-    float4 co, cd, cs;
-    bool have;            // the record was gathered (entries nobody needs any more are not)
-    auto gather = [&](int base) {
-        p = make_float2(0.f, 0.f);
-        rr = make_float2(0.f, 0.f);
-        co = make_float4(0.f, 0.f, 0.f, 0.f);
-        cd = make_float4(0.f, 0.f, 0.f, 0.f);
-        cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Register-staged gather, software-pipelined over the batches: this lane's record for the CURRENT batch was requested
+    // during the previous batch's pair loop, and the list index of the NEXT batch's entry right behind it -- an index ->
+    // record chain issued in one go costs the wave two exposed memory round trips per batch (the record's address needs
+    // the index).  The record's quads are used as they were loaded: q2 = (r, g, b, depth) IS the colour image of the
+    // entry, so nothing has to be shuffled into place behind the loads (a shuffle there drags the s_waitcnt with it,
+    // in front of the pair loop: the first layout, q1 = (C, op, r, g), q2 = (b, depth, ..), did exactly that).
+    f32x4_t q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0;
+    int32_t oid = 0;      // FUSED: the entry's object id (0 = not an object entry of interest)
+    bool have = false;    // the record was gathered (entries nobody needs any more are not)
+    auto fetch_index = [&](int base) {
+        const int i = base + lane;
+        return i < n ? gload(gauss_sorted + range.x + i) : 0u;
+    };
+    auto fetch_record = [&](int base, uint32_t g) {
         have = false;
+        oid = 0;
         const int i = base + lane;
         if (i < n) {
-            const uint32_t g = gload(gauss_sorted + range.x + i);
             const bool is_obj = FUSED && i < n_sem && (int)g >= sem.n_env;
             if (alive != 0ull || is_obj) {
                 const float4* rec = splats + (size_t)g * 3;
-                const float4 q0 = gload(rec), q1 = gload(rec + 1), q2 = gload(rec + 2);
-                p = make_float2(q0.x, q0.y);
-                co = make_float4(q0.z, q0.w, q1.x, q1.y);
-                cd = make_float4(q1.z, q1.w, q2.x, q2.y);
-                rr = make_float2(q2.z, q2.w);
+                q0 = gload_quad(rec); q1 = gload_quad(rec + 1); q2 = gload_quad(rec + 2);
                 have = true;
-                if (is_obj) {
-                    const float* col = sem.colors + 3 * (size_t)(gload(sem.object_id + g) - 1);
-                    cs = make_float4(gload(col), gload(col + 1), gload(col + 2), q2.y);      // .w = depth (> 0.2: doubles as "object entry")
-                }
+                if (is_obj) oid = gload(sem.object_id + g);
             }
         }
     };
-    gather(0);
+    fetch_record(0, fetch_index(0));
+    uint32_t g_next = fetch_index(WAVE_BATCH);
     const float rx0 = (float)qx0, ry0 = (float)qy0;
     const float rx1 = fminf(rx0 + 7.0f, (float)(W - 1)), ry1 = fminf(ry0 + 7.0f, (float)(H - 1));
 
@@ -184,8 +182,18 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
         const float bx0 = rx0 + (float)ax0, by0 = ry0 + (float)ay0;
         const float bx1 = fminf(rx0 + (float)ax1, rx1), by1 = fminf(ry0 + (float)ay1, ry1);
         // with the scene pixels saturated only object entries are still of interest
+        // the quads are taken as they arrive, HERE: without this the compiler forms the packed operands of the staging
+        // arithmetic right behind the loads, in the previous iteration, and waits for the loads there
+        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(oid));
+        const float2 p = make_float2(q0.x, q0.y);
+        const float4 co = make_float4(q0.z, q0.w, q1.x, q1.y);
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (FUSED && oid > 0) {
+            const float* col = sem.colors + 3 * (size_t)(oid - 1);
+            cs = make_float4(gload(col), gload(col + 1), gload(col + 2), q2.w);      // .w = depth (> 0.2: doubles as "object entry")
+        }
         const bool live = have && (alive != 0ull || cs.w != 0.0f) &&
-                          rect_may_contribute(make_cull_splat(p, co, rr.x, rr.y), bx0, by0, bx1, by1);
+                          rect_may_contribute(make_cull_splat(p, co, q1.z, q1.w), bx0, by0, bx1, by1);
         const unsigned long long mask = __ballot(live);
         const int cnt = __popcll(mask);
         const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
@@ -198,7 +206,7 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
             gq[0] = p.x;  gq[2] = p.y;
             gq[4] = -0.5f * co.x;  gq[6] = -co.y;
             gq[8] = -0.5f * co.z;  gq[10] = co.w;
-            s_c[pos] = cd;
+            s_c[pos] = make_float4(q2.x, q2.y, q2.z, q2.w);
             if (FUSED) s_s[pos] = cs;
             if (AUX) s_i[pos] = (uint32_t)(base + lane + 1);
         }
@@ -213,7 +221,8 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
         // which of the parked entries are objects': one bit per compacted position, kept in an SGPR pair
         unsigned long long objbits = 0ull;
         if (FUSED && sem_alive != 0ull) objbits = __builtin_amdgcn_ballot_w64(lane < cnt && s_s[lane].w != 0.0f);
-        gather(base + WAVE_BATCH);                // lands while this batch is composited
+        fetch_record(base + WAVE_BATCH, g_next);  // lands while this batch is composited (its index: requested a batch ago)
+        g_next = fetch_index(base + 2 * WAVE_BATCH);
         const int pairs = __builtin_amdgcn_readfirstlane((cnt + 1) >> 1);
         // PAIR_UNROLL pairs per trip.  The LDS byte offsets of the trip live in VGPRs the compiler cannot see through
         // (it would otherwise keep them on the scalar unit and pay a v_mov per ds_read: 3-4 of the ~36 VALU instructions

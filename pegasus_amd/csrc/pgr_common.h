@@ -32,6 +32,7 @@ __device__ __forceinline__ uint2 gload(const uint2* p) { const u32x2_t v = *(con
 __device__ __forceinline__ uint4 gload(const uint4* p) { const u32x4_t v = *(const PGR_GLOBAL u32x4_t*)p; return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ float2 gload(const float2* p) { const f32x2_t v = *(const PGR_GLOBAL f32x2_t*)p; return make_float2(v.x, v.y); }
 __device__ __forceinline__ float4 gload(const float4* p) { const f32x4_t v = *(const PGR_GLOBAL f32x4_t*)p; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ f32x4_t gload_quad(const float4* p) { return *(const PGR_GLOBAL f32x4_t*)p; }   // as one register tuple
 __device__ __forceinline__ void gstore(uint32_t* p, uint32_t v) { *(PGR_GLOBAL uint32_t*)p = v; }
 __device__ __forceinline__ void gstore(float* p, float v) { *(PGR_GLOBAL float*)p = v; }
 __device__ __forceinline__ void gstore(uint64_t* p, uint64_t v) { *(PGR_GLOBAL uint64_t*)p = v; }

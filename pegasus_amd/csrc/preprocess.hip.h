@@ -150,7 +150,8 @@ __device__ __forceinline__ uint2 candidate_rect(const TileRect& r, float mx, flo
 
 // Per-Gaussian, per-view record the later stages gather: ONE 48-byte row instead of four arrays, so a gather
 // touches 1-2 64-byte sectors instead of 3-4 (PMC: the compositor fetched 2.3x its algorithmic bytes with the
-// split layout).  q0 = (x, y, A, B), q1 = (C, opacity, r, g), q2 = (b, depth, B/C, B/A).
+// split layout).  q0 = (x, y, A, B), q1 = (C, opacity, B/C, B/A), q2 = (r, g, b, depth): the
+// binning walks need q0 and q1 only, the compositor parks q2 as it is.
 constexpr int SPLAT_F4 = 3;
 
 struct PreOut {
@@ -383,8 +384,8 @@ __global__ __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                     crect = candidate_rect(r, pix_x, pix_y, c_xx, c_yy, con_x, con_y, con_z, op, rad);
                     float4* rec = out_splats + (size_t)i * SPLAT_F4;
                     rec[0] = make_float4(pix_x, pix_y, con_x, con_y);
-                    rec[1] = make_float4(con_z, op, rgb.x, rgb.y);
-                    rec[2] = make_float4(rgb.z, tz, con_y / con_z, con_y / con_x);     // + the cull record's B/C, B/A (cull.hip.h)
+                    rec[1] = make_float4(con_z, op, con_y / con_z, con_y / con_x);     // + the cull record's B/C, B/A (cull.hip.h)
+                    rec[2] = make_float4(rgb.x, rgb.y, rgb.z, tz);
                 }
             }
         }

@@ -38,7 +38,7 @@ __device__ __forceinline__ uint2 pack_rect(int minx, int miny, int maxx, int max
 
 struct BinView {                 // per-view pointers used by the binning kernels (device table)
     const uint2* rects;          // [n] packed CANDIDATE tile rectangles (preprocess.hip.h candidate_rect)
-    const float4* splats;        // [n, 3] records (preprocess.hip.h): q0 = (x,y,A,B), q1 = (C,op,r,g), q2 = (b,depth,B/C,B/A)
+    const float4* splats;        // [n, 3] records (preprocess.hip.h): q0 = (x,y,A,B), q1 = (C,op,B/C,B/A), q2 = (r,g,b,depth)
     uint32_t* tile_count;        // [tiles] zero-filled before bin_count
     uint32_t* rel;               // [chunks, tiles]
     uint2* ranges;               // [tiles]
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restr
                 if (ticket >= (uint32_t)GROUPS || ((vis_bits >> ticket) & 1ull)) return ticket;
             }
         };
-        struct Fetched { uint2 r; float4 q0, q1, q2; };
+        struct Fetched { uint2 r; float4 q0, q1; float depth; };
         auto fetch = [&](uint32_t ticket) {
             Fetched f;
             const int i = begin + (int)ticket * WAVE + lane;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restr
             f.r = gload(bv.rects + ic);
             f.q0 = gload(bv.splats + (size_t)ic * 3);
             f.q1 = gload(bv.splats + (size_t)ic * 3 + 1);
-            f.q2 = gload(bv.splats + (size_t)ic * 3 + 2);
+            f.depth = SCATTER ? gload(reinterpret_cast<const float*>(bv.splats + (size_t)ic * 3 + 2) + 3) : 0.0f;
             if (i >= end) f.r = make_uint2(0u, 0u);
             return f;
         };
@@ -182,10 +182,10 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restr
             float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
             if (area) {
                 const CullSplat cs = make_cull_splat(make_float2(cur.q0.x, cur.q0.y), make_float4(cur.q0.z, cur.q0.w, cur.q1.x, cur.q1.y),
-                                                     cur.q2.z, cur.q2.w);
+                                                     cur.q1.z, cur.q1.w);
                 s0 = make_float4(cs.mx, cs.my, cs.A, cs.B);
                 s1 = make_float4(cs.C, cs.rBC, cs.rBA, cs.tau);
-                s2 = make_float4(__uint_as_float(cs.flags | ((uint32_t)w << 2)), __uint_as_float(r.x), 1.0f / (float)w, SCATTER ? cur.q2.y : 0.0f);
+                s2 = make_float4(__uint_as_float(cs.flags | ((uint32_t)w << 2)), __uint_as_float(r.x), 1.0f / (float)w, cur.depth);
             }
             stage[lane * 3 + 0] = s0; stage[lane * 3 + 1] = s1; stage[lane * 3 + 2] = s2;
             __builtin_amdgcn_wave_barrier();

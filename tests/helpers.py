@@ -55,8 +55,8 @@ def fetch_workspace(view_index, n, width, height):
     rec = grab(v["splats"], 12 * n, np.float32).reshape(n, 12)
     r["xy"] = np.ascontiguousarray(rec[:, 0:2])
     r["conic_opacity"] = np.ascontiguousarray(rec[:, 2:6])
-    r["rgb4"] = np.ascontiguousarray(rec[:, 6:10])
-    r["depth"] = np.ascontiguousarray(rec[:, 9])
+    r["rgb4"] = np.ascontiguousarray(rec[:, 8:12])        # record: x, y, A, B, C, opacity, B/C, B/A, r, g, b, depth
+    r["depth"] = np.ascontiguousarray(rec[:, 11])
     rects = grab(v["rects"], 4 * n, np.uint16).reshape(n, 4).astype(np.int32)
     r["rects"] = rects
     r["tiles_touched"] = (rects[:, 2] - rects[:, 0]) * (rects[:, 3] - rects[:, 1])
