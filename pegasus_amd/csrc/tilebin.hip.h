@@ -798,6 +798,9 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* 
     }
 }
 
+#ifndef PGR_T1_WAVES
+#define PGR_T1_WAVES 6      // the 512-thread tier: three workgroups per CU (48 KiB of LDS each) need six waves per SIMD
+#endif
 // Lists longer than 2048: workgroups stride over the queue of their tier.  One launch per tier (THREADS, E):
 //   (512, 8)    2049..4096 keys, 48 KiB of LDS: three workgroups per CU;
 //   (1024, 8)   4097..8192 keys, one bucket per key (96 KiB image): one per CU;
@@ -807,7 +810,7 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* 
 // A kernel per tier keeps each one's register budget its own: with the open-ended tier's code in the same kernel the
 // 4097..8192 path (a quarter of C3's keys) ran out of the 128 VGPRs a 1024-thread workgroup gets and spilled.
 template <int THREADS, int E, bool LAST>
-__global__ __launch_bounds__(THREADS) void tile_sort_long_kernel(const BinView* __restrict__ views, int tiles,
+__global__ __launch_bounds__(THREADS, (THREADS == 512 ? PGR_T1_WAVES : 4)) void tile_sort_long_kernel(const BinView* __restrict__ views, int tiles,
                                                                  const uint4* __restrict__ queue,
                                                                  const uint32_t* __restrict__ n_queue) {
     constexpr int CAP = THREADS * E;
