@@ -27,7 +27,10 @@
 namespace pgr {
 
 constexpr int BIN_CHUNK = 4096;        // Gaussians per binning workgroup
-constexpr int BIN_THREADS = 1024;
+#ifndef PGR_BIN_THREADS
+#define PGR_BIN_THREADS 512     // 8 waves share a chunk's 64 groups by ticket; 37 KiB of LDS at 2500 tiles = four per CU
+#endif                           // (measured: 1024 threads +5 % in the count walk, 768 and 256 +8..10 %)
+constexpr int BIN_THREADS = PGR_BIN_THREADS;
 constexpr int BIN_LDS_TILES = 16384;   // tiles histogrammed per LDS pass (64 KiB)
 constexpr int SORT_THREADS = 256;
 
