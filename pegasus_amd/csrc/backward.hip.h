@@ -3,10 +3,10 @@
 // of alpha is not differentiated, the screen-space mean gradient is NDC-scaled (pixel gradient * W/2, H/2),
 // colours clamped at 0 and clamped view-space coordinates pass no gradient.
 //
-//   composite_backward_wave_kernel  one wave per half tile (the forward's mapping: 2 pixels per lane).  The
+//   composite_backward_quarter_kernel  one wave per quarter tile (the forward's work unit: 1 pixel per lane).  The
 //       tile's list is walked BACK to front from the deepest contributor of any pixel of the wave; for every
-//       entry the 10 per-Gaussian partial gradients are summed over the wave's 128 pixels with a DPP
-//       reduction and land with ONE float atomic per component per (half tile, entry) -- 128x fewer atomics
+//       entry that can reach the quarter the 10 per-Gaussian partial gradients are summed over the wave's 64 pixels
+//       with a DPP reduction and land with ONE float atomic per component per (quarter, entry) -- 64x fewer atomics
 //       than one per pixel (scattered global atomics run at ~9 G/s on MI355X).
 //   preprocess_backward_kernel      one thread per Gaussian: conic -> cov2D -> (cov3D, view-space mean) ->
 //       scale / rotation; projection; SH -> coefficients and view direction.
@@ -32,107 +32,140 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(WAVE) void composite_backward_wave_kernel(
+// One wave per 8x8 quarter tile, one pixel per lane -- the forward compositor's work unit, and its per-quarter skip
+// test: an entry that cannot reach alpha >= 1/255 anywhere in the quarter was blended by none of its pixels and gets no
+// gradient from them, so only the entries that pass are parked (ballot-compacted, list order kept) and walked, BACK to
+// front, from the deepest contributor of any pixel of the quarter.  (Round 1 walked every entry of a 16x8 half tile
+// with two pixels per lane: 5 000 waves for a whole view, each evaluating ~1 000 entries twice; the quarter form has
+// 10 000 waves that evaluate the ~43 % of their entries the skip test leaves: composite backward 1.97 -> see DESIGN.)
+// The next batch's records are requested before the current one is walked (composite.hip.h's gather).
+__global__ __launch_bounds__(WAVE) void composite_backward_quarter_kernel(
     const CameraDev* __restrict__ camp, const uint2* __restrict__ ranges, const uint32_t* __restrict__ gauss_sorted,
     const float4* __restrict__ splats, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ g_color, const float* __restrict__ g_depth, float* __restrict__ g_rows) {
     const CameraDev& cam = *camp;
     const int W = cam.width, H = cam.height;
-    const int tile = (int)(blockIdx.x >> 1), half = (int)(blockIdx.x & 1);
+    const int tile = (int)(blockIdx.x >> 2), quarter = (int)(blockIdx.x & 3);
     const int tile_x = tile % cam.grid_x, tile_y = tile / cam.grid_x;
     const int lane = threadIdx.x;
-    const int px = tile_x * TILE + (lane & (TILE - 1));
-    const int py[2] = {tile_y * TILE + half * HALF_ROWS + (lane >> 4), tile_y * TILE + half * HALF_ROWS + (lane >> 4) + 4};
+    const int qx0 = tile_x * TILE + (quarter & 1) * 8, qy0 = tile_y * TILE + (quarter >> 1) * 8;
+    if (qx0 >= W || qy0 >= H) return;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = px < W && py < H;
     const size_t P = (size_t)W * H;
+    const size_t pix = inside ? (size_t)py * W + px : 0;
     const uint2 range = ranges[tile];
 
-    float T[2], S[2][3], SD[2], gC[2][3], gD[2];
-    uint32_t last[2];
+    const uint32_t last = inside ? n_contrib[pix] : 0u;
+    float T = inside ? final_T[pix] : 0.0f;
+    float S[3], gC[3];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const bool inside = px < W && py[k] < H;
-        const size_t pix = inside ? (size_t)py[k] * W + px : 0;
-        last[k] = inside ? n_contrib[pix] : 0u;
-        T[k] = inside ? final_T[pix] : 0.0f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            gC[k][c] = inside ? g_color[c * P + pix] : 0.0f;
-            S[k][c] = T[k] * cam.bg[c];
-        }
-        gD[k] = (inside && g_depth) ? g_depth[pix] : 0.0f;
-        SD[k] = 0.0f;
+    for (int c = 0; c < 3; ++c) {
+        gC[c] = inside ? g_color[c * P + pix] : 0.0f;
+        S[c] = T * cam.bg[c];
     }
-    // deepest contributor of any pixel of the wave
-    uint32_t n_used = max(last[0], last[1]);
+    const float gD = (inside && g_depth) ? g_depth[pix] : 0.0f;
+    float SD = 0.0f;
+    // deepest contributor of any pixel of the quarter
+    uint32_t n_used = last;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) n_used = max(n_used, (uint32_t)__shfl_xor((int)n_used, d, WAVE));
+    n_used = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_used);
     if (n_used == 0) return;
 
     __shared__ float4 s_q0[WAVE_BATCH], s_q1[WAVE_BATCH], s_q2[WAVE_BATCH];
-    __shared__ uint32_t s_g[WAVE_BATCH];
-    const float pxf = (float)px;
+    __shared__ uint2 s_gi[WAVE_BATCH];           // (Gaussian, list position)
+    const float pxf = (float)px, pyf = (float)py;
+    const float rx0 = (float)qx0, ry0 = (float)qy0;
+    const float rx1 = fminf(rx0 + 7.0f, (float)(W - 1)), ry1 = fminf(ry0 + 7.0f, (float)(H - 1));
 
-    for (int base = (int)((n_used - 1) / WAVE_BATCH) * WAVE_BATCH; base >= 0; base -= WAVE_BATCH) {
-        __syncthreads();
-        if (base + lane < (int)n_used) {
-            const uint32_t g = gauss_sorted[range.x + base + lane];
+    f32x4_t q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0;
+    uint32_t g_cur = 0, g_next = 0;
+    auto fetch_index = [&](int base) {
+        const int i = base + lane;
+        return (base >= 0 && i < (int)n_used) ? gload(gauss_sorted + range.x + i) : 0u;
+    };
+    auto fetch_record = [&](int base, uint32_t g) {
+        g_cur = g;
+        if (base >= 0 && base + lane < (int)n_used) {
             const float4* rec = splats + (size_t)g * 3;
-            s_q0[lane] = rec[0]; s_q1[lane] = rec[1]; s_q2[lane] = rec[2];
-            s_g[lane] = g;
+            q0 = gload_quad(rec); q1 = gload_quad(rec + 1); q2 = gload_quad(rec + 2);
+        }
+    };
+    const int first = (int)((n_used - 1) / WAVE_BATCH) * WAVE_BATCH;
+    fetch_record(first, fetch_index(first));
+    g_next = fetch_index(first - WAVE_BATCH);
+
+    for (int base = first; base >= 0; base -= WAVE_BATCH) {
+        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(g_cur));      // the quads are taken as they arrive, here
+        const bool have = base + lane < (int)n_used;
+        const float2 p = make_float2(q0.x, q0.y);
+        const float4 co = make_float4(q0.z, q0.w, q1.x, q1.y);
+        const bool live = have && rect_may_contribute(make_cull_splat(p, co, q1.z, q1.w), rx0, ry0, rx1, ry1);
+        const unsigned long long mask = __ballot(live);
+        const int cnt = __popcll(mask);
+        if (live) {
+            const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            s_q0[pos] = make_float4(q0.x, q0.y, q0.z, q0.w);
+            s_q1[pos] = make_float4(q1.x, q1.y, q1.z, q1.w);
+            s_q2[pos] = make_float4(q2.x, q2.y, q2.z, q2.w);
+            s_gi[pos] = make_uint2(g_cur, (uint32_t)(base + lane));
         }
         __syncthreads();
-        const int top = min(WAVE_BATCH, (int)n_used - base) - 1;
-        for (int j = top; j >= 0; --j) {
-            const uint32_t idx = (uint32_t)(base + j);
-            const float4 q0 = s_q0[j], q1 = s_q1[j], q2 = s_q2[j];
-            const float A = q0.z, B = q0.w, Cc = q1.x, op = q1.y;
-            const float col[3] = {q2.x, q2.y, q2.z};
-            const float z = q2.w;
+        fetch_record(base - WAVE_BATCH, g_next);      // lands while this batch is walked
+        g_next = fetch_index(base - 2 * WAVE_BATCH);
+        for (int j = cnt - 1; j >= 0; --j) {
+            const float4 e0 = s_q0[j], e1 = s_q1[j], e2 = s_q2[j];
+            const uint2 gi = s_gi[j];
+            const float A = e0.z, B = e0.w, Cc = e1.x, op = e1.y;
+            const float dx = e0.x - pxf, dy = e0.y - pyf;
+            // the forward's own arithmetic decides which entries it blended
+            const float power = fmaf(dx, fmaf(-0.5f * A, dx, -B * dy), (-0.5f * Cc * dy) * dy);
+            const float G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
+            const float alpha = fminf(ALPHA_MAX, op * G);
+            const bool valid = gi.y < last && !(power > 0.0f) && !(alpha < ALPHA_MIN);
+            if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
             float acc[10];
 #pragma unroll
             for (int k = 0; k < 10; ++k) acc[k] = 0.0f;
-            bool any_valid = false;
+            if (valid) {
+                const float one_m = 1.0f - alpha;
+                const float r = 1.0f / one_m;                 // one division; the five quotients are products with it
+                T = T * r;                                    // transmittance in front of this entry
+                const float w = alpha * T;
+                const float col[3] = {e2.x, e2.y, e2.z};
+                const float z = e2.w;
+                float dL_dalpha = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const float dx = q0.x - pxf, dy = q0.y - (float)py[k];
-                // the forward's own arithmetic decides which entries it blended
-                const float power = fmaf(dx, fmaf(-0.5f * A, dx, -B * dy), (-0.5f * Cc * dy) * dy);
-                const float G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
-                const float alpha = fminf(ALPHA_MAX, op * G);
-                const bool valid = idx < last[k] && !(power > 0.0f) && !(alpha < ALPHA_MIN);
-                if (valid) {
-                    any_valid = true;
-                    const float one_m = 1.0f - alpha;
-                    T[k] = T[k] / one_m;                      // transmittance in front of this entry
-                    const float w = alpha * T[k];
-                    float dL_dalpha = 0.0f;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        dL_dalpha += gC[k][c] * (T[k] * col[c] - S[k][c] / one_m);
-                        acc[6 + c] += w * gC[k][c];
-                        S[k][c] += w * col[c];
-                    }
-                    dL_dalpha += gD[k] * (T[k] * z - SD[k] / one_m);
-                    acc[9] += w * gD[k];
-                    SD[k] += w * z;
-                    acc[5] += G * dL_dalpha;
-                    const float dLp = G * op * dL_dalpha;    // dL/dpower
-                    acc[2] += -0.5f * dx * dx * dLp;
-                    acc[3] += -dx * dy * dLp;
-                    acc[4] += -0.5f * dy * dy * dLp;
-                    acc[0] += -(A * dx + B * dy) * dLp;
-                    acc[1] += -(Cc * dy + B * dx) * dLp;
+                for (int c = 0; c < 3; ++c) {
+                    dL_dalpha += gC[c] * (T * col[c] - S[c] * r);
+                    acc[6 + c] = w * gC[c];
+                    S[c] += w * col[c];
                 }
+                dL_dalpha += gD * (T * z - SD * r);
+                acc[9] = w * gD;
+                SD += w * z;
+                acc[5] = G * dL_dalpha;
+                const float dLp = G * op * dL_dalpha;    // dL/dpower
+                acc[2] = -0.5f * dx * dx * dLp;
+                acc[3] = -dx * dy * dLp;
+                acc[4] = -0.5f * dy * dy * dLp;
+                acc[0] = -(A * dx + B * dy) * dLp;
+                acc[1] = -(Cc * dy + B * dx) * dLp;
             }
-            if (__any(any_valid)) {
-                float* row = g_rows + (size_t)s_g[j] * GRAD_ROW;
+            // the ten totals (each valid in lane 63) move to lanes 0..9 and leave in ONE atomic instruction: ten lanes on
+            // one 48-byte row are one request to the L2's atomic unit, ten single-lane instructions are ten -- and the
+            // kernel is bound by exactly that rate (~10 G scattered atomics/s)
+            float mine = 0.0f;
 #pragma unroll
-                for (int k = 0; k < 10; ++k) {
-                    const float tot = wave_sum_to_lane63(acc[k]);
-                    if (lane == WAVE - 1 && tot != 0.0f) atomicAdd(row + k, tot);
-                }
+            for (int k = 0; k < 10; ++k) {
+                const float tot = wave_sum_to_lane63(acc[k]);
+                const float t63 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), WAVE - 1));
+                mine = lane == k ? t63 : mine;
             }
+            if (lane < 10 && mine != 0.0f) atomicAdd(g_rows + (size_t)gi.x * GRAD_ROW + lane, mine);
         }
+        __syncthreads();
     }
 }
 
@@ -194,6 +227,9 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PgrScene sc, c
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= sc.n) return;
     const bool live = radii[i] > 0;
+    // SH coefficients (and their gradients) as twelve aligned quads per Gaussian
+    const bool sh_quads = sc.shs && sc.sh_stride == 16 && (reinterpret_cast<uintptr_t>(sc.shs) & 15u) == 0 &&
+                          (!o.shs || (reinterpret_cast<uintptr_t>(o.shs) & 15u) == 0);
     const float* row = g_rows + (size_t)i * GRAD_ROW;
     float gp[3] = {0.f, 0.f, 0.f};
     float gS[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -298,6 +334,38 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PgrScene sc, c
             constexpr int NC = (DEG + 1) * (DEG + 1);
             const float* sh = sc.shs + (size_t)i * sc.sh_stride * 3;
             float gu[3] = {0.f, 0.f, 0.f};
+            if (sh_quads) {
+                // the common layout (16 coefficients x rgb = twelve aligned quads per Gaussian): coefficients in and
+                // gradients out as 16-byte accesses -- the scalar form is 48 four-byte loads (three times over) and 48
+                // four-byte stores per thread, each touching 64 different cache lines per instruction
+                float shv[48], outv[48];
+#pragma unroll
+                for (int q = 0; q < 12; ++q) {
+                    const float4 v = reinterpret_cast<const float4*>(sh)[q];
+                    shv[4 * q] = v.x; shv[4 * q + 1] = v.y; shv[4 * q + 2] = v.z; shv[4 * q + 3] = v.w;
+                }
+#pragma unroll
+                for (int k = 0; k < 48; ++k) outv[k] = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    float accv = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) accv += bb[k] * shv[3 * k + ch];
+                    const float g = (accv + 0.5f < 0.0f) ? 0.f : gcol[ch];
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) {
+                        outv[3 * k + ch] = bb[k] * g;
+                        gu[0] += g * shv[3 * k + ch] * bx[k];
+                        gu[1] += g * shv[3 * k + ch] * by[k];
+                        gu[2] += g * shv[3 * k + ch] * bz[k];
+                    }
+                }
+                if (o.shs) {
+                    float4* dst = reinterpret_cast<float4*>(o.shs + (size_t)i * 48);
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) dst[q] = make_float4(outv[4 * q], outv[4 * q + 1], outv[4 * q + 2], outv[4 * q + 3]);
+                }
+            } else {
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 float accv = 0.f;
@@ -312,15 +380,22 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PgrScene sc, c
                     gu[2] += g * sh[3 * k + ch] * bz[k];
                 }
             }
+            }
             const float dot = u[0] * gu[0] + u[1] * gu[1] + u[2] * gu[2];
 #pragma unroll
             for (int k = 0; k < 3; ++k) gp[k] += (gu[k] - u[k] * dot) / len;
         }
     } else if (o.shs) {
-        const int nf = sc.sh_stride * 3;
-        for (int k = 0; k < nf; ++k) o.shs[(size_t)i * nf + k] = 0.f;
+        if (sh_quads) {
+            float4* dst = reinterpret_cast<float4*>(o.shs + (size_t)i * 48);
+#pragma unroll
+            for (int q = 0; q < 12; ++q) dst[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            const int nf = sc.sh_stride * 3;
+            for (int k = 0; k < nf; ++k) o.shs[(size_t)i * nf + k] = 0.f;
+        }
     }
-    if (live && o.shs) {   // coefficients above the active degree receive no gradient
+    if (live && o.shs && !sh_quads) {   // coefficients above the active degree receive no gradient
         constexpr int NC = (DEG + 1) * (DEG + 1);
         for (int k = NC; k < sc.sh_stride; ++k)
             for (int ch = 0; ch < 3; ++ch) o.shs[((size_t)i * sc.sh_stride + k) * 3 + ch] = 0.f;

@@ -517,8 +517,8 @@ int32_t pgr_backward(const PgrScene* scene, const PgrCamera* cam, const float* g
     const CameraDev* camd = reinterpret_cast<const CameraDev*>(ws + B.cams);
     if (!hip_ok(hipMemsetAsync(grad_rows, 0, (size_t)N * GRAD_ROW * sizeof(float), stream), "memset grad rows"))
         return PGR_ERR_LAUNCH_FAILURE;
-    composite_backward_wave_kernel<<<2 * L.tiles, WAVE, 0, stream>>>(camd, vw.ranges, vw.gauss_sorted, vw.splats, final_T,
-                                                                     n_contrib, grad_color, grad_depth, grad_rows);
+    composite_backward_quarter_kernel<<<4 * L.tiles, WAVE, 0, stream>>>(camd, vw.ranges, vw.gauss_sorted, vw.splats, final_T,
+                                                                        n_contrib, grad_color, grad_depth, grad_rows);
     const GradOut go{grads->means2d, grads->means3d, grads->opacities, grads->colors, grads->shs, grads->cov3d,
                      grads->scales, grads->rotations};
     const int blocks = (N + 255) / 256;
