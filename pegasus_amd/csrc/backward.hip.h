@@ -21,16 +21,29 @@ namespace pgr {
 //   [0] d/dx_pix  [1] d/dy_pix  [2] d/dA  [3] d/dB  [4] d/dC  [5] d/dopacity  [6..8] d/drgb  [9] d/dz
 constexpr int GRAD_ROW = 12;
 
-// sum over the 64 lanes of a wave; the total is valid in lane 63
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false)); // row_bcast:15
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false)); // row_bcast:31
-    return v;
+// Sums of ten values over the 64 lanes of a wave; the totals are valid in lane 63.  Step-major: every DPP step is
+// applied to all ten values before the next one, so that no instruction reads a register its predecessor wrote (a DPP
+// read needs two wait states behind the write: value-major, the compiler padded the sixty DPP operations with 69 s_nop)
+// -- and as the bare instructions: through the update_dpp builtin the two row-broadcast steps cost a v_mov_b32_dpp plus
+// an add each (+0 is not the additive identity the DPP combiner wants, -0 is), and 49 moves initialise the builtin's
+// `old` operand.  60 instructions instead of ~200 issue slots per list entry, in a kernel that is bound by them.
+#define PGR_DPP_STEP10(CTRL)                                                                                              \
+    asm volatile("v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\tv_add_f32_dpp %2, %2, %2 " CTRL   \
+                 "\n\tv_add_f32_dpp %3, %3, %3 " CTRL "\n\tv_add_f32_dpp %4, %4, %4 " CTRL "\n\tv_add_f32_dpp %5, %5, %5 " CTRL \
+                 "\n\tv_add_f32_dpp %6, %6, %6 " CTRL "\n\tv_add_f32_dpp %7, %7, %7 " CTRL "\n\tv_add_f32_dpp %8, %8, %8 " CTRL \
+                 "\n\tv_add_f32_dpp %9, %9, %9 " CTRL                                                                      \
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]))
+__device__ __forceinline__ void wave_sum10_to_lane63(float (&a)[10]) {
+    asm volatile("s_nop 1" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]));
+    PGR_DPP_STEP10("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    PGR_DPP_STEP10("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    PGR_DPP_STEP10("row_half_mirror row_mask:0xf bank_mask:0xf");
+    PGR_DPP_STEP10("row_mirror row_mask:0xf bank_mask:0xf");
+    PGR_DPP_STEP10("row_bcast:15 row_mask:0xa bank_mask:0xf");
+    PGR_DPP_STEP10("row_bcast:31 row_mask:0xc bank_mask:0xf");
+    asm volatile("s_nop 1" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]));
 }
+#undef PGR_DPP_STEP10
 
 // One wave per 8x8 quarter tile, one pixel per lane -- the forward compositor's work unit, and its per-quarter skip
 // test: an entry that cannot reach alpha >= 1/255 anywhere in the quarter was blended by none of its pixels and gets no
@@ -39,13 +52,21 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 // with two pixels per lane: 5 000 waves for a whole view, each evaluating ~1 000 entries twice; the quarter form has
 // 10 000 waves that evaluate the ~43 % of their entries the skip test leaves: composite backward 1.97 -> see DESIGN.)
 // The next batch's records are requested before the current one is walked (composite.hip.h's gather).
+#ifdef PGR_BWD_STATS
+__device__ unsigned long long g_bwd_stats[40000][4];   // per wave: n_used, live entries, entries with a valid pixel, cycles
+#endif
 __global__ __launch_bounds__(WAVE) void composite_backward_quarter_kernel(
     const CameraDev* __restrict__ camp, const uint2* __restrict__ ranges, const uint32_t* __restrict__ gauss_sorted,
     const float4* __restrict__ splats, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ g_color, const float* __restrict__ g_depth, float* __restrict__ g_rows) {
+    const float* __restrict__ g_color, const float* __restrict__ g_depth, float* __restrict__ g_rows,
+    const uint32_t* __restrict__ work_order) {
+    // the forward's work order (composite.hip.h: XCD streams, longest lists first): with ONE view per launch the kernel
+    // lasts as long as its longest wave, which had better start first
+    const uint32_t item = work_order ? work_order[blockIdx.x] : blockIdx.x;
+    if (item == INVALID_ITEM) return;
     const CameraDev& cam = *camp;
     const int W = cam.width, H = cam.height;
-    const int tile = (int)(blockIdx.x >> 2), quarter = (int)(blockIdx.x & 3);
+    const int tile = (int)(item >> 2), quarter = (int)(item & 3);
     const int tile_x = tile % cam.grid_x, tile_y = tile / cam.grid_x;
     const int lane = threadIdx.x;
     const int qx0 = tile_x * TILE + (quarter & 1) * 8, qy0 = tile_y * TILE + (quarter >> 1) * 8;
@@ -67,6 +88,10 @@ __global__ __launch_bounds__(WAVE) void composite_backward_quarter_kernel(
     const float gD = (inside && g_depth) ? g_depth[pix] : 0.0f;
     float SD = 0.0f;
     // deepest contributor of any pixel of the quarter
+#ifdef PGR_BWD_STATS
+    const unsigned long long t_begin_ = __builtin_readcyclecounter();
+    unsigned long long st_live_ = 0, st_valid_ = 0;
+#endif
     uint32_t n_used = last;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) n_used = max(n_used, (uint32_t)__shfl_xor((int)n_used, d, WAVE));
@@ -104,6 +129,9 @@ __global__ __launch_bounds__(WAVE) void composite_backward_quarter_kernel(
         const bool live = have && rect_may_contribute(make_cull_splat(p, co, q1.z, q1.w), rx0, ry0, rx1, ry1);
         const unsigned long long mask = __ballot(live);
         const int cnt = __popcll(mask);
+#ifdef PGR_BWD_STATS
+        st_live_ += cnt;
+#endif
         if (live) {
             const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             s_q0[pos] = make_float4(q0.x, q0.y, q0.z, q0.w);
@@ -125,6 +153,9 @@ __global__ __launch_bounds__(WAVE) void composite_backward_quarter_kernel(
             const float alpha = fminf(ALPHA_MAX, op * G);
             const bool valid = gi.y < last && !(power > 0.0f) && !(alpha < ALPHA_MIN);
             if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
+#ifdef PGR_BWD_STATS
+            st_valid_++;
+#endif
             float acc[10];
 #pragma unroll
             for (int k = 0; k < 10; ++k) acc[k] = 0.0f;
@@ -156,17 +187,23 @@ __global__ __launch_bounds__(WAVE) void composite_backward_quarter_kernel(
             // the ten totals (each valid in lane 63) move to lanes 0..9 and leave in ONE atomic instruction: ten lanes on
             // one 48-byte row are one request to the L2's atomic unit, ten single-lane instructions are ten -- and the
             // kernel is bound by exactly that rate (~10 G scattered atomics/s)
+            wave_sum10_to_lane63(acc);
             float mine = 0.0f;
 #pragma unroll
             for (int k = 0; k < 10; ++k) {
-                const float tot = wave_sum_to_lane63(acc[k]);
-                const float t63 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), WAVE - 1));
+                const float t63 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc[k]), WAVE - 1));
                 mine = lane == k ? t63 : mine;
             }
             if (lane < 10 && mine != 0.0f) atomicAdd(g_rows + (size_t)gi.x * GRAD_ROW + lane, mine);
         }
         __syncthreads();
     }
+#ifdef PGR_BWD_STATS
+    if (lane == 0 && item < 40000) {
+        g_bwd_stats[item][0] = n_used; g_bwd_stats[item][1] = st_live_; g_bwd_stats[item][2] = st_valid_;
+        g_bwd_stats[item][3] = __builtin_readcyclecounter() - t_begin_;
+    }
+#endif
 }
 
 struct GradOut {
