@@ -133,7 +133,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         ws, radii, final_T, n_contrib = saved[k:]
         device = ws.device
         H, W = int(rs.image_height), int(rs.image_width)
-        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=device)
+        # preprocess_backward_kernel writes every element of every gradient it is handed (zeros for culled Gaussians): no
+        # zero fill (384 MB for the SH gradient of a 2 M-Gaussian scene) -- except for an empty scene, where nothing runs
+        alloc = torch.empty if n > 0 else torch.zeros
+        z = lambda *shape: alloc(shape, dtype=torch.float32, device=device)
         g = dict(means2d=z(n, 3), means3d=z(n, 3), opacities=z(n, 1))
         if t["sh"] is not None:
             g["shs"] = z(*t["sh"].shape)
