@@ -3,14 +3,13 @@
 // of alpha is not differentiated, the screen-space mean gradient is NDC-scaled (pixel gradient * W/2, H/2),
 // colours clamped at 0 and clamped view-space coordinates pass no gradient.
 //
-//   composite_backward_quarter_kernel  one wave per quarter tile (the forward's work unit: 1 pixel per lane).  The
-//       tile's list is walked BACK to front from the deepest contributor of any pixel of the wave; for every
-//       entry that can reach the quarter the 10 per-Gaussian partial gradients are summed over the wave's 64 pixels
-//       with a DPP reduction and land with ONE float atomic per component per (quarter, entry) -- 64x fewer atomics
-//       than one per pixel (scattered global atomics run at ~9 G/s on MI355X).
+//   composite_backward_block_kernel  one wave per 4x4-pixel block, four list entries per step (below): the ten
+//       per-Gaussian partial gradients of an entry are summed over the block's pixels and land as one 10-lane float
+//       atomic on the Gaussian's row.
 //   preprocess_backward_kernel      one thread per Gaussian: conic -> cov2D -> (cov3D, view-space mean) ->
 //       scale / rotation; projection; SH -> coefficients and view direction.
 #pragma once
+#include <type_traits>
 #include "composite.hip.h"
 #include "pgr_common.h"
 #include "preprocess.hip.h"
@@ -21,64 +20,39 @@ namespace pgr {
 //   [0] d/dx_pix  [1] d/dy_pix  [2] d/dA  [3] d/dB  [4] d/dC  [5] d/dopacity  [6..8] d/drgb  [9] d/dz
 constexpr int GRAD_ROW = 12;
 
-// Sums of ten values over the 64 lanes of a wave; the totals are valid in lane 63.  Step-major: every DPP step is
-// applied to all ten values before the next one, so that no instruction reads a register its predecessor wrote (a DPP
-// read needs two wait states behind the write: value-major, the compiler padded the sixty DPP operations with 69 s_nop)
-// -- and as the bare instructions: through the update_dpp builtin the two row-broadcast steps cost a v_mov_b32_dpp plus
-// an add each (+0 is not the additive identity the DPP combiner wants, -0 is), and 49 moves initialise the builtin's
-// `old` operand.  60 instructions instead of ~200 issue slots per list entry, in a kernel that is bound by them.
-#define PGR_DPP_STEP10(CTRL)                                                                                              \
-    asm volatile("v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\tv_add_f32_dpp %2, %2, %2 " CTRL   \
-                 "\n\tv_add_f32_dpp %3, %3, %3 " CTRL "\n\tv_add_f32_dpp %4, %4, %4 " CTRL "\n\tv_add_f32_dpp %5, %5, %5 " CTRL \
-                 "\n\tv_add_f32_dpp %6, %6, %6 " CTRL "\n\tv_add_f32_dpp %7, %7, %7 " CTRL "\n\tv_add_f32_dpp %8, %8, %8 " CTRL \
-                 "\n\tv_add_f32_dpp %9, %9, %9 " CTRL                                                                      \
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]))
-__device__ __forceinline__ void wave_sum10_to_lane63(float (&a)[10]) {
-    asm volatile("s_nop 1" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]));
-    PGR_DPP_STEP10("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
-    PGR_DPP_STEP10("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
-    PGR_DPP_STEP10("row_half_mirror row_mask:0xf bank_mask:0xf");
-    PGR_DPP_STEP10("row_mirror row_mask:0xf bank_mask:0xf");
-    PGR_DPP_STEP10("row_bcast:15 row_mask:0xa bank_mask:0xf");
-    PGR_DPP_STEP10("row_bcast:31 row_mask:0xc bank_mask:0xf");
-    asm volatile("s_nop 1" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]));
-}
-#undef PGR_DPP_STEP10
-
-// One wave per 8x8 quarter tile, one pixel per lane -- the forward compositor's work unit, and its per-quarter skip
-// test: an entry that cannot reach alpha >= 1/255 anywhere in the quarter was blended by none of its pixels and gets no
-// gradient from them, so only the entries that pass are parked (ballot-compacted, list order kept) and walked, BACK to
-// front, from the deepest contributor of any pixel of the quarter.  (Round 1 walked every entry of a 16x8 half tile
-// with two pixels per lane: 5 000 waves for a whole view, each evaluating ~1 000 entries twice; the quarter form has
-// 10 000 waves that evaluate the ~43 % of their entries the skip test leaves: composite backward 1.97 -> see DESIGN.)
-// The next batch's records are requested before the current one is walked (composite.hip.h's gather).
-#ifdef PGR_BWD_STATS
-__device__ unsigned long long g_bwd_stats[40000][4];   // per wave: n_used, live entries, entries with a valid pixel, cycles
-#endif
-__global__ __launch_bounds__(WAVE) void composite_backward_quarter_kernel(
+// ---- compositor backward: one wave per 4x4-pixel block, four list entries per step ------------------------------
+// The tile's list is walked BACK to front from the deepest contributor of any pixel of the block, in 64-entry batches
+// gathered one batch ahead (composite.hip.h's gather); only the entries the forward's skip test lets through for this
+// block are parked (an entry that cannot reach alpha >= 1/255 in the block was blended by none of its pixels).
+// With ONE view per launch (training) a kernel lasts as long as its longest wave; the first round-2 form -- one wave
+// per 8x8 quarter, one entry per step, 0.72 ms on the 2 M-Gaussian scene after 1.97 ms for round 1's 16x8 half tiles
+// with two pixels per lane -- spent 1 000 dependent steps on a quarter whose pixels blended 1 000 entries.  Here
+// lane = 4 * pixel + slot, and the four lanes of a pixel take four CONSECUTIVE parked entries at once.  What is sequential in the walk -- T <- T / (1 - alpha) and the suffix sums
+// of colour and depth -- is a prefix product and four prefix sums over the four lanes of a quad (two quad_perm steps
+// each); everything else is per entry.  The ten partials are summed over the block's 16 pixels (two row shifts, then a
+// 640-byte LDS transpose that also lines the 4 x 10 totals up for ONE atomic instruction).
+__global__ __launch_bounds__(WAVE) void composite_backward_block_kernel(
     const CameraDev* __restrict__ camp, const uint2* __restrict__ ranges, const uint32_t* __restrict__ gauss_sorted,
     const float4* __restrict__ splats, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ g_color, const float* __restrict__ g_depth, float* __restrict__ g_rows,
     const uint32_t* __restrict__ work_order) {
-    // the forward's work order (composite.hip.h: XCD streams, longest lists first): with ONE view per launch the kernel
-    // lasts as long as its longest wave, which had better start first
-    const uint32_t item = work_order ? work_order[blockIdx.x] : blockIdx.x;
+    const uint32_t item = work_order ? work_order[blockIdx.x >> 2] : (blockIdx.x >> 2);
     if (item == INVALID_ITEM) return;
     const CameraDev& cam = *camp;
     const int W = cam.width, H = cam.height;
-    const int tile = (int)(item >> 2), quarter = (int)(item & 3);
+    const int tile = (int)(item >> 2), quarter = (int)(item & 3), sub = (int)(blockIdx.x & 3);
     const int tile_x = tile % cam.grid_x, tile_y = tile / cam.grid_x;
-    const int lane = threadIdx.x;
-    const int qx0 = tile_x * TILE + (quarter & 1) * 8, qy0 = tile_y * TILE + (quarter >> 1) * 8;
-    if (qx0 >= W || qy0 >= H) return;
-    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const int lane = threadIdx.x, slot = lane & 3, pl = lane >> 2;
+    const int bx0 = tile_x * TILE + (quarter & 1) * 8 + (sub & 1) * 4, by0 = tile_y * TILE + (quarter >> 1) * 8 + (sub >> 1) * 4;
+    if (bx0 >= W || by0 >= H) return;
+    const int px = bx0 + (pl & 3), py = by0 + (pl >> 2);
     const bool inside = px < W && py < H;
     const size_t P = (size_t)W * H;
     const size_t pix = inside ? (size_t)py * W + px : 0;
     const uint2 range = ranges[tile];
 
     const uint32_t last = inside ? n_contrib[pix] : 0u;
-    float T = inside ? final_T[pix] : 0.0f;
+    float T = inside ? final_T[pix] : 0.0f;        // per-pixel state, the same in the four lanes of a pixel
     float S[3], gC[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -87,11 +61,6 @@ __global__ __launch_bounds__(WAVE) void composite_backward_quarter_kernel(
     }
     const float gD = (inside && g_depth) ? g_depth[pix] : 0.0f;
     float SD = 0.0f;
-    // deepest contributor of any pixel of the quarter
-#ifdef PGR_BWD_STATS
-    const unsigned long long t_begin_ = __builtin_readcyclecounter();
-    unsigned long long st_live_ = 0, st_valid_ = 0;
-#endif
     uint32_t n_used = last;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) n_used = max(n_used, (uint32_t)__shfl_xor((int)n_used, d, WAVE));
@@ -100,9 +69,12 @@ __global__ __launch_bounds__(WAVE) void composite_backward_quarter_kernel(
 
     __shared__ float4 s_q0[WAVE_BATCH], s_q1[WAVE_BATCH], s_q2[WAVE_BATCH];
     __shared__ uint2 s_gi[WAVE_BATCH];           // (Gaussian, list position)
+    __shared__ float s_red[10 * 16];             // [value][row of the wave][slot]
     const float pxf = (float)px, pyf = (float)py;
-    const float rx0 = (float)qx0, ry0 = (float)qy0;
-    const float rx1 = fminf(rx0 + 7.0f, (float)(W - 1)), ry1 = fminf(ry0 + 7.0f, (float)(H - 1));
+    const float rx0 = (float)bx0, ry0 = (float)by0;
+    const float rx1 = fminf(rx0 + 3.0f, (float)(W - 1)), ry1 = fminf(ry0 + 3.0f, (float)(H - 1));
+    const bool ge1 = slot >= 1, ge2 = slot >= 2;
+    const int out_slot = lane / 10, out_k = lane - out_slot * 10;      // lanes 0..39: (entry slot, value) of the atomic
 
     f32x4_t q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0;
     uint32_t g_cur = 0, g_next = 0;
@@ -117,6 +89,24 @@ __global__ __launch_bounds__(WAVE) void composite_backward_quarter_kernel(
             q0 = gload_quad(rec); q1 = gload_quad(rec + 1); q2 = gload_quad(rec + 2);
         }
     };
+    // quad_perm lane exchange inside the four lanes of a pixel
+    auto quad = [](float v, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    using QP_0012 = std::integral_constant<int, 0x90>;    // quad_perm [0,0,1,2]: the lane one slot down
+    using QP_0101 = std::integral_constant<int, 0x44>;    // quad_perm [0,1,0,1]: the lane two slots down
+    using QP_3333 = std::integral_constant<int, 0xFF>;    // quad_perm [3,3,3,3]: the pixel's last slot
+    auto prefix_prod = [&](float x) {
+        const float a = quad(x, QP_0012{}); x = ge1 ? x * a : x;
+        const float b = quad(x, QP_0101{}); x = ge2 ? x * b : x;
+        return x;
+    };
+    auto prefix_sum = [&](float x) {
+        const float a = quad(x, QP_0012{}); x = ge1 ? x + a : x;
+        const float b = quad(x, QP_0101{}); x = ge2 ? x + b : x;
+        return x;
+    };
+
     const int first = (int)((n_used - 1) / WAVE_BATCH) * WAVE_BATCH;
     fetch_record(first, fetch_index(first));
     g_next = fetch_index(first - WAVE_BATCH);
@@ -124,14 +114,10 @@ __global__ __launch_bounds__(WAVE) void composite_backward_quarter_kernel(
     for (int base = first; base >= 0; base -= WAVE_BATCH) {
         asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(g_cur));      // the quads are taken as they arrive, here
         const bool have = base + lane < (int)n_used;
-        const float2 p = make_float2(q0.x, q0.y);
-        const float4 co = make_float4(q0.z, q0.w, q1.x, q1.y);
-        const bool live = have && rect_may_contribute(make_cull_splat(p, co, q1.z, q1.w), rx0, ry0, rx1, ry1);
+        const bool live = have && rect_may_contribute(make_cull_splat(make_float2(q0.x, q0.y), make_float4(q0.z, q0.w, q1.x, q1.y),
+                                                                      q1.z, q1.w), rx0, ry0, rx1, ry1);
         const unsigned long long mask = __ballot(live);
         const int cnt = __popcll(mask);
-#ifdef PGR_BWD_STATS
-        st_live_ += cnt;
-#endif
         if (live) {
             const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             s_q0[pos] = make_float4(q0.x, q0.y, q0.z, q0.w);
@@ -142,40 +128,43 @@ __global__ __launch_bounds__(WAVE) void composite_backward_quarter_kernel(
         __syncthreads();
         fetch_record(base - WAVE_BATCH, g_next);      // lands while this batch is walked
         g_next = fetch_index(base - 2 * WAVE_BATCH);
-        for (int j = cnt - 1; j >= 0; --j) {
-            const float4 e0 = s_q0[j], e1 = s_q1[j], e2 = s_q2[j];
-            const uint2 gi = s_gi[j];
+        for (int hi = cnt - 1; hi >= 0; hi -= 4) {     // slot 0 takes entry hi (the deepest), slot 3 entry hi - 3
+            const int j = hi - slot;
+            const int jc = j < 0 ? 0 : j;
+            const float4 e0 = s_q0[jc], e1 = s_q1[jc], e2 = s_q2[jc];
+            const uint2 gi = s_gi[jc];
             const float A = e0.z, B = e0.w, Cc = e1.x, op = e1.y;
             const float dx = e0.x - pxf, dy = e0.y - pyf;
-            // the forward's own arithmetic decides which entries it blended
             const float power = fmaf(dx, fmaf(-0.5f * A, dx, -B * dy), (-0.5f * Cc * dy) * dy);
             const float G = __builtin_amdgcn_exp2f(power * 1.4426950408889634f);
             const float alpha = fminf(ALPHA_MAX, op * G);
-            const bool valid = gi.y < last && !(power > 0.0f) && !(alpha < ALPHA_MIN);
+            const bool valid = j >= 0 && gi.y < last && !(power > 0.0f) && !(alpha < ALPHA_MIN);
             if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
-#ifdef PGR_BWD_STATS
-            st_valid_++;
-#endif
+            const float av = valid ? alpha : 0.0f;
+            const float r = valid ? 1.0f / (1.0f - alpha) : 1.0f;
+            const float Tin = T * prefix_prod(r);          // transmittance in front of this lane's entry
+            const float w = av * Tin;
+            const float col[3] = {e2.x, e2.y, e2.z};
+            const float z = e2.w;
+            float cin[4], cinc[4];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) cin[c] = w * col[c];
+            cin[3] = w * z;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cinc[c] = prefix_sum(cin[c]);
             float acc[10];
 #pragma unroll
             for (int k = 0; k < 10; ++k) acc[k] = 0.0f;
             if (valid) {
-                const float one_m = 1.0f - alpha;
-                const float r = 1.0f / one_m;                 // one division; the five quotients are products with it
-                T = T * r;                                    // transmittance in front of this entry
-                const float w = alpha * T;
-                const float col[3] = {e2.x, e2.y, e2.z};
-                const float z = e2.w;
                 float dL_dalpha = 0.0f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    dL_dalpha += gC[c] * (T * col[c] - S[c] * r);
+                    const float Sb = S[c] + (cinc[c] - cin[c]);         // the sum behind this lane's entry
+                    dL_dalpha += gC[c] * (Tin * col[c] - Sb * r);
                     acc[6 + c] = w * gC[c];
-                    S[c] += w * col[c];
                 }
-                dL_dalpha += gD * (T * z - SD * r);
+                dL_dalpha += gD * (Tin * z - (SD + (cinc[3] - cin[3])) * r);
                 acc[9] = w * gD;
-                SD += w * z;
                 acc[5] = G * dL_dalpha;
                 const float dLp = G * op * dL_dalpha;    // dL/dpower
                 acc[2] = -0.5f * dx * dx * dLp;
@@ -184,26 +173,37 @@ __global__ __launch_bounds__(WAVE) void composite_backward_quarter_kernel(
                 acc[0] = -(A * dx + B * dy) * dLp;
                 acc[1] = -(Cc * dy + B * dx) * dLp;
             }
-            // the ten totals (each valid in lane 63) move to lanes 0..9 and leave in ONE atomic instruction: ten lanes on
-            // one 48-byte row are one request to the L2's atomic unit, ten single-lane instructions are ten -- and the
-            // kernel is bound by exactly that rate (~10 G scattered atomics/s)
-            wave_sum10_to_lane63(acc);
-            float mine = 0.0f;
+            // the pixel's state after these four entries: what its last slot holds
+            T = quad(Tin, QP_3333{});
 #pragma unroll
-            for (int k = 0; k < 10; ++k) {
-                const float t63 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc[k]), WAVE - 1));
-                mine = lane == k ? t63 : mine;
+            for (int c = 0; c < 3; ++c) S[c] += quad(cinc[c], QP_3333{});
+            SD += quad(cinc[3], QP_3333{});
+            // sums over the 16 pixels: lanes 4 apart inside a row of 16, then the four rows through LDS
+            asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]));
+#define PGR_ROW_STEP(CTRL)                                                                                                  \
+    asm volatile("v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\tv_add_f32_dpp %2, %2, %2 " CTRL       \
+                 "\n\tv_add_f32_dpp %3, %3, %3 " CTRL "\n\tv_add_f32_dpp %4, %4, %4 " CTRL "\n\tv_add_f32_dpp %5, %5, %5 " CTRL   \
+                 "\n\tv_add_f32_dpp %6, %6, %6 " CTRL "\n\tv_add_f32_dpp %7, %7, %7 " CTRL "\n\tv_add_f32_dpp %8, %8, %8 " CTRL   \
+                 "\n\tv_add_f32_dpp %9, %9, %9 " CTRL                                                                        \
+                 : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]))
+            PGR_ROW_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+            PGR_ROW_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+#undef PGR_ROW_STEP
+            asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]));
+            if ((lane & 12) == 12) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) s_red[k * 16 + (lane >> 4) * 4 + slot] = acc[k];
             }
-            if (lane < 10 && mine != 0.0f) atomicAdd(g_rows + (size_t)gi.x * GRAD_ROW + lane, mine);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 40 && hi - out_slot >= 0) {
+                const float* red = s_red + out_k * 16 + out_slot;
+                const float tot = (red[0] + red[4]) + (red[8] + red[12]);
+                if (tot != 0.0f) atomicAdd(g_rows + (size_t)s_gi[hi - out_slot].x * GRAD_ROW + out_k, tot);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
     }
-#ifdef PGR_BWD_STATS
-    if (lane == 0 && item < 40000) {
-        g_bwd_stats[item][0] = n_used; g_bwd_stats[item][1] = st_live_; g_bwd_stats[item][2] = st_valid_;
-        g_bwd_stats[item][3] = __builtin_readcyclecounter() - t_begin_;
-    }
-#endif
 }
 
 struct GradOut {

@@ -518,7 +518,7 @@ int32_t pgr_backward(const PgrScene* scene, const PgrCamera* cam, const float* g
     if (!hip_ok(hipMemsetAsync(grad_rows, 0, (size_t)N * GRAD_ROW * sizeof(float), stream), "memset grad rows"))
         return PGR_ERR_LAUNCH_FAILURE;
     // the forward's work order is still in the workspace (one view: item = 4 * tile + quarter)
-    composite_backward_quarter_kernel<<<(uint32_t)B.order_slots, WAVE, 0, stream>>>(
+    composite_backward_block_kernel<<<4u * (uint32_t)B.order_slots, WAVE, 0, stream>>>(
         camd, vw.ranges, vw.gauss_sorted, vw.splats, final_T, n_contrib, grad_color, grad_depth, grad_rows,
         reinterpret_cast<const uint32_t*>(ws + B.work_order));
     const GradOut go{grads->means2d, grads->means3d, grads->opacities, grads->colors, grads->shs, grads->cov3d,
@@ -618,13 +618,6 @@ int32_t pgr_quantize_frame(const float* img_chw, const float* depth_hw, int32_t 
 
 }  // extern "C"
 
-#ifdef PGR_BWD_STATS
-extern "C" int32_t pgr_debug_bwd_stats(unsigned long long* out, int32_t n_waves) {
-    if (hipDeviceSynchronize() != hipSuccess) return -4;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pgr::g_bwd_stats), (size_t)n_waves * 32) != hipSuccess) return -4;
-    return 0;
-}
-#endif
 #ifdef PGR_COMP_STATS
 extern "C" int32_t pgr_debug_comp_stats(unsigned long long* out, int32_t reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -4;

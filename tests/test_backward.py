@@ -66,13 +66,16 @@ def test_oracle_backward_matches_finite_differences(oracle, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["tiny", "cube"])
+@pytest.mark.parametrize("case", ["tiny", "ragged", "cube"])
 def test_hip_backward_matches_oracle(oracle, gpu_device, case):
     """loss.backward() through the drop-in GaussianRasterizer == the oracle's analytic gradients."""
     import torch
     from pegasus_amd import diff_gaussian_rasterization as dgr, scenes
     if case == "tiny":
         P, v = tiny_scene(3, n=40, W=80, H=64)
+        P = {k: np.asarray(a, np.float32) for k, a in P.items()}
+    elif case == "ragged":      # image sides that are multiples of neither the tile nor the backward's 4x4 pixel block
+        P, v = tiny_scene(7, n=60, W=77, H=53)
         P = {k: np.asarray(a, np.float32) for k, a in P.items()}
     else:
         cloud, views = scenes.scene_c1(seed=4, n=3000)
