@@ -13,7 +13,10 @@ ARCH = "gfx950"
 # -ffp-contract=off: every fused multiply-add in the kernels is an explicit fmaf(), which is what
 # makes the integer stages bit-exact against the oracle (DESIGN.md "Arithmetic contract").
 # -munsafe-fp-atomics: the backward pass accumulates with hardware global_atomic_add_f32 instead of a CAS loop.
-FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC", "-shared",
+# -fno-slp-vectorize: the SLP vectoriser pairs scalar fp32 operations into v_pk_* and pays for it in v_mov to line the
+# operands up (61 moves in the 614 VALU instructions of the preprocess' per-view body): preprocess -3 %, binning -1.5 %.
+# The compositor's packed arithmetic is written with vector types and does not depend on it.
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-munsafe-fp-atomics", "-fPIC", "-shared",
          f"--offload-arch={ARCH}"]
 
 
@@ -25,7 +28,7 @@ def needs_build() -> bool:
     if not LIB.exists():
         return True
     srcs, hdrs = sources()
-    newest = max(p.stat().st_mtime for p in srcs + hdrs)
+    newest = max(p.stat().st_mtime for p in srcs + hdrs + [Path(__file__)])      # (the flags live in this file)
     return LIB.stat().st_mtime < newest
 
 

@@ -11,7 +11,7 @@ if [ "$mode" = build ]; then
   specs=$1; shift
   for s in $specs; do
     U=${s%%:*}; Wv=${s##*:}
-    ( cd pegasus_amd/csrc && hipcc -O3 -std=c++17 -ffp-contract=off -munsafe-fp-atomics -fPIC -shared --offload-arch=gfx950 \
+    ( cd pegasus_amd/csrc && hipcc -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -munsafe-fp-atomics -fPIC -shared --offload-arch=gfx950 \
         -DPGR_COMP_WAVES=$Wv "$@" -o ../../build_variants/lib_u${U}_w${Wv}.so pegasus_raster.hip ) &
   done
   wait
