@@ -82,3 +82,37 @@ def test_semantic_descriptor_is_checked_before_any_enqueue(gpu_device):
     again = R.forward_views(act["means3d"], act["opacities"], [spec], semantic=good, **kw)[0]
     torch.cuda.synchronize()
     assert torch.equal(again["sem_color"], ok["sem_color"])
+
+
+@pytest.mark.gpu
+def test_batch_in_which_only_some_views_overflow(gpu_device):
+    """A batch whose instance capacity is enough for some of its views and not for others: the overflowed views are left out
+    of the sort queues and the compositor (nothing reads past the buffers), the others render, the host sees the flags, and
+    the transparent re-render ends with the frames a roomy first attempt gives."""
+    import numpy as np
+    import torch
+    from pegasus_amd import frames as F, rasterizer, scenes
+    cloud, views = scenes.scene_c3(scale=0.04, n_views=4, width=320, height=240)
+    act = cloud.activated()
+    fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"],
+                         cloud.object_id, sh_degree=3, device=gpu_device)
+    specs = [fr.view_spec(v) for v in views]
+    ref = {k: v.clone() for k, v in fr.render_frames(specs).items()}
+    torch.cuda.synchronize()
+    need = []
+    for sp in specs:                                       # every view alone: its own instance count
+        rasterizer.forward_views(fr.means3d, fr.opacities, [sp], shs=fr.shs, scales=fr.scales, rotations=fr.rotations,
+                                 sh_degree=fr.sh_degree, tie_index=fr.tie_index, want_radii=False)
+        need.append(int(rasterizer.last_forward_info()["num_instances"][0]))
+    need.sort()
+    assert need[0] < need[-1], need
+    between = (need[0] + need[-1]) // 2                    # room for the lightest view, not for the heaviest
+    for key in list(rasterizer._WS.capacity_hint):
+        rasterizer._WS.capacity_hint[key] = between
+    for kk in [k for k in rasterizer._WS.buf if isinstance(k, tuple) and len(k) == 2 and isinstance(k[1], tuple)]:
+        rasterizer._WS.buf.pop(kk)
+    out = fr.alloc_frames(len(specs), 240, 320)
+    fr.render_frames_async(specs, out, slot=0).wait()
+    torch.cuda.synchronize()
+    for k in ("color", "depth", "seg", "masks"):
+        assert torch.equal(out[k], ref[k]), k
