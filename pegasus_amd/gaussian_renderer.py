@@ -8,11 +8,39 @@ src/gs/dev/gs_manipulation_static.py:311-315)."""
 from __future__ import annotations
 
 import math
+import weakref
 
 import torch
 
 from .diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 from .sh_utils import eval_sh
+
+
+# Activated parameters of a model, kept between calls while the model does not change.  PEGASUS renders one scene from
+# many cameras, one `render()` call each (pegasus.py:254-271, src/gs/render.py); the getters behind `pc.get_opacity`,
+# `get_scaling`, `get_rotation` and `get_features` are four elementwise kernels and a 192-byte-per-Gaussian `cat`
+#  -- 0.36 ms of a 0.93 ms call on the 2 M-Gaussian scene.  Keyed on the identity and version counter of
+# the raw tensors: any in-place edit or re-assignment (pose application, merge, mask) misses.  Inference only.
+_ACT_CACHE = weakref.WeakKeyDictionary()
+_RAW = {"get_opacity": ("_opacity",), "get_scaling": ("_scaling",), "get_rotation": ("_rotation",),
+        "get_features": ("_features_dc", "_features_rest")}
+
+
+def _activated(pc, getter: str):
+    raw = [getattr(pc, a, None) for a in _RAW[getter]]
+    if torch.is_grad_enabled() or any(not isinstance(t, torch.Tensor) for t in raw):
+        return getattr(pc, getter)
+    key = tuple((id(t), t._version, t.data_ptr(), tuple(t.shape)) for t in raw)
+    try:
+        slot = _ACT_CACHE.setdefault(pc, {})
+    except TypeError:                      # a model class that cannot be weakly referenced: no cache
+        return getattr(pc, getter)
+    hit = slot.get(getter)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    value = getattr(pc, getter)
+    slot[getter] = (key, value, raw)       # `raw` keeps the keyed tensors alive: their ids and addresses cannot be reused
+    return value
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
@@ -39,14 +67,14 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
 
     means3D = pc.get_xyz
     means2D = screenspace_points
-    opacity = pc.get_opacity
+    opacity = _activated(pc, "get_opacity")
 
     scales = rotations = cov3D_precomp = None
     if getattr(pipe, "compute_cov3D_python", False):
         cov3D_precomp = pc.get_covariance(scaling_modifier)
     else:
-        scales = pc.get_scaling
-        rotations = pc.get_rotation
+        scales = _activated(pc, "get_scaling")
+        rotations = _activated(pc, "get_rotation")
 
     shs = colors_precomp = None
     if override_color is None:
@@ -57,7 +85,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
             sh2rgb = eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized)
             colors_precomp = torch.clamp_min(sh2rgb + 0.5, 0.0)
         else:
-            shs = pc.get_features
+            shs = _activated(pc, "get_features")
     else:
         colors_precomp = override_color
 

@@ -166,3 +166,43 @@ def test_generate_writes_bop_layout(gpu_device, tmp_path):
     assert rgb.shape == (160, 160, 3) and rgb.dtype == np.uint8 and rgb.max() > 0
     assert depth.shape == (160, 160) and depth.dtype == np.uint16 and 200 < depth[depth > 0].mean() < 3000   # millimetres
     assert all(set(np.unique(m)) <= {0, 255} for m in masks) and sum(int(m.sum()) for m in masks) > 0
+
+
+@pytest.mark.gpu
+def test_render_facade_activation_cache_follows_the_model(gpu_device):
+    """render() keeps the activated parameters of an unchanged model between calls (inference); an in-place edit or a
+    re-assignment of a raw tensor must show in the very next frame."""
+    import sys
+    from argparse import ArgumentParser
+    import torch
+    root = str(Path(__file__).resolve().parents[1])
+    for p in (root, root + "/compat"):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from gaussian_renderer import render, GaussianModel
+    from scene.cameras import Camera
+    from arguments import PipelineParams
+    from pegasus_amd import scenes
+    dev = gpu_device
+    cloud, views = scenes.scene_c1(seed=9, n=4000)
+    v = views[0]
+    with torch.no_grad():
+        pc = GaussianModel.from_arrays(cloud.xyz, cloud.features_dc, cloud.features_rest, cloud.opacity, cloud.scaling,
+                                       cloud.rotation, device=dev)
+        cam = Camera(colmap_id=0, R=v.R_c2w, T=v.t_w2c, FoVx=v.fovx, FoVy=v.fovy, image=None, image_width=v.width,
+                     image_height=v.height, gt_alpha_mask=None, image_name="0", uid=0, data_device=str(dev))
+        pipe = PipelineParams(ArgumentParser())
+        bg = torch.zeros(3, device=dev)
+        a = render(cam, pc, pipe, bg)["render"].clone()
+        b = render(cam, pc, pipe, bg)["render"].clone()          # second call: cached activations
+        assert torch.equal(a, b)
+        pc._opacity.sub_(2.0)                                      # in-place edit: version counter moves
+        c = render(cam, pc, pipe, bg)["render"].clone()
+        assert not torch.equal(a, c)
+        pc._features_dc = pc._features_dc.clone() * 0.5            # re-assignment
+        d = render(cam, pc, pipe, bg)["render"].clone()
+        assert not torch.equal(c, d)
+        fresh = GaussianModel.from_arrays(cloud.xyz, cloud.features_dc * 0.5, cloud.features_rest, cloud.opacity - 2.0,
+                                          cloud.scaling, cloud.rotation, device=dev)
+        e = render(cam, fresh, pipe, bg)["render"]
+        assert torch.equal(d, e)                                   # what an uncached model with the same values renders
