@@ -1,25 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- rendered views/sec (RGB + depth + mask) on the 2 M-Gaussian merged scene @800x800.
 
-Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` ; for N>1 it is launched through
-``python -m torch.distributed.run`` with one rank per GPU.  One "step" = one pass of the rasterizer hot
-path over one camera of the synthetic merged scene (BASELINE.json configs[2]: environment + 8 objects,
-2.0 M Gaussians, 800x800).  Views shard across ranks with no data-path collective (weak scaling: every
-rank renders K views of its own shard of the camera list); rank 0 prints ONE JSON line.
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``.
+
+* N = 1: this process renders.
+* N > 1 and no torchrun environment: this process is only a LAUNCHER.  Before anything touches a GPU it starts
+  ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`` as a
+  CHILD process and exits with its code (it never re-execs itself), after checking that N HIP devices are visible.
+* N > 1 under an outer torchrun (WORLD_SIZE set; how the driver launches it): one rank per GPU over RCCL; WORLD_SIZE must
+  equal --gpus or the run refuses to print a mislabelled line.
+
+One "step" = one batch of B = 32 cameras of the synthetic merged scene (BASELINE.json configs[2]: environment + 8 objects,
+2.0 M Gaussians, 800x800) through the rasterizer hot path.  Views shard across ranks (view v -> rank v mod N, scene
+replicated: SURVEY.md section 8e), weak scaling: every rank renders K batches of its own shard.  For N > 1 the path's ONE
+collective -- the gather of every finished batch to rank 0, in the reference's on-disk precision -- runs inside the timed
+region by default (asynchronous, one gather in flight beside the next batch); the render-only rate is timed in a second
+K-step pass and reported beside it.  Rank 0 prints ONE JSON line.
 
 The JSON line also carries
-  roofline      -- the dominant kernel's algorithmic bytes / its average duration measured live with
-                   HIP events on the launch stream (pgr_forward_profiled), against 8 TB/s HBM peak
-  cpu_baseline  -- the CPU oracle ("port": there is no reference CPU rasterizer) timed on this box's
-                   host cores on a bounded sample of the same workload (rank 0, N=1 only)
+  roofline      -- the dominant kernel's algorithmic bytes / its average duration measured live with HIP events on the
+                   launch stream (pgr_forward_batch_profiled), against 8 TB/s HBM peak; `valu` prices the compositor's
+                   pixel-Gaussian evaluations against the chip's VALU lane rate
+  cpu_baseline  -- the CPU oracle ("port": there is no reference CPU rasterizer) timed on this box's host cores on a
+                   bounded sample of the same workload (rank 0, N = 1 only)
+  drop_in       -- PEGASUS's own per-camera loop (one render() per view through the reference's four wrappers) on a
+                   bounded sample (rank 0, N = 1 only)
 """
 from __future__ import annotations
 
 import argparse
-import ctypes as C
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -29,12 +43,15 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_PEAK_LANE_OPS = 78.6e12   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (SURVEY.md section 8d "secondary ceiling")
+LANE_OPS_PER_EVAL = 20         # VALU lane-ops of one pixel-Gaussian evaluation (same section)
+SEQUENCE_STEPS = 200           # BASELINE.json configs[4]: "Dynamic 200-step physics sequence"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c5"])
@@ -43,32 +60,88 @@ def parse():
     ap.add_argument("--batch", type=int, default=32,
                     help="views per step (one batch call); 16 default steps x 32 = the 512 views of configs[2], each once")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-drop-in", action="store_true", help="skip the per-camera render() sample (drop_in)")
+    ap.add_argument("--facade", action="store_true",
+                    help="only the drop-in path: frames/s of PEGASUS's per-camera loop through the four render wrappers "
+                         "and the latency of one render() call, on a larger sample")
     ap.add_argument("--separate-semantic", action="store_true",
                     help="semantic image by a second full pass over the objects (default: fused into the scene pass)")
     ap.add_argument("--sync-steps", action="store_true", help="one blocking render_batch per step (no pipelining)")
     ap.add_argument("--serialize-slots", action="store_true",
-                    help="A/B: make the two pipeline slots execute one after the other on the GPU (round-1 behaviour)")
+                    help="A/B: make the pipeline slots execute one after the other on the GPU (round-1 behaviour)")
     ap.add_argument("--input-order", action="store_true",
                     help="keep the scene in its input order (default: one-time Morton layout per object, outside the timed region)")
     ap.add_argument("--dynamic", action="store_true",
-                    help="dynamic sequence: every frame is a TIME STEP with its own object poses (posed inside the "
-                         "preprocess) and one camera, plus its BOP pose records")
+                    help="dynamic sequence (BASELINE.json configs[4]): every frame is a TIME STEP of the recorded drop "
+                         "(tests/golden/simulation_steps_body1_first200.npz, the reference's simulation_steps.json body 1) "
+                         "with its own object poses, posed inside the preprocess, one camera per step, + BOP pose records")
     ap.add_argument("--raster-only", action="store_true", help="time only the full-scene RGB+depth pass (R), no masks")
     ap.add_argument("--slots", type=int, default=3, help="batches in flight (pipeline slots: workspaces, frame sets)")
     ap.add_argument("--streams", type=int, default=0, help="streams the slots share round-robin (0 = one per slot)")
     ap.add_argument("--step-log", action="store_true", help="per-step (enqueue, wait) host milliseconds on stderr")
-    ap.add_argument("--gather", action="store_true",
-                    help="N > 1: also gather every batch's finished frames to rank 0 inside the timed region, in the "
-                         "reference's on-disk precision (uint8 RGB, uint16 depth, uint8 masks; pegasus.py:347,355) -- the "
-                         "one RCCL exchange of the path (SURVEY.md section 8e); asynchronous, overlapping the next batch")
+    ap.add_argument("--gather", dest="gather", action="store_true", default=None,
+                    help="N > 1 (default there): gather every batch's finished frames to rank 0 inside the timed region, in "
+                         "the reference's on-disk precision (uint8 RGB, uint16 depth, one mask byte per pixel; "
+                         "pegasus.py:347,355) -- the one RCCL exchange of the path (SURVEY.md section 8e)")
+    ap.add_argument("--no-gather", dest="gather", action="store_false", help="N > 1: frames stay on the rank that rendered them")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; nccl = RCCL (the measured configuration).  gloo stages the gathered "
+                         "frames through host memory: rehearsals and CPU tests only, flagged in the JSON line")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="REHEARSAL: allow more ranks than HIP devices (rank r uses device r mod count; needs --backend gloo, "
+                         "RCCL refuses two ranks on one GPU); the JSON line is flagged and is not a result")
+    ap.add_argument("--stub-renderer", action="store_true",
+                    help="TEST ONLY: exercise launch / sharding / gather / timing with a deterministic CPU frame source "
+                         "(no rasterizer, gloo); the JSON line is flagged invalid")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--profile-steps", type=int, default=0,
                     help="batches measured per-stage with HIP events (0 = the same batches as the timed steps)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def build_workload(name, scale, n_views):
+# --------------------------------------------------------------------------------------------------------------------
+# launcher
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def visible_devices() -> int:
+    """HIP devices this process could use.  torch.cuda.device_count() does not initialise the GPU on this image, so the
+    launcher may call it and still spawn children afterwards."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def self_launch(args, argv) -> int:
+    """``python bench.py --gpus N`` without a torchrun environment: start the N ranks as a child process tree."""
+    n = int(args.gpus)
+    if not args.stub_renderer:
+        have = visible_devices()
+        if have < n and not args.share_devices:
+            print(f"bench.py --gpus {n}: only {have} HIP device(s) visible on this node; refusing to print a line that is "
+                  f"not an {n}-GPU measurement (rehearsal on fewer devices: --share-devices --backend gloo)", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"), *argv]
+    env = dict(os.environ)
+    env["PGR_BENCH_LAUNCHER"] = "self"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    print("bench.py launcher:", " ".join(cmd), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# workload
+
+def build_workload(name, scale, n_views, with_poses=False):
     from pegasus_amd import scenes
+    rest = None
     if name == "c1":
         cloud, views = scenes.scene_c1()
         label = "C1 10k-Gaussian cube, 256x256"
@@ -76,13 +149,15 @@ def build_workload(name, scale, n_views):
         cloud, views = scenes.scene_c2(n=int(150_000 * scale), n_views=n_views)
         label = "C2 single object 150k Gaussians, 800x800 hemisphere views"
     elif name == "c5":
-        cloud, views = scenes.scene_c5(scale=scale, n_views=n_views)
-        label = "C5 5M-Gaussian scene, 800x800"
+        cloud, views, rest = scenes.merged_scene(5, int(3_400_000 * scale), 20, int(80_000 * scale), n_views)
+        label = "C5 5M-Gaussian scene (3.4M environment + 20 objects), 800x800"
     else:
-        cloud, views = scenes.scene_c3(scale=scale, n_views=n_views)
+        cloud, views, rest = scenes.merged_scene(3, int(1_360_000 * scale), 8, int(80_000 * scale), n_views)
         label = "C3 merged env + 8 objects, 2M Gaussians, 800x800"
     if scale != 1.0:
         label += f" [scale={scale}: NOT the baseline config]"
+    if with_poses:
+        return cloud, views, label, rest
     return cloud, views, label
 
 
@@ -94,216 +169,402 @@ def algorithmic_bytes(N, V, I, P):
         "bin_count": 0,
         "bin_scatter": 12 * I,
         "tile_sort": 24 * I + 8 * I,
-        "composite": 44 * I + 16 * P,      # + 16 P for the fused semantic image, not counted (SURVEY's figure)
+        "composite": 44 * I + 16 * P,      # (the fused semantic image adds 16 P of writes: reported beside it)
     }
     return 16 * N + 272 * V + 88 * I + 16 * P, per_stage
 
 
-def main():
-    args = parse()
+class RealEngine:
+    """The product path: FrameRenderer over the resident scene, `n_slots` batches in flight."""
+    stub = False
+
+    def __init__(self, args, rank, world, dev):
+        import torch
+        from pegasus_amd import _lib, frames as F
+        _lib.lib()
+        self.args, self.rank, self.world, self.dev, self.torch = args, rank, world, dev, torch
+        B = self.B = max(1, args.batch)
+        n_views_total = max(args.views, B) * world
+        cloud, views, label, rest = build_workload(args.workload, args.scale, n_views_total, with_poses=True)
+        self.cloud, self.views, self.label = cloud, views, label
+        self.act = act = cloud.activated()
+        fr = self.fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"],
+                                       cloud.object_id, sh_degree=3, device=dev, spatial_order=not args.input_order)
+        fr.serialize_slots = args.serialize_slots
+        fr.n_streams = args.streams or None
+        self.specs = [fr.view_spec(v) for v in views]
+        self.W, self.H = views[0].width, views[0].height
+        self.with_masks = not args.raster_only and fr.K > 0
+        self.n_slots = max(1, args.slots)
+        self.frame_sets = [fr.alloc_frames(B, self.H, self.W, masks=self.with_masks) for _ in range(self.n_slots)]
+        self.frames = self.frame_sets[0]
+        # dynamic sequence: the whole trajectory exists before rendering starts (the reference simulates first,
+        # /root/reference/pegasus.py:216 then :247); time step s -> rank s mod world, poses composed absolutely per step
+        self.pose_seq = self.m2w_seq = None
+        if args.dynamic:
+            if fr.K == 0 or rest is None:
+                raise SystemExit("--dynamic needs a scene with objects (c3, c5)")
+            from pegasus_amd import trajectory as TJ
+            oid = cloud.object_id
+            centers = [act["means3d"][oid == k].astype(np.float64).mean(0) for k in range(1, fr.K + 1)]
+            self.pose_seq, motions = TJ.sequence_poses(TJ.load_fixture(), centers, SEQUENCE_STEPS)
+            rest_m2w = []
+            for Rm, t in rest:
+                M = np.eye(4); M[:3, :3] = Rm; M[:3, 3] = t
+                rest_m2w.append(M)
+            self.m2w_seq = [{k: mot[k] @ rest_m2w[k - 1] for k in mot} for mot in motions]
+
+    # frame j of this rank is global frame j * world + rank (view v -> rank v mod world; step s -> rank s mod world)
+    def frame_ids(self, i):
+        return [((i * self.B + k) * self.world + self.rank) for k in range(self.B)]
+
+    def batch_views(self, i):
+        return [self.specs[g % len(self.specs)] for g in self.frame_ids(i)]
+
+    def batch_poses(self, i):
+        return None if self.pose_seq is None else self.pose_seq[[g % SEQUENCE_STEPS for g in self.frame_ids(i)]]
+
+    def batch_records(self, i):
+        if self.pose_seq is None:
+            return None
+        from pegasus_amd import bop_pose
+        ids = self.frame_ids(i)
+        return bop_pose.batch_pose_records([self.views[g % len(self.views)] for g in ids],
+                                           [self.m2w_seq[g % SEQUENCE_STEPS] for g in ids])
+
+    def enqueue(self, i, slot):
+        fr, a = self.fr, self.args
+        if a.separate_semantic:
+            return fr.render_batch_async(self.batch_views(i), self.frame_sets[slot], masks=self.with_masks, slot=slot)
+        h = fr.render_frames_async(self.batch_views(i), self.frame_sets[slot], masks=self.with_masks, slot=slot,
+                                   poses=self.batch_poses(i))
+        self.batch_records(i)                 # BOP scene_gt / scene_camera entries of the batch (host, overlapped)
+        return h
+
+    def step_blocking(self, i, **kw):
+        fr, a = self.fr, self.args
+        if a.separate_semantic:
+            return fr.render_batch(self.batch_views(i), self.frames, masks=self.with_masks, **kw)
+        kw.pop("sem_stage_ms", None)
+        poses = self.batch_poses(i)
+        if poses is not None and kw.get("stage_ms") is None:      # (the profiling entry point has no posed variant:
+            kw.pop("stage_ms", None)                              #  stage times are taken on the unposed scene)
+            return fr.render_frames(self.batch_views(i), self.frames, masks=self.with_masks, poses=poses, **kw)
+        return fr.render_frames(self.batch_views(i), self.frames, masks=self.with_masks, **kw)
+
+    def pack(self, fr_set):
+        """What leaves the GPU for a finished batch: NEW tensors (the frame set is re-rendered while they travel)."""
+        from pegasus_amd import masks as M
+        return M.pack_frames(color=fr_set["color"][:self.B], depth=fr_set["depth"][:self.B],
+                             masks=fr_set["masks"][:self.B] if "masks" in fr_set else None)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def settle(self, run_steps):
+        """Set-up, not warm-up: let the workspaces reach their size.  The instance capacity is a hint that grows when a
+        batch comes close to it (a multi-GB reallocation, tens of ms, once per scene and pipeline slot); small scenes start
+        below their need and would otherwise pay that inside the timed region."""
+        from pegasus_amd import rasterizer
+        for _ in range(3):
+            before = dict(rasterizer._WS.capacity_hint)
+            run_steps(0, max(2, self.n_slots), False)     # every slot: its stream, workspace and frame set exist after this
+            self.sync()
+            if dict(rasterizer._WS.capacity_hint) == before:
+                break
+
+
+class StubEngine:
+    """TEST ONLY (--stub-renderer): a deterministic CPU frame source with the engine's interface, so that the launcher,
+    the sharding, the asynchronous gather, its check and the timing protocol run on 2 gloo ranks without a GPU."""
+    stub = True
+
+    def __init__(self, args, rank, world, dev):
+        import torch
+        self.args, self.rank, self.world, self.torch = args, rank, world, torch
+        self.B = max(1, args.batch)
+        self.n_slots = max(1, args.slots)
+        self.label = "STUB frame source (no rasterizer): launch-path test only"
+        self.W, self.H, self.with_masks, self.pose_seq = 5, 4, True, None
+
+    def frame_ids(self, i):
+        return [((i * self.B + k) * self.world + self.rank) for k in range(self.B)]
+
+    @staticmethod
+    def frames_of(ids, torch):
+        g = torch.tensor(ids, dtype=torch.int64)
+        rgb = (g.view(-1, 1, 1, 1) % 251 + torch.arange(3).view(1, 1, 1, 3)).to(torch.uint8).expand(-1, 4, 5, 3).contiguous()
+        depth = ((g * 7) % 30000).to(torch.int16).view(-1, 1, 1).expand(-1, 4, 5).contiguous()
+        bits = (g % 256).to(torch.uint8).view(-1, 1, 1, 1).expand(-1, 4, 5, 1).contiguous()
+        return {"rgb": rgb, "depth_mm": depth, "mask_bits": bits}
+
+    def enqueue(self, i, slot):
+        ids = self.frame_ids(i)
+
+        class _H:
+            def wait(_self):
+                return ids
+        return _H()
+
+    def step_blocking(self, i, **kw):
+        return self.frame_ids(i)
+
+    def pack(self, ids):
+        return self.frames_of(ids, self.torch)
+
+    def sync(self):
+        pass
+
+    def settle(self, run_steps):
+        run_steps(0, 1, False)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# worker
+
+def _checksums(local):
+    """Per-tensor byte sums (int64) of a packed batch -- what the gather check compares across ranks."""
+    import torch
+    return {k: int(t.contiguous().view(torch.uint8).to(torch.int64).sum().item()) for k, t in local.items()}
+
+
+def run_worker(args):
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    world = int(env_world) if env_world else 1
+    if args.gpus is None:
+        args.gpus = world
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}; refusing to print a mislabelled line")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = "gloo" if args.stub_renderer else args.backend
+    rehearsal = args.stub_renderer or args.share_devices or (world > 1 and backend != "nccl")
+    dev = torch.device("cpu")
+    if not args.stub_renderer:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+        n_dev = torch.cuda.device_count()
+        if local_rank >= n_dev and not args.share_devices:
+            raise SystemExit(f"bench.py: rank {rank} has no device of its own ({n_dev} visible, local rank {local_rank})")
+        if args.share_devices and backend == "nccl" and world > n_dev:
+            raise SystemExit("--share-devices needs --backend gloo (RCCL refuses two ranks on one GPU)")
+        torch.cuda.set_device(local_rank % n_dev)
+        dev = torch.device("cuda", local_rank % n_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+        world = dist.get_world_size()              # the size actually initialised is what the line reports
+    devices = [None]
+    me = {"rank": rank, "device": str(dev)}
+    if dev.type == "cuda":
+        p = torch.cuda.get_device_properties(dev)
+        me.update(name=p.name, total_memory_gb=round(p.total_memory / 2**30, 1), pci_bus_id=getattr(p, "pci_bus_id", None))
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, me)
+    else:
+        devices = [me]
 
-    from pegasus_amd import _lib, frames as F, rasterizer
-    _lib.lib()
+    gather_on = world > 1 and (args.gather if args.gather is not None else True)
+    eng = (StubEngine if args.stub_renderer else RealEngine)(args, rank, world, dev)
+    if args.facade:
+        if world != 1 or eng.stub:
+            raise SystemExit("--facade measures the single-process drop-in path: run it with --gpus 1")
+        d = drop_in_numbers(eng, n_frames=16, n_render_calls=128)
+        print(json.dumps({"metric": "drop-in frames/sec through PEGASUS's per-camera loop (RGB+depth+visible masks+semantic "
+                                    f"mask, one render() per data point) on {eng.cloud.n / 1e6:.2g}M-Gaussian scene @{eng.W}x{eng.H}",
+                          "value": d["frames_per_s"], "unit": "frames/s", "n_gpus": 1, "higher_is_better": True,
+                          "dtype": "f32", "data": "synthetic", "config": {"workload": eng.label, "objects": eng.fr.K},
+                          "drop_in": d}))
+        return 0
+    B, n_slots = eng.B, eng.n_slots
+    gather_state = {"inflight": None, "bytes": 0, "batches": 0}
 
-    # every rank builds the same scene (replicated: 472 MB at 2 M Gaussians) and takes views rank::world
-    B = max(1, args.batch)
-    n_views_total = max(args.views, B) * world
-    cloud, views, label = build_workload(args.workload, args.scale, n_views_total)
-    my_views = views[rank::world] or views
-    act = cloud.activated()
-    fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"],
-                         cloud.object_id, sh_degree=3, device=dev, spatial_order=not args.input_order)
-    fr.serialize_slots = args.serialize_slots
-    fr.n_streams = args.streams or None
-    specs = [fr.view_spec(v) for v in my_views]
-    W, H = my_views[0].width, my_views[0].height
-    P = W * H
-    with_masks = not args.raster_only and fr.K > 0
-    frames = fr.alloc_frames(B, H, W, masks=with_masks)      # frame buffers, reused (two sets: 2-deep pipeline)
-    n_slots = max(1, args.slots)
-    frame_sets = [frames] + [fr.alloc_frames(B, H, W, masks=with_masks) for _ in range(n_slots - 1)]
+    def to_wire(local):
+        return {k: t.cpu() for k, t in local.items()} if (backend == "gloo" and not eng.stub) else local
 
-    def batch_views(i):
-        return [specs[(i * B + k) % len(specs)] for k in range(B)]
-
-    # dynamic sequence (BASELINE.json configs[4]): the whole trajectory exists before rendering starts (the reference
-    # simulates first, /root/reference/pegasus.py:216 then :247); time step s moves object k rigidly about its centre
-    pose_seq = m2w_seq = None
-    if args.dynamic:
-        from scipy.spatial.transform import Rotation as Rot
-        from pegasus_amd.compose import pose_table
-        from pegasus_amd import bop_pose
-        oid = cloud.object_id
-        centers = [act["means3d"][oid == k].mean(0) for k in range(1, fr.K + 1)]
-        S = (2 * (args.warmup + args.steps) + max(1, args.profile_steps) + 1) * B
-        pose_seq = np.zeros((S, fr.K, 20), np.float32)
-        m2w_seq = []
-        for s_i in range(S):
-            pairs, m2w = [], {}
-            for k in range(fr.K):
-                T = np.eye(4)
-                # bounded, periodic motion: the objects spin, rock, slide within a few centimetres and bounce -- the
-                # workload stays the same however long the sequence runs
-                T[:3, :3] = Rot.from_euler("zx", [0.015 * s_i * (1 + 0.1 * k), 0.3 * math.sin(0.013 * s_i + k)]).as_matrix()
-                T[:3, 3] = [0.04 * math.sin(0.02 * s_i + k), 0.04 * math.cos(0.017 * s_i + 2 * k),
-                            0.02 * abs(math.sin(0.05 * s_i + k))]
-                pairs.append((T, centers[k]))
-                C4 = np.eye(4); C4[:3, 3] = centers[k]
-                Ci = np.eye(4); Ci[:3, 3] = -centers[k]
-                m2w[k + 1] = C4 @ T @ Ci            # placement of the (already merged) object at time s
-            pose_seq[s_i] = pose_table(pairs)
-            m2w_seq.append(m2w)
-
-    def batch_poses(i):
-        return None if pose_seq is None else pose_seq[(i * B) % len(pose_seq):(i * B) % len(pose_seq) + B]
-
-    def batch_records(i):
-        if pose_seq is None:
-            return None
-        s0 = (i * B) % len(pose_seq)
-        vs = [my_views[(i * B + k) % len(my_views)] for k in range(B)]
-        return bop_pose.batch_pose_records(vs, m2w_seq[s0:s0 + B])
-
-    def step(i, **kw):
-        if args.separate_semantic:
-            return fr.render_batch(batch_views(i), frames, masks=with_masks, **kw)
-        kw.pop("sem_stage_ms", None)
-        if pose_seq is not None and kw.get("stage_ms") is None:   # (the profiling entry point has no posed variant:
-            kw.pop("stage_ms", None)                              #  stage times are taken on the unposed scene)
-            return fr.render_frames(batch_views(i), frames, masks=with_masks, poses=batch_poses(i), **kw)
-        return fr.render_frames(batch_views(i), frames, masks=with_masks, **kw)
-
-    gather_state = {"inflight": None, "bytes": 0}
-
-    def gather_finished(fr_set):
-        """Quantise a finished batch on the GPU and start its gather to rank 0 (grouped send/recv on RCCL: the peers
-        stream over their own xGMI links); the previous batch's gather is completed first, so one is in flight."""
-        if not (args.gather and world > 1):
-            return
-        from pegasus_amd import masks as M
-        from pegasus_amd import view_shard as VS
+    def finish_inflight():
         if gather_state["inflight"] is not None:
             finish, works = gather_state["inflight"]
             for w_ in works:
                 w_.wait()
-            finish()
-        q = [M.quantize_frame(fr_set["color"][k], fr_set["depth"][k, 0]) for k in range(B)]
-        local = {"rgb": torch.stack([a for a, _ in q]), "depth_mm": torch.stack([b for _, b in q])}
-        if "masks" in fr_set:
-            local["masks"] = fr_set["masks"][:B]
+            out = finish()
+            gather_state["inflight"] = None
+            return out
+        return None
+
+    def gather_finished(token, gather):
+        """Pack a finished batch on the GPU and start its gather to rank 0 (grouped send/recv on RCCL: the peers stream
+        over their own xGMI links); the previous batch's gather is completed first, so one is in flight."""
+        if not gather:
+            return
+        from pegasus_amd import view_shard as VS
+        finish_inflight()
+        local = to_wire(eng.pack(token))
         gather_state["bytes"] = sum(t.numel() * t.element_size() for t in local.values())
+        gather_state["batches"] += 1
         gather_state["inflight"] = VS.gather_frames(local, B * world, dst=0, async_op=True)
 
-    def run_steps(first, count):
-        """`count` steps as an `n_slots`-deep software pipeline: batch i is enqueued (scene pass and semantic pass on two
-        streams, no host sync) while batch i-1 finishes; every batch's overflow status is checked."""
+    def run_steps(first, count, gather):
+        """`count` steps as an `n_slots`-deep software pipeline: batch i is enqueued (no host sync) while batch i-1
+        finishes; every batch's overflow status is checked in wait()."""
         if args.sync_steps:
             for i in range(first, first + count):
-                gather_finished(step(i))
+                gather_finished(eng.step_blocking(i), gather)
+            finish_inflight()
             return
         pending = []                                  # at most n_slots - 1 older batches in flight
         for i in range(first, first + count):
-            render = fr.render_batch_async if args.separate_semantic else fr.render_frames_async
-            if pose_seq is not None:
-                h = fr.render_frames_async(batch_views(i), frame_sets[i % n_slots], masks=with_masks,
-                                           slot=i % n_slots, poses=batch_poses(i))
-                batch_records(i)                  # BOP scene_gt / scene_camera entries of the batch (host, overlapped)
-            else:
-                t_e = time.perf_counter()
-                h = render(batch_views(i), frame_sets[i % n_slots], masks=with_masks, slot=i % n_slots)
+            t_e = time.perf_counter()
+            h = eng.enqueue(i, i % n_slots)
             t_w = time.perf_counter()
             pending.append(h)
             while len(pending) >= n_slots:
-                gather_finished(pending.pop(0).wait())
-            if args.step_log and pose_seq is None:
+                gather_finished(pending.pop(0).wait(), gather)
+            if args.step_log:
                 print(f"step {i}: enqueue {(t_w - t_e) * 1e3:.2f} ms, wait {(time.perf_counter() - t_w) * 1e3:.2f} ms", file=sys.stderr)
         while pending:
-            gather_finished(pending.pop(0).wait())
-        if gather_state["inflight"] is not None:
-            finish, works = gather_state["inflight"]
-            for w_ in works:
-                w_.wait()
-            finish()
-            gather_state["inflight"] = None
+            gather_finished(pending.pop(0).wait(), gather)
+        finish_inflight()
 
-    # set-up, not warm-up: let the workspaces reach their size.  The instance capacity is a hint that grows when a batch
-    # comes close to it (a multi-GB reallocation, tens of ms, once per scene and pipeline slot); small scenes start below
-    # their need (C2: 1 M for views that list 1.4 M) and would otherwise pay that inside the timed region.
-    for _ in range(3):
-        before = dict(rasterizer._WS.capacity_hint)
-        run_steps(0, max(2, n_slots))                 # every slot: its stream, workspace and frame set exist after this
-        torch.cuda.synchronize()
-        if dict(rasterizer._WS.capacity_hint) == before:
-            break
-    run_steps(0, args.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(args.warmup, args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        te = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    def timed(first, count, gather):
+        """EXACTLY `count` steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+        eng.sync()
+        if world > 1:
+            dist.barrier()
+        eng.sync()
+        t0 = time.perf_counter()
+        run_steps(first, count, gather)
+        eng.sync()
+        if world > 1:
+            dist.barrier()
+        eng.sync()
+        el = time.perf_counter() - t0
+        if world > 1:
+            te = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        return el
 
-    # ---- per-view statistics and per-stage HIP-event timing of whole batches (outside the timed region) ----
-    stage_ms = np.zeros((0, _lib.PGR_NUM_STAGES))
-    sem_ms = np.zeros((0, _lib.PGR_NUM_STAGES))
-    stats = []
-    raster_only_fps = None
-    if rank == 0:
-        for i in range(args.profile_steps if args.profile_steps > 0 else min(4, args.steps)):   # N, V, I, evaluations
-            res = rasterizer.forward_views(fr.means3d, fr.opacities, batch_views(args.warmup + i), shs=fr.shs, scales=fr.scales,
-                                           rotations=fr.rotations, sh_degree=3, want_radii=True, want_aux=True)
-            info = rasterizer.last_forward_info()
-            for k, r in enumerate(res):
-                stats.append(dict(V=int((r["radii"] > 0).sum().item()), I=info["num_instances"][k],
-                                  evals=int(r["n_contrib"].sum(dtype=torch.int64).item())))
-            del res
-        rows, srows = [], []
-        prof = (range(args.warmup, args.warmup + args.steps) if args.profile_steps <= 0
-                else range(max(1, args.profile_steps)))
-        for i in prof:
-            ms, sms = [], []
-            step(i, stage_ms=ms, sem_stage_ms=sms)
-            rows.append(ms)
-            srows.append(sms if sms else [0.0] * _lib.PGR_NUM_STAGES)
-        stage_ms, sem_ms = np.asarray(rows), np.asarray(srows)
-        # R: raster-only rate (one full-scene RGB+depth forward per view), for the record next to F
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            fr.render_batch(batch_views(i), frames, masks=False)
-        torch.cuda.synchronize()
-        raster_only_fps = args.steps * B / (time.perf_counter() - t1)
+    eng.settle(run_steps)
+    run_steps(0, args.warmup, gather_on)
+    elapsed = timed(args.warmup, args.steps, gather_on)
+    elapsed_render_only = timed(args.warmup, args.steps, False) if gather_on else None
+
+    # ---- gather check (N > 1, outside the timed region): one more batch through the same pack + gather; rank 0 compares
+    # the byte sums of what it RECEIVED from every rank with the sums those ranks computed on what they SENT
+    gather_check = None
+    if world > 1 and gather_on:
+        from pegasus_amd import view_shard as VS
+        i_chk = args.warmup + args.steps
+        token = eng.step_blocking(i_chk)
+        eng.sync()
+        local = to_wire(eng.pack(token))
+        sums = [None] * world
+        dist.all_gather_object(sums, _checksums(local))
+        got = VS.gather_frames(local, B * world, dst=0)
+        if rank == 0:
+            ok = True
+            for r in range(world):
+                idx = VS.shard_indices(B * world, r, world)
+                ok = ok and _checksums({k: got[k][idx] for k in got}) == sums[r]
+            if eng.stub:                              # the stub's frames are a function of their global id: check content too
+                ids = [((i_chk * B + k) * world + r) for k in range(B) for r in range(world)]
+                want = StubEngine.frames_of(ids, torch)
+                ok = ok and all(torch.equal(got[k], want[k]) for k in want)
+            gather_check = "ok" if ok else "MISMATCH"
+        flag = torch.tensor([0 if (rank != 0 or gather_check == "ok") else 1], device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(flag)
+        if int(flag.item()):
+            raise SystemExit("bench.py: gathered frames differ from what the ranks sent (gather check failed)")
 
     if rank != 0:
         if world > 1:
+            dist.barrier()
             dist.destroy_process_group()
-        return
+        return 0
 
     total_views = args.steps * B * world
     value = total_views / elapsed
-    N = cloud.n
+    line = {
+        "metric": None, "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+    }
+    launcher = ("self: python bench.py --gpus N started torch.distributed.run as a child process"
+                if os.environ.get("PGR_BENCH_LAUNCHER") == "self" else
+                ("external torchrun (WORLD_SIZE in the environment)" if env_world else "single process"))
+    dist_info = {"world_size": world, "backend": ("nccl (RCCL)" if backend == "nccl" else backend) if world > 1 else None,
+                 "launcher": launcher, "devices": devices}
+    gather_info = {"mode": "off (frames stay on the rank that rendered them)"}
+    if gather_on:
+        gather_info = {
+            "mode": "every batch's packed frames gathered to rank 0 inside the timed region, one gather in flight",
+            "payload": "uint8 RGB [H,W,3] + uint16 depth mm [H,W] + K masks as bit planes (ceil(K/8) bytes per pixel)",
+            "bytes_per_rank_and_batch": gather_state["bytes"],
+            "views_per_s_with_gather": round(value, 3),
+            "views_per_s_render_only": round(total_views / elapsed_render_only, 3),
+            "inbound_to_root_gb_per_s": round(gather_state["bytes"] * (world - 1) * args.steps / elapsed / 1e9, 2),
+            "check": gather_check,
+        }
+    if eng.stub:
+        line.update(metric="STUB launch-path test (no rasterizer) -- INVALID as a measurement", stub=True,
+                    config={"workload": eng.label, "views_per_step": B, "parallelism": f"view-shard x{world}",
+                            "distributed": dist_info, "gather": gather_info})
+        print(json.dumps(line))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
+
+    _finish_real_line(args, eng, line, value, world, dist_info, gather_info, rehearsal)
+    print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, rehearsal):
+    """Rank 0, product path: per-view statistics, per-stage HIP-event timing of whole batches, roofline, CPU baseline and
+    the drop-in sample -- all outside the timed region."""
+    import torch
+    from pegasus_amd import _lib, rasterizer
+    fr, B, W, H = eng.fr, eng.B, eng.W, eng.H
+    P = W * H
+    with_masks = eng.with_masks
+    stats = []
+    for i in range(args.profile_steps if args.profile_steps > 0 else min(4, args.steps)):   # N, V, I, evaluations
+        res = rasterizer.forward_views(fr.means3d, fr.opacities, eng.batch_views(args.warmup + i), shs=fr.shs, scales=fr.scales,
+                                       rotations=fr.rotations, sh_degree=3, want_radii=True, want_aux=True)
+        info = rasterizer.last_forward_info()
+        for k, r in enumerate(res):
+            stats.append(dict(V=int((r["radii"] > 0).sum().item()), I=info["num_instances"][k],
+                              evals=int(r["n_contrib"].sum(dtype=torch.int64).item())))
+        del res
+    rows, srows = [], []
+    prof = (range(args.warmup, args.warmup + args.steps) if args.profile_steps <= 0 else range(max(1, args.profile_steps)))
+    for i in prof:
+        ms, sms = [], []
+        eng.step_blocking(i, stage_ms=ms, sem_stage_ms=sms)
+        rows.append(ms)
+        srows.append(sms if sms else [0.0] * _lib.PGR_NUM_STAGES)
+    stage_ms = np.asarray(rows)
+    # R: raster-only rate (one full-scene RGB+depth forward per view), for the record next to F
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        fr.render_batch(eng.batch_views(i), eng.frames, masks=False)
+    torch.cuda.synchronize()
+    raster_only_fps = args.steps * B / (time.perf_counter() - t1)
+
+    N = eng.cloud.n
     V = float(np.mean([s["V"] for s in stats]))
     I = float(np.mean([s["I"] for s in stats]))
     evals = float(np.mean([s["evals"] for s in stats]))
@@ -315,6 +576,7 @@ def main():
     dom_bytes = per_stage_bytes[dom_name] * B / launches
     dom_ms = float(mean_ms[dom]) / launches
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    evals_per_s = evals * B / (mean_ms[4] * 1e-3) if mean_ms[4] > 0 else None
     roofline = {
         "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
@@ -323,89 +585,182 @@ def main():
         "stage_ms_per_view": {k: round(float(m) / B, 4) for k, m in zip(_lib.STAGE_NAMES, mean_ms)},
         "whole_path": {"bytes_per_view": int(B_view), "achieved": round(B_view * value / world / 1e9, 2),
                        "frac": round(B_view * value / world / 1e9 / HBM_PEAK_GBS, 5)},
-        "composite_evals_per_s": round(evals * B / (mean_ms[4] * 1e-3), 1) if mean_ms[4] > 0 else None,
+        # the compositor is VALU-bound: SURVEY.md section 8d's secondary ceiling, evaluations from the n_contrib sums
+        "valu": (None if not evals_per_s else
+                 {"evals_per_s": round(evals_per_s, 1), "lane_ops_per_eval": LANE_OPS_PER_EVAL, "peak": VALU_PEAK_LANE_OPS,
+                  "unit": "lane-op/s", "frac": round(evals_per_s * LANE_OPS_PER_EVAL / VALU_PEAK_LANE_OPS, 4),
+                  "definition": "sum of n_contrib over the batch (pixel-Gaussian evaluations up to each pixel's last blended "
+                                "entry) / composite stage time x 20 lane-ops, against 256 CU x 4 SIMD x 32 lanes x 2.4 GHz"}),
+        "composite_evals_per_s": round(evals_per_s, 1) if evals_per_s else None,
         "semantic": "separate objects-only pass" if args.separate_semantic else
-                    "fused: second accumulator in the scene's compositing walk (stage composite)",
-        "raster_only_views_per_s": round(raster_only_fps, 2) if raster_only_fps else None,
+                    "fused: second accumulator in the scene's compositing walk (stage composite; +16 P bytes of image writes "
+                    "per view that SURVEY's 44 I + 16 P does not count)",
+        "raster_only_views_per_s": round(raster_only_fps, 2),
         "N": N, "V": round(V), "I": round(I), "P": P,
     }
-
-    # HBM-side traffic of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-    # (separate passes, gfx950 unit = KiB; see profiles/README.md), committed as profiles/pmc_traffic.json
+    # HBM-side traffic and unit utilisation of the dominant kernel: rocprofv3 --pmc passes of this same command (separate
+    # passes per counter group, gfx950 unit and FETCH_SIZE corrections: profiles/README.md), written by
+    # scripts/pmc_profile.sh -> scripts/pmc_report.py as ONE file, so the numbers here and the committed text summary
+    # cannot diverge
     try:
-        pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
-        k = pmc["kernels"].get(dom_name)
-        if k and pmc.get("workload") == args.workload and pmc.get("batch") == B:
-            roofline["traffic"] = int(k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"])
+        pmc = json.loads((ROOT / "profiles" / "pmc.json").read_text())
+        kern = pmc["stage_kernel"].get(dom_name)
+        k = pmc["kernels"].get(kern) if kern else None
+        fused_default = with_masks and not args.separate_semantic
+        if k and pmc.get("workload") == args.workload and pmc.get("batch") == B and pmc.get("fused") == fused_default:
+            roofline["traffic"] = int(k["traffic_bytes_per_launch"])
+            roofline["traffic_detail"] = {kk: k[kk] for kk in ("kernel", "dispatches", "fetch_size_kib_per_launch",
+                                                               "write_size_kib_per_launch") if kk in k}
+            roofline["traffic_detail"]["kernel"] = kern
             roofline["traffic_source"] = pmc["source"]
-    except (OSError, ValueError, KeyError):
-        pass
-    # the compositor is not bound by either roofline the schema names (HBM / MFMA): report beside them how busy the unit
-    # that does bound it is -- VALU issue slots from the SQ counters (profiles/pmc_busy.json, scripts/pmc_busy.py)
-    try:
-        busy = json.loads((ROOT / "profiles" / "pmc_busy.json").read_text())
-        k = next((v for name, v in busy["kernels"].items() if dom_name == "composite" and "composite_quarter_kernel<false, false>" in name), None)
-        if k:
-            roofline["valu_issue"] = {"busy_frac": k["valu_busy"], "lds_busy_frac": k["lds_busy"],
-                                      "kernel": "composite_quarter_kernel<false, false> (raster-only twin of the fused kernel)",
-                                      "definition": "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles); SQ_LDS_IDX_ACTIVE / (256 CUs x kernel cycles)",
-                                      "source": busy["source"]}
+            if "valu_busy" in k:
+                roofline["valu_issue"] = {"busy_frac": k["valu_busy"], "lds_busy_frac": k.get("lds_busy"), "kernel": kern,
+                                          "definition": pmc.get("busy_definition")}
     except (OSError, ValueError, KeyError):
         pass
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        import oracle
-        oracle.build()
-        cores = os.cpu_count() or 1
-        n_done, t_cpu = 0, 0.0
-        n_env = fr.n_env
-        sem_shs = fr.sem_shs.cpu().numpy() if with_masks else None
-        while n_done < len(my_views) and (n_done == 0 or t_cpu + t_cpu / n_done < args.cpu_budget_s):
-            v = my_views[n_done]
-            t1 = time.perf_counter()
-            oracle.forward(**act, sh_degree=3, **v.raster_kwargs(), num_threads=cores, want_binning=False)
-            if with_masks:
-                seg = oracle.forward(act["means3d"][n_env:], act["opacities"][n_env:], scales=act["scales"][n_env:],
-                                     rotations=act["rotations"][n_env:], shs=sem_shs, sh_degree=0,
-                                     **v.raster_kwargs(), num_threads=cores, want_binning=False)
-                oracle.color_masks(seg["color"], fr.colors_np, 0.1)
-            t_cpu += time.perf_counter() - t1
-            n_done += 1
-        try:
-            cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
-        except (OSError, StopIteration):
-            cpu_model = "unknown"
-        cpu = {"value": round(n_done / t_cpu, 4), "unit": "frames/s" if with_masks else "views/s", "cores": cores,
-               "kind": "port", "cpu_model": cpu_model,
-               "sample": f"first {n_done} frame(s) of the same scene and cameras, oracle/pgr_oracle.c with OpenMP "
-                         f"({cores} threads), reference-style lists; no reference CPU rasterizer exists"}
+        cpu = _cpu_baseline(args, eng)
+    drop_in = None
+    if world == 1 and not args.no_drop_in and with_masks and not args.dynamic and args.workload in ("c3", "c5"):
+        drop_in = drop_in_numbers(eng, n_frames=4, n_render_calls=48)
 
-    line = {
-        "metric": (f"rendered views/sec (RGB+depth+mask) on {N / 1e6:.2g}M-Gaussian scene @{W}x{H}" if with_masks else
-                   f"rendered views/sec (RGB+depth, raster only) on {N / 1e6:.2g}M-Gaussian scene @{W}x{H}"),
-        "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": label, "gaussians": N, "width": W, "height": H, "views_per_step": B,
-                   "distinct_views": len(my_views), "objects": fr.K,
-                   "sequence": ("dynamic: every frame is a time step with its own object poses (posed inside the "
-                                "preprocess) + BOP pose records" if args.dynamic else "static scene, camera batches"),
-                   "scene_layout": ("input order" if fr.order is None else
-                                    "Morton order per object (one-time, at scene load, outside the timed region)"),
-                   "outputs": ("color[3,H,W] f32 + depth[1,H,W] f32 + semantic image[3,H,W] f32 + masks[K,H,W] u8"
-                               if with_masks else "color[3,H,W] f32 + depth[1,H,W] f32"),
-                   "parallelism": f"view-shard x{world}",
-                   "gather": (f"every batch's quantised frames gathered to rank 0 inside the timed region "
-                              f"({gather_state['bytes'] / 1e6:.0f} MB per rank and batch)" if args.gather and world > 1 else
-                              "off (frames stay on the rank that rendered them)")},
-        "roofline": roofline,
-        "cpu_baseline": cpu,
-    }
-    print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    N_label = f"{N / 1e6:.2g}M"
+    line.update(
+        metric=(f"rendered views/sec (RGB+depth+mask) on {N_label}-Gaussian scene @{W}x{H}" if with_masks else
+                f"rendered views/sec (RGB+depth, raster only) on {N_label}-Gaussian scene @{W}x{H}"),
+        config={"workload": eng.label, "gaussians": N, "width": W, "height": H, "views_per_step": B,
+                "distinct_views": len(eng.views) // world, "objects": fr.K,
+                "sequence": (f"dynamic: every frame is a time step of the reference's recorded drop (simulation_steps.json "
+                             f"body 1, steps 0..{SEQUENCE_STEPS - 1}, per-object phase offsets; poses composed absolutely and "
+                             f"applied inside the preprocess) + BOP pose records" if args.dynamic else
+                             "static scene, camera batches"),
+                "scene_layout": ("input order" if fr.order is None else
+                                 "Morton order per object (one-time, at scene load, outside the timed region)"),
+                "outputs": ("color[3,H,W] f32 + depth[1,H,W] f32 + semantic image[3,H,W] f32 + masks[K,H,W] u8"
+                            if with_masks else "color[3,H,W] f32 + depth[1,H,W] f32"),
+                "parallelism": f"view-shard x{world}", "distributed": dist_info, "gather": gather_info},
+        roofline=roofline, cpu_baseline=cpu, drop_in=drop_in)
+    if rehearsal:
+        line["rehearsal"] = ("NOT a result: ranks share devices and/or the gather runs on gloo through host memory; "
+                             "only the launch, sharding and gather logic is exercised")
+
+
+def _cpu_baseline(args, eng):
+    import oracle
+    oracle.build()
+    fr, act = eng.fr, eng.act
+    cores = os.cpu_count() or 1
+    n_done, t_cpu = 0, 0.0
+    n_env = fr.n_env
+    with_masks = eng.with_masks
+    sem_shs = fr.sem_shs.cpu().numpy() if with_masks else None
+    oid = eng.cloud.object_id
+    while n_done < len(eng.views) and (n_done == 0 or t_cpu + t_cpu / n_done < args.cpu_budget_s):
+        v = eng.views[n_done]
+        posed = {} if eng.pose_seq is None else dict(object_id=oid, poses=eng.pose_seq[n_done % SEQUENCE_STEPS])
+        t1 = time.perf_counter()
+        oracle.forward(**act, sh_degree=3, **v.raster_kwargs(), num_threads=cores, want_binning=False, **posed)
+        if with_masks:
+            posed_o = {} if eng.pose_seq is None else dict(object_id=oid[n_env:], poses=eng.pose_seq[n_done % SEQUENCE_STEPS])
+            seg = oracle.forward(act["means3d"][n_env:], act["opacities"][n_env:], scales=act["scales"][n_env:],
+                                 rotations=act["rotations"][n_env:], shs=sem_shs, sh_degree=0,
+                                 **v.raster_kwargs(), num_threads=cores, want_binning=False, **posed_o)
+            oracle.color_masks(seg["color"], fr.colors_np, 0.1)
+        t_cpu += time.perf_counter() - t1
+        n_done += 1
+    try:
+        cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except (OSError, StopIteration):
+        cpu_model = "unknown"
+    return {"value": round(n_done / t_cpu, 4), "unit": "frames/s" if with_masks else "views/s", "cores": cores,
+            "kind": "port", "cpu_model": cpu_model,
+            "sample": f"first {n_done} frame(s) of the same scene and cameras, oracle/pgr_oracle.c with OpenMP "
+                      f"({cores} threads), reference-style lists; no reference CPU rasterizer exists"}
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# the drop-in path: what unchanged PEGASUS calls
+
+def drop_in_numbers(eng, n_frames=4, n_render_calls=48):
+    """PEGASUS's own per-camera loop on this scene (/root/reference/pegasus.py:254-358): per frame one deepcopy + merge of
+    the scene, then render_rgb_and_depth, render_visib_mask and render_semanticsegmentation_mask through
+    pegasus_amd/render.py's wrappers (same names and arguments as /root/reference/src/gs/render.py) -- and the latency of a
+    single gaussian_renderer.render() call over the merged model."""
+    import copy
+    import torch
+    from argparse import ArgumentParser
+    sys.path.insert(0, str(ROOT / "compat"))
+    from pegasus_amd import render as RW
+    from pegasus_amd import gaussian_renderer as GR
+    from pegasus_amd.cameras import Camera
+    from pegasus_amd.gaussian_model import GaussianModel
+    from pegasus_amd import masks as M
+    from arguments import PipelineParams
+    dev, cloud = eng.dev, eng.cloud
+    oid = cloud.object_id
+    K = int(oid.max())
+
+    def model(sel):
+        return GaussianModel.from_arrays(cloud.xyz[sel], cloud.features_dc[sel], cloud.features_rest[sel], cloud.opacity[sel],
+                                         cloud.scaling[sel], cloud.rotation[sel], device=dev)
+    env = model(oid == 0)
+    objects = {k: model(oid == k) for k in range(1, K + 1)}
+    colors = M.generate_colors(K)
+    RW.assign_semantic_colors(objects, colors)
+    color_set = torch.as_tensor(colors, device=dev)
+    cams = [Camera(colmap_id=i, R=v.R_c2w, T=v.t_w2c, FoVx=v.fovx, FoVy=v.fovy, image=None, image_width=v.width,
+                   image_height=v.height, gt_alpha_mask=None, image_name=str(i), uid=i, data_device=dev)
+            for i, v in enumerate(eng.views[:max(n_frames + 1, n_render_calls)])]
+    pipe = PipelineParams(ArgumentParser())
+    bg = torch.zeros(3, device=dev)
+    H, W = eng.H, eng.W
+
+    def frame(cam):
+        scene = copy.deepcopy(env)                                   # pegasus.py:255-264
+        for obj in objects.values():
+            obj._features_dc = copy.deepcopy(obj._features_dc_color)
+            obj._features_rest = copy.deepcopy(obj._features_rest_color)
+            scene.merge_gaussians(gaussian=obj)
+        rgb, depth = RW.render_rgb_and_depth(cam, scene, pipe, bg)
+        masks, seg = RW.render_visib_mask(cam, env, objects, color_set, H, W, pipe, bg)
+        sem = RW.render_semanticsegmentation_mask(cam, env, objects, color_set, H, W, pipe, bg, False)
+        return scene
+
+    with torch.no_grad():
+        scene = frame(cams[0])                                       # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for c in cams[1:n_frames + 1]:
+            scene = frame(c)
+        torch.cuda.synchronize()
+        t_frame = (time.perf_counter() - t0) / n_frames
+        for c in cams[:4]:
+            GR.render(c, scene, pipe, bg)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for c in cams[:n_render_calls]:
+            GR.render(c, scene, pipe, bg)
+        torch.cuda.synchronize()
+        t_call = (time.perf_counter() - t0) / min(n_render_calls, len(cams))
+    return {"frames_per_s": round(1.0 / t_frame, 2), "ms_per_frame": round(t_frame * 1e3, 3),
+            "render_call_ms": round(t_call * 1e3, 4), "render_calls_per_s": round(1.0 / t_call, 1),
+            "frame": "deepcopy + merge of the scene, render_rgb_and_depth, render_visib_mask (K masks to the host as float64, "
+                     "as the reference returns them) and render_semanticsegmentation_mask -- the ['rgb','seg_vis','sem_seg'] "
+                     "data points of /root/reference/pegasus.py:254-358, one camera per frame",
+            "sample": f"{n_frames} frames, {min(n_render_calls, len(cams))} render() calls; same scene and cameras as the batch path"}
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if (args.gpus or 1) > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, argv)
+    if args.facade:
+        args.no_cpu_baseline = True
+    return run_worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

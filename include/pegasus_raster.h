@@ -275,6 +275,18 @@ int32_t pgr_color_masks(const float *img_chw, int32_t n_images, int32_t width, i
 int32_t pgr_quantize_frame(const float *img_chw, const float *depth_hw, int32_t width, int32_t height,
                            uint8_t *rgb_hwc, uint16_t *depth_mm_hw, void *stream);
 
+/* Batch form of pgr_quantize_frame plus the K per-object masks of every frame as bit planes -- one launch turns a
+ * finished batch into what leaves the GPU (the writer threads of /root/reference/pegasus.py:346-358, or the gather of
+ * finished frames to the root rank):
+ *   rgb_bhwc[b]      = uint8(color[b] * 255)   (wraps, no clamp)        color_b3hw  [n_images,3,H,W]
+ *   depth_mm_bhw[b]  = uint16(depth[b] * 1000)                          depth_bhw   [n_images,H,W]
+ *   mask_bits_bhwj[b,y,x,j] bit (m % 8) = masks[b,m,y,x] != 0, j = m / 8   masks_bkhw  [n_images,k,H,W] of
+ *                      pgr_color_masks; ceil(k/8) bytes per pixel (one byte for the usual k <= 8 objects)
+ * Each input/output pair may be NULL (both or neither). */
+int32_t pgr_pack_frames(const float *color_b3hw, const float *depth_bhw, const uint8_t *masks_bkhw, int32_t n_images,
+                        int32_t k, int32_t width, int32_t height, uint8_t *rgb_bhwc, uint16_t *depth_mm_bhw,
+                        uint8_t *mask_bits_bhwj, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -539,4 +539,37 @@ __global__ void quantize_kernel(const float* __restrict__ img, const float* __re
     }
 }
 
+// Batch form of the two casts plus the K visibility masks of a frame as bit planes: one launch turns a finished batch
+// into what leaves the GPU (disk writers, or the gather to the root rank: SURVEY.md section 8e's 3.84 MB per 800x800
+// frame = u8 x 3 + u16 + one mask byte).  grid.y = image; mask byte j of a pixel holds masks 8j .. 8j+7 (bit k % 8).
+__global__ void pack_frames_kernel(const float* __restrict__ color, const float* __restrict__ depth,
+                                   const uint8_t* __restrict__ masks, size_t P, int k, uint8_t* __restrict__ rgb_hwc,
+                                   uint16_t* __restrict__ depth_mm, uint8_t* __restrict__ mask_bits) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const size_t b = blockIdx.y;
+    if (color && rgb_hwc) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = color[(b * 3 + c) * P + p] * 255.0f;
+            v = fminf(fmaxf(v, -2147483520.0f), 2147483520.0f);
+            rgb_hwc[(b * P + p) * 3 + c] = (uint8_t)((int)v & 0xFF);
+        }
+    }
+    if (depth && depth_mm) {
+        float v = depth[b * P + p] * 1000.0f;
+        v = fminf(fmaxf(v, -2147483520.0f), 2147483520.0f);
+        depth_mm[b * P + p] = (uint16_t)((int)v & 0xFFFF);
+    }
+    if (masks && mask_bits) {
+        const int bytes = (k + 7) / 8;
+        for (int j = 0; j < bytes; ++j) {
+            uint32_t bits = 0;
+            for (int m = 8 * j; m < min(k, 8 * j + 8); ++m)
+                bits |= (masks[(b * (size_t)k + m) * P + p] ? 1u : 0u) << (m & 7);
+            mask_bits[(b * P + p) * bytes + j] = (uint8_t)bits;
+        }
+    }
+}
+
 }  // namespace pgr

@@ -616,6 +616,20 @@ int32_t pgr_quantize_frame(const float* img_chw, const float* depth_hw, int32_t 
     return hip_ok(hipGetLastError(), "quantize launch") ? PGR_OK : PGR_ERR_LAUNCH_FAILURE;
 }
 
+int32_t pgr_pack_frames(const float* color_b3hw, const float* depth_bhw, const uint8_t* masks_bkhw, int32_t n_images,
+                        int32_t k, int32_t width, int32_t height, uint8_t* rgb_bhwc, uint16_t* depth_mm_bhw,
+                        uint8_t* mask_bits_bhwj, void* stream_v) {
+    if (n_images < 0 || n_images > 65535 || width <= 0 || height <= 0 || k < 0 ||
+        ((color_b3hw == nullptr) != (rgb_bhwc == nullptr)) || ((depth_bhw == nullptr) != (depth_mm_bhw == nullptr)) ||
+        ((masks_bkhw == nullptr) != (mask_bits_bhwj == nullptr)) || (masks_bkhw && k == 0))
+        return PGR_ERR_INVALID_ARGUMENT;
+    if (n_images == 0) return PGR_OK;
+    const size_t P = (size_t)width * height;
+    pack_frames_kernel<<<dim3((unsigned)((P + 255) / 256), n_images), 256, 0, static_cast<hipStream_t>(stream_v)>>>(
+        color_b3hw, depth_bhw, masks_bkhw, P, k, rgb_bhwc, depth_mm_bhw, mask_bits_bhwj);
+    return hip_ok(hipGetLastError(), "pack_frames launch") ? PGR_OK : PGR_ERR_LAUNCH_FAILURE;
+}
+
 }  // extern "C"
 
 #ifdef PGR_COMP_STATS

@@ -74,3 +74,41 @@ def quantize_frame(img_chw: torch.Tensor, depth: torch.Tensor):
                                         C.c_void_p(rgb.data_ptr()), C.c_void_p(mm.data_ptr()), _stream(img.device)),
                    "pgr_quantize_frame")
     return rgb, mm
+
+
+def pack_frames(color: torch.Tensor = None, depth: torch.Tensor = None, masks: torch.Tensor = None) -> dict:
+    """One launch for a whole finished batch (pgr_pack_frames): ``color`` [B,3,H,W] -> "rgb" uint8 [B,H,W,3],
+    ``depth`` [B,1,H,W] -> "depth_mm" int16 storage of uint16 millimetres [B,H,W] (both exactly the reference's numpy
+    casts, /root/reference/pegasus.py:347,355), ``masks`` uint8 [B,K,H,W] -> "mask_bits" uint8 [B,H,W,ceil(K/8)] with
+    mask m in bit m % 8 of byte m // 8.  The outputs are NEW tensors: a frame set may be re-rendered while they travel."""
+    L = _lib.lib()
+    ref = next(t for t in (color, depth, masks) if t is not None)
+    if ref.device.type != "cuda":
+        raise RuntimeError("pack_frames needs HIP device tensors; there is no CPU path")
+    dev = ref.device
+    B, (H, W) = int(ref.shape[0]), ref.shape[-2:]
+    out, ptr = {}, lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    if color is not None:
+        color = color.contiguous().float()
+        out["rgb"] = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev)
+    if depth is not None:
+        depth = depth.contiguous().float()
+        out["depth_mm"] = torch.empty((B, H, W), dtype=torch.int16, device=dev)
+    K = 0
+    if masks is not None:
+        masks = masks.contiguous()
+        if masks.dtype != torch.uint8:
+            raise ValueError("masks must be uint8 [B,K,H,W] (pgr_color_masks output)")
+        K = int(masks.shape[1])
+        out["mask_bits"] = torch.empty((B, H, W, (K + 7) // 8), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.pgr_pack_frames(ptr(color), ptr(depth), ptr(masks), B, K, W, H, ptr(out.get("rgb")),
+                                     ptr(out.get("depth_mm")), ptr(out.get("mask_bits")), _stream(dev)),
+                   "pgr_pack_frames")
+    return out
+
+
+def unpack_mask_bits(mask_bits: torch.Tensor, k: int) -> torch.Tensor:
+    """Inverse of pack_frames' mask packing: uint8 [B,H,W,ceil(k/8)] -> uint8 [B,k,H,W] (any device; host writers)."""
+    planes = [(mask_bits[..., m // 8] >> (m % 8)) & 1 for m in range(k)]
+    return torch.stack(planes, 1) if planes else mask_bits.new_zeros((mask_bits.shape[0], 0) + tuple(mask_bits.shape[1:3]))

@@ -1,0 +1,72 @@
+"""bench.py's N > 1 path without a GPU: `python bench.py --gpus 2` must start its own two ranks (no outer wrapper), report
+the world size it actually initialised, run the per-batch gather inside the timed region and verify what arrived.  The
+frame source is bench.py's --stub-renderer (the rasterizer has no CPU path by design); everything else -- launcher,
+argument handling, sharding, asynchronous gather, gather check, timing protocol, JSON line -- is the code the GPU run uses."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _run(cmd, env=None, timeout=300):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run(cmd, cwd=str(ROOT), env=e, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+def test_gpus_2_launches_two_ranks_by_itself_and_gathers():
+    p, line = _run([sys.executable, "bench.py", "--gpus", "2", "--stub-renderer", "--steps", "3", "--warmup", "1", "--batch", "4"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len([l for l in p.stdout.splitlines() if l.startswith("{")]) == 1          # ONE line, from rank 0
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    d = line["config"]["distributed"]
+    assert d["world_size"] == 2 and d["launcher"].startswith("self")
+    assert [x["rank"] for x in d["devices"]] == [0, 1]
+    g = line["config"]["gather"]
+    assert g["check"] == "ok" and g["bytes_per_rank_and_batch"] == 4 * 4 * 5 * (3 + 2 + 1)
+    assert g["views_per_s_with_gather"] == line["value"] and g["views_per_s_render_only"] > 0
+    assert line["value"] > 0 and abs(line["ms_per_step"] * 3 * line["value"] / 1e3 - 3 * 4 * 2) < 0.05
+    assert line.get("stub") is True and "INVALID" in line["metric"]
+
+
+def test_outer_torchrun_and_no_gather():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", "bench.py", "--gpus", "2", "--stub-renderer", "--steps", "2", "--warmup", "0",
+           "--batch", "3", "--no-gather", "--sync-steps"]
+    p, line = _run(cmd)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["config"]["distributed"]["launcher"].startswith("external")
+    assert line["config"]["gather"]["mode"].startswith("off")
+
+
+def test_world_size_mismatch_is_refused():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29612", "bench.py", "--gpus", "4", "--stub-renderer", "--steps", "1", "--warmup", "0"]
+    p, line = _run(cmd)
+    assert p.returncode != 0 and line is None
+    assert "WORLD_SIZE=2 but --gpus 4" in p.stderr
+
+
+def test_more_ranks_than_devices_fails_loudly():
+    """The container has no HIP device: `--gpus 2` of the real renderer must refuse instead of printing an N = 1 line."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("needs fewer than 2 devices")
+    p, line = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert p.returncode == 2 and line is None
+    assert "HIP device(s) visible" in p.stderr
+
+
+def test_single_rank_stub_has_no_gather():
+    p, line = _run([sys.executable, "bench.py", "--stub-renderer", "--steps", "2", "--warmup", "1", "--batch", "2"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line["n_gpus"] == 1 and line["config"]["gather"]["mode"].startswith("off")
+    assert line["config"]["distributed"]["launcher"] == "single process"
