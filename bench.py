@@ -717,15 +717,28 @@ def drop_in_numbers(eng, n_frames=4, n_render_calls=48):
     bg = torch.zeros(3, device=dev)
     H, W = eng.H, eng.W
 
-    def frame(cam):
+    parts = {"compose": 0.0, "render_rgb_and_depth": 0.0, "render_visib_mask": 0.0, "render_semanticsegmentation_mask": 0.0}
+
+    def lap(name, t_prev):
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        parts[name] += now - t_prev
+        return now
+
+    def frame(cam, clock=False):
+        t = time.perf_counter()
         scene = copy.deepcopy(env)                                   # pegasus.py:255-264
         for obj in objects.values():
             obj._features_dc = copy.deepcopy(obj._features_dc_color)
             obj._features_rest = copy.deepcopy(obj._features_rest_color)
             scene.merge_gaussians(gaussian=obj)
+        t = lap("compose", t) if clock else t
         rgb, depth = RW.render_rgb_and_depth(cam, scene, pipe, bg)
+        t = lap("render_rgb_and_depth", t) if clock else t
         masks, seg = RW.render_visib_mask(cam, env, objects, color_set, H, W, pipe, bg)
+        t = lap("render_visib_mask", t) if clock else t
         sem = RW.render_semanticsegmentation_mask(cam, env, objects, color_set, H, W, pipe, bg, False)
+        t = lap("render_semanticsegmentation_mask", t) if clock else t
         return scene
 
     with torch.no_grad():
@@ -736,6 +749,8 @@ def drop_in_numbers(eng, n_frames=4, n_render_calls=48):
             scene = frame(c)
         torch.cuda.synchronize()
         t_frame = (time.perf_counter() - t0) / n_frames
+        for c in cams[1:n_frames + 1]:                               # once more with a synchronisation after every part
+            frame(c, clock=True)
         for c in cams[:4]:
             GR.render(c, scene, pipe, bg)
         torch.cuda.synchronize()
@@ -746,6 +761,7 @@ def drop_in_numbers(eng, n_frames=4, n_render_calls=48):
         t_call = (time.perf_counter() - t0) / min(n_render_calls, len(cams))
     return {"frames_per_s": round(1.0 / t_frame, 2), "ms_per_frame": round(t_frame * 1e3, 3),
             "render_call_ms": round(t_call * 1e3, 4), "render_calls_per_s": round(1.0 / t_call, 1),
+            "ms_per_part": {k: round(v / n_frames * 1e3, 3) for k, v in parts.items()},
             "frame": "deepcopy + merge of the scene, render_rgb_and_depth, render_visib_mask (K masks to the host as float64, "
                      "as the reference returns them) and render_semanticsegmentation_mask -- the ['rgb','seg_vis','sem_seg'] "
                      "data points of /root/reference/pegasus.py:254-358, one camera per frame",

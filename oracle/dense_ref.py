@@ -8,7 +8,47 @@ import math
 
 import numpy as np
 
-from pegasus_amd.sh_utils import sh_basis
+
+def real_sh_basis(deg, d):
+    """Real spherical harmonics Y_l^m(d), l = 0..deg, m = -l..l, of a unit direction d -- derived here from first
+    principles in float64 (associated Legendre functions + the orthonormalisation factor from factorials), NOT from the
+    product's constant table (pegasus_amd/sh_utils.py) or the oracle's (oracle/pgr_oracle.c): a wrong constant or sign in
+    either shows up as a disagreement with this function (tests/test_oracle_kat.py).
+
+        Y_l^0  = K_l^0 P_l^0(cos t)
+        Y_l^m  = sqrt(2) K_l^m  cos(m p)  P_l^m(cos t)      m > 0
+        Y_l^-m = sqrt(2) K_l^m  sin(m p)  P_l^m(cos t)      m > 0
+        K_l^m  = sqrt((2 l + 1) / (4 pi) * (l - m)! / (l + m)!)
+
+    with P_l^m INCLUDING the Condon-Shortley phase (-1)^m -- the convention of the 3DGS paper's colour model
+    (band 1 = (-y, z, -x) * sqrt(3 / 4 pi)), cited at /root/reference/README.md:285-299."""
+    x, y, z = (float(v) for v in d)
+    ct = max(-1.0, min(1.0, z))
+    st = math.sqrt(max(0.0, 1.0 - ct * ct))
+    phi = math.atan2(y, x)
+    # P_m^m = (-1)^m (2m-1)!! sin^m ; P_{m+1}^m = x (2m+1) P_m^m ; (l-m) P_l^m = x (2l-1) P_{l-1}^m - (l+m-1) P_{l-2}^m
+    P = {}
+    for m in range(deg + 1):
+        pmm = 1.0
+        for k in range(1, m + 1):
+            pmm *= -(2 * k - 1) * st
+        P[(m, m)] = pmm
+        if m + 1 <= deg:
+            P[(m + 1, m)] = ct * (2 * m + 1) * pmm
+        for l in range(m + 2, deg + 1):
+            P[(l, m)] = (ct * (2 * l - 1) * P[(l - 1, m)] - (l + m - 1) * P[(l - 2, m)]) / (l - m)
+    out = []
+    for l in range(deg + 1):
+        for m in range(-l, l + 1):
+            a = abs(m)
+            K = math.sqrt((2 * l + 1) / (4 * math.pi) * math.factorial(l - a) / math.factorial(l + a))
+            if m == 0:
+                out.append(K * P[(l, 0)])
+            elif m > 0:
+                out.append(math.sqrt(2.0) * K * math.cos(a * phi) * P[(l, a)])
+            else:
+                out.append(math.sqrt(2.0) * K * math.sin(a * phi) * P[(l, a)])
+    return np.asarray(out, dtype=np.float64)
 
 
 def quat_R(q):
@@ -59,7 +99,7 @@ def dense_forward(means3d, opacities, scales, rotations, shs, sh_degree, width, 
             continue
         d = means3d[i] - campos
         d = d / np.linalg.norm(d)
-        b = sh_basis(sh_degree, d)
+        b = real_sh_basis(sh_degree, d)
         rgb = np.maximum(b @ shs[i, :b.shape[0]] + 0.5, 0.0)
         recs.append((t[2], i, pix, conic, opacities[i], rgb, (minx, miny, maxx, maxy)))
     recs.sort(key=lambda r: (np.float32(r[0]), r[1]))

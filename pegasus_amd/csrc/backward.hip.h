@@ -179,17 +179,21 @@ __global__ __launch_bounds__(WAVE) void composite_backward_block_kernel(
             for (int c = 0; c < 3; ++c) S[c] += quad(cinc[c], QP_3333{});
             SD += quad(cinc[3], QP_3333{});
             // sums over the 16 pixels: lanes 4 apart inside a row of 16, then the four rows through LDS
-            asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]));
+            // A DPP operand read needs two wait states after the VALU write of that register.  Both row steps and the s_nop
+            // in front of them are ONE asm statement: the hazard recognizer does not look into inline asm, and between separate
+            // statements the compiler may place register copies for the "+v" operands (a v_mov right in front of a DPP read of
+            // its destination).  Inside the block every register's two steps are ten instructions apart.
 #define PGR_ROW_STEP(CTRL)                                                                                                  \
-    asm volatile("v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\tv_add_f32_dpp %2, %2, %2 " CTRL       \
-                 "\n\tv_add_f32_dpp %3, %3, %3 " CTRL "\n\tv_add_f32_dpp %4, %4, %4 " CTRL "\n\tv_add_f32_dpp %5, %5, %5 " CTRL   \
-                 "\n\tv_add_f32_dpp %6, %6, %6 " CTRL "\n\tv_add_f32_dpp %7, %7, %7 " CTRL "\n\tv_add_f32_dpp %8, %8, %8 " CTRL   \
-                 "\n\tv_add_f32_dpp %9, %9, %9 " CTRL                                                                        \
-                 : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]))
-            PGR_ROW_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-            PGR_ROW_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    "v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\tv_add_f32_dpp %2, %2, %2 " CTRL "\n\t"            \
+    "v_add_f32_dpp %3, %3, %3 " CTRL "\n\tv_add_f32_dpp %4, %4, %4 " CTRL "\n\tv_add_f32_dpp %5, %5, %5 " CTRL "\n\t"            \
+    "v_add_f32_dpp %6, %6, %6 " CTRL "\n\tv_add_f32_dpp %7, %7, %7 " CTRL "\n\tv_add_f32_dpp %8, %8, %8 " CTRL "\n\t"            \
+    "v_add_f32_dpp %9, %9, %9 " CTRL "\n\t"
+            asm volatile("s_nop 1\n\t"
+                         PGR_ROW_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                         PGR_ROW_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                         : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                           "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]));
 #undef PGR_ROW_STEP
-            asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]));
             if ((lane & 12) == 12) {
 #pragma unroll
                 for (int k = 0; k < 10; ++k) s_red[k * 16 + (lane >> 4) * 4 + slot] = acc[k];

@@ -132,11 +132,17 @@ class FrameRenderer:
             for i in range(B):
                 outs[i]["sem_color"], outs[i]["sem_depth"] = frames["seg"][i], frames["seg_depth"][i]
         st.wait_stream(cur)
+        posed = self._posed(poses, B)
+        if posed is not None:
+            # allocated on the caller's stream, read on the slot stream: tell the caching allocator, so that a caller who drops
+            # its pose tensor right after this call cannot have the memory recycled under the running batch.  (The view
+            # specs' matrices and every other argument are referenced by the returned handle until wait().)
+            posed["poses"].record_stream(st)
         with torch.cuda.stream(st):
             h = R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales, tie_index=self.tie_index,
                                 rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False, outputs=outs,
                                 async_slot=("frames", slot), semantic=self.semantic if fused else None,
-                                posed=self._posed(poses, B))
+                                posed=posed)
             if fused:
                 M.color_masks(frames["seg"][:B], self.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])
             ev = torch.cuda.Event()
@@ -150,6 +156,7 @@ class FrameRenderer:
 
         class _Pending:
             event = ev
+            _args = (specs, posed)       # keeps the caller's device tensors alive while the batch runs
 
             def wait(self_inner):
                 h.wait()

@@ -1,10 +1,13 @@
-"""``gaussian_renderer.render`` counterpart: the facade every PEGASUS render path goes through
+"""``gaussian_renderer.render``: the one function every PEGASUS render path goes through
 (/root/reference/src/gs/render.py:16,57,86,118; /root/reference/pegasus.py:271;
 /root/reference/src/gs/gs_viewer.py:66; /root/reference/src/visualization/object_visualization.py:623).
 
-Contract fixed by its callers: returns a dict with "render" [3,H,W], "depth" [1,H,W],
-"viewspace_points", "visibility_filter" (radii > 0), "radii" (src/gs/render.py:16-17,
-src/gs/dev/gs_manipulation_static.py:311-315)."""
+Its contract is fixed by those callers: ``render(camera, model, pipe, bg, scaling_modifier=1.0, override_color=None)``
+returns a dict with "render" [3,H,W], "depth" [1,H,W], "viewspace_points", "visibility_filter" (radii > 0) and "radii"
+(/root/reference/src/gs/render.py:16-17, /root/reference/src/gs/dev/gs_manipulation_static.py:311-315).  The body below
+is this build's own: three small input builders (view, geometry, colour) in front of the drop-in rasterizer, with the
+model's activated parameters kept between calls of an unchanged model.
+"""
 from __future__ import annotations
 
 import math
@@ -13,85 +16,89 @@ import weakref
 import torch
 
 from .diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-from .sh_utils import eval_sh
+from .sh_utils import sh_basis
+
+# ---- activated parameters of a model, kept while the model does not change ------------------------------------------------
+# PEGASUS renders one scene from many cameras with one render() call each (pegasus.py:254-271); the getters behind
+# get_opacity / get_scaling / get_rotation / get_features are four elementwise kernels and a 192-byte-per-Gaussian
+# concatenation: 0.36 ms of a 0.93 ms call on the 2 M-Gaussian scene.  Inference only.
+#
+# A slot is valid while every raw tensor behind the getter is the same object (id), has the same autograd version counter
+# and the same storage address and shape.  The slot holds an alias of each raw tensor's storage, so neither the object id
+# nor the address can be recycled for something else while the slot exists.  What the key CANNOT see is a write that
+# bypasses the version counter (`param.data.add_(..)`, raw pointer writes from another library): after such an edit call
+# ``invalidate_activations(model)``.  Tensors without a version counter (created under torch.inference_mode()) are simply
+# not cached.
+_SLOTS = weakref.WeakKeyDictionary()
+_SOURCES = {"get_opacity": ("_opacity",), "get_scaling": ("_scaling",), "get_rotation": ("_rotation",),
+            "get_features": ("_features_dc", "_features_rest")}
 
 
-# Activated parameters of a model, kept between calls while the model does not change.  PEGASUS renders one scene from
-# many cameras, one `render()` call each (pegasus.py:254-271, src/gs/render.py); the getters behind `pc.get_opacity`,
-# `get_scaling`, `get_rotation` and `get_features` are four elementwise kernels and a 192-byte-per-Gaussian `cat`
-#  -- 0.36 ms of a 0.93 ms call on the 2 M-Gaussian scene.  Keyed on the identity and version counter of
-# the raw tensors: any in-place edit or re-assignment (pose application, merge, mask) misses.  Inference only.
-_ACT_CACHE = weakref.WeakKeyDictionary()
-_RAW = {"get_opacity": ("_opacity",), "get_scaling": ("_scaling",), "get_rotation": ("_rotation",),
-        "get_features": ("_features_dc", "_features_rest")}
+def invalidate_activations(pc=None) -> None:
+    """Forget the kept activations of ``pc`` (or of every model).  Needed only after edits the version counter does not
+    see, e.g. writes through ``tensor.data``."""
+    if pc is None:
+        _SLOTS.clear()
+    else:
+        _SLOTS.pop(pc, None)
 
 
-def _activated(pc, getter: str):
-    raw = [getattr(pc, a, None) for a in _RAW[getter]]
-    if torch.is_grad_enabled() or any(not isinstance(t, torch.Tensor) for t in raw):
+def _kept(pc, getter: str):
+    sources = [getattr(pc, name, None) for name in _SOURCES[getter]]
+    if torch.is_grad_enabled() or not all(isinstance(t, torch.Tensor) for t in sources):
         return getattr(pc, getter)
-    key = tuple((id(t), t._version, t.data_ptr(), tuple(t.shape)) for t in raw)
     try:
-        slot = _ACT_CACHE.setdefault(pc, {})
-    except TypeError:                      # a model class that cannot be weakly referenced: no cache
+        key = tuple((id(t), t._version, t.data_ptr(), tuple(t.shape)) for t in sources)
+        per_model = _SLOTS.setdefault(pc, {})
+    except (RuntimeError, TypeError):      # inference tensors have no version counter; some classes take no weak reference
         return getattr(pc, getter)
-    hit = slot.get(getter)
-    if hit is not None and hit[0] == key:
-        return hit[1]
-    value = getattr(pc, getter)
-    slot[getter] = (key, value, raw)       # `raw` keeps the keyed tensors alive: their ids and addresses cannot be reused
-    return value
+    slot = per_model.get(getter)
+    if slot is None or slot[0] != key:
+        slot = per_model[getter] = (key, getattr(pc, getter), sources, [t.detach() for t in sources])
+    return slot[1]
+
+
+# ---- the three input groups of a rasterizer call ---------------------------------------------------------------------------
+
+def _view(cam, pc, pipe, bg, scaling_modifier) -> GaussianRasterizationSettings:
+    return GaussianRasterizationSettings(
+        image_height=int(cam.image_height), image_width=int(cam.image_width),
+        tanfovx=math.tan(0.5 * cam.FoVx), tanfovy=math.tan(0.5 * cam.FoVy),
+        bg=bg, scale_modifier=scaling_modifier,
+        viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, campos=cam.camera_center,
+        sh_degree=pc.active_sh_degree, prefiltered=False, debug=bool(getattr(pipe, "debug", False)))
+
+
+def _geometry(pc, pipe, scaling_modifier) -> dict:
+    """Either the model's own 3D covariances (pipe.compute_cov3D_python) or scale + rotation for the kernel to combine."""
+    if getattr(pipe, "compute_cov3D_python", False):
+        return dict(cov3D_precomp=pc.get_covariance(scaling_modifier))
+    return dict(scales=_kept(pc, "get_scaling"), rotations=_kept(pc, "get_rotation"))
+
+
+def _colour(pc, pipe, cam, override_color) -> dict:
+    """Precomputed per-Gaussian colours (an override, or SH evaluated here when pipe.convert_SHs_python asks for it), else
+    the SH coefficients for the kernel to evaluate."""
+    if override_color is not None:
+        return dict(colors_precomp=override_color)
+    if not getattr(pipe, "convert_SHs_python", False):
+        return dict(shs=_kept(pc, "get_features"))
+    coeff = pc.get_features                                        # [N, (max_deg+1)^2, 3]
+    towards = torch.nn.functional.normalize(pc.get_xyz - cam.camera_center.reshape(1, 3), dim=1)
+    basis = sh_basis(pc.active_sh_degree, towards)                 # [N, (deg+1)^2]
+    rgb = torch.einsum("nk,nkc->nc", basis, coeff[:, :basis.shape[1]])
+    return dict(colors_precomp=(rgb + 0.5).clamp_min(0.0))
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
     """Render the scene ``pc`` (a GaussianModel) from ``viewpoint_camera``.  ``bg_color`` must be on the GPU."""
-    # upstream's idiom: a zero tensor whose .grad receives the screen-space (NDC-scaled) gradient of the 2D means, which
-    # training-style callers read for densification (render_pkg["viewspace_points"].grad)
-    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True,
-                                          device=pc.get_xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
-
-    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
-    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
-    raster_settings = GaussianRasterizationSettings(
-        image_height=int(viewpoint_camera.image_height),
-        image_width=int(viewpoint_camera.image_width),
-        tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
-        viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
-        sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False,
-        debug=getattr(pipe, "debug", False))
-    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
-
-    means3D = pc.get_xyz
-    means2D = screenspace_points
-    opacity = _activated(pc, "get_opacity")
-
-    scales = rotations = cov3D_precomp = None
-    if getattr(pipe, "compute_cov3D_python", False):
-        cov3D_precomp = pc.get_covariance(scaling_modifier)
-    else:
-        scales = _activated(pc, "get_scaling")
-        rotations = _activated(pc, "get_rotation")
-
-    shs = colors_precomp = None
-    if override_color is None:
-        if getattr(pipe, "convert_SHs_python", False):
-            shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
-            dir_pp = pc.get_xyz - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
-            dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
-            sh2rgb = eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized)
-            colors_precomp = torch.clamp_min(sh2rgb + 0.5, 0.0)
-        else:
-            shs = _activated(pc, "get_features")
-    else:
-        colors_precomp = override_color
-
-    rendered_image, radii, depth = rasterizer(
-        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
-        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
-
-    return {"render": rendered_image, "depth": depth, "viewspace_points": screenspace_points,
-            "visibility_filter": radii > 0, "radii": radii}
+    xyz = pc.get_xyz
+    # "viewspace_points": a zero tensor shaped like the means whose .grad receives the screen-space (NDC-scaled) gradient
+    # of the 2D means -- training-style callers read it for densification.  A leaf that asks for a gradient only when
+    # autograd is on; the render loops run under torch.no_grad() (pegasus.py:248) and get plain zeros.
+    probe = torch.zeros_like(xyz, requires_grad=torch.is_grad_enabled())
+    rasterizer = GaussianRasterizer(raster_settings=_view(viewpoint_camera, pc, pipe, bg_color, scaling_modifier))
+    image, radii, depth = rasterizer(means3D=xyz, means2D=probe, opacities=_kept(pc, "get_opacity"),
+                                     **_colour(pc, pipe, viewpoint_camera, override_color),
+                                     **_geometry(pc, pipe, scaling_modifier))
+    return {"render": image, "depth": depth, "viewspace_points": probe, "visibility_filter": radii > 0, "radii": radii}

@@ -219,6 +219,10 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
                 status = L.pgr_batch_status(C.c_void_p(pb._scratch.data_ptr()), nv, need)
                 if status != _lib.PGR_ERR_INSTANCE_OVERFLOW:
                     _lib.check(status, "pgr_forward_frames_async")
+                    _LAST_INFO.clear()
+                    _LAST_INFO.update(num_instances=[int(x) for x in need], max_instances=int(pb._max_inst),
+                                      used_max_instances=int(pb._max_inst), n=n, width=W, height=H, n_views=nv,
+                                      workspace=pb._keep[1], workspace_bytes=int(pb._keep[1].numel()))
                     return results
                 _WS.capacity_hint[key] = _grown_capacity(max(need), 1.6)
             raise RuntimeError("instance capacity did not converge")

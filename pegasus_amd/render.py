@@ -46,26 +46,81 @@ def render_silhouette_mask(cam, gs_object_list, gs_env, width, height, color_set
     return mask_silhouette
 
 
+_GEOMETRY = ("_xyz", "_opacity", "_scaling", "_rotation")
+_ALL = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+_kept_scene = {}       # the objects-only scene of the last call and, per camera, its render
+
+
+def _fingerprint(tensors):
+    """Identity of a set of tensors as far as torch can tell without reading them: object, version counter, storage,
+    shape.  None (= never equal) for tensors without a version counter (torch.inference_mode)."""
+    try:
+        return tuple((id(t), t._version, t.data_ptr(), tuple(t.shape)) for t in tensors)
+    except RuntimeError:
+        return None
+
+
 def _semantic_scene(gs_environment, gs_object_list):
-    scene = copy.deepcopy(gs_environment)
-    for current in gs_object_list.values():
+    """The scene the reference composes for its two semantic renders (/root/reference/src/gs/render.py:68-84,100-113):
+    deepcopy the environment, paint every object in its semantic colour (IN PLACE -- the caller's objects keep the paint,
+    as in the reference), merge them, then mask the environment rows out again.  What is left is the objects alone in
+    dictionary order, so it is built as exactly that: one concatenation per attribute, no 2 M-row copy that is thrown away.
+    The scene of an unchanged object list is kept between calls (both semantic wrappers ask for the same one per frame)."""
+    objects = list(gs_object_list.values())
+    for current in objects:
         _restore_semantics(current)
-        scene.merge_gaussians(gaussian=current)
-    return _without_environment(scene, gs_environment._xyz.shape[0])
+    key = _fingerprint([getattr(o, k) for o in objects for k in _GEOMETRY] +
+                       [t for o in objects for t in (o._features_dc_semantics, o._features_rest_semantics)
+                        if isinstance(t, torch.Tensor)])
+    key = None if key is None else (key, tuple(id(o) for o in objects), id(gs_environment),
+                                    getattr(gs_environment, "active_sh_degree", None))
+    if key is not None and _kept_scene.get("key") == key:
+        return _kept_scene["scene"], key
+    scene = copy.copy(gs_environment)                   # the environment's settings (SH degrees, ...), none of its rows
+    for k in _ALL:
+        parts = [getattr(o, k) for o in objects]
+        setattr(scene, k, torch.cat(parts, 0) if parts else getattr(gs_environment, k)[:0])
+    _kept_scene.clear()
+    _kept_scene.update(key=key, scene=scene, renders={}, keep=objects)
+    return scene, key
+
+
+def _semantic_image(cam, gs_environment, gs_object_list, pipe_settings, bg):
+    """Objects-only semantic render of ``cam``.  The reference renders this same image twice per frame, once in
+    render_visib_mask and once in render_semanticsegmentation_mask; the second request of an unchanged (scene, camera,
+    background) gets the first one's image."""
+    scene, key = _semantic_scene(gs_environment, gs_object_list)
+    cam_key = None
+    if key is not None:
+        cam_key = _fingerprint([cam.world_view_transform, cam.full_proj_transform, cam.camera_center, bg])
+        cam_key = None if cam_key is None else (cam_key, id(cam), int(cam.image_height), int(cam.image_width),
+                                                float(cam.FoVx), float(cam.FoVy), torch.is_grad_enabled(),
+                                                bool(getattr(pipe_settings, "convert_SHs_python", False)),
+                                                bool(getattr(pipe_settings, "compute_cov3D_python", False)))
+        hit = _kept_scene["renders"].get("last")
+        if cam_key is not None and hit is not None and hit[0] == cam_key:
+            return hit[1]
+    img = render(cam, scene, pipe_settings, bg)["render"]
+    if cam_key is not None and not torch.is_grad_enabled():
+        _kept_scene["renders"]["last"] = (cam_key, img, (cam, bg))
+    return img
 
 
 def render_visib_mask(cam, gs_environment, gs_object_list, color_set, height, width, pipe_settings, bg):
     """All objects in their semantic colours, environment removed; K masks by colour distance (render.py:68-97)."""
-    img = render(cam, _semantic_scene(gs_environment, gs_object_list), pipe_settings, bg)["render"]
+    img = _semantic_image(cam, gs_environment, gs_object_list, pipe_settings, bg)
     m = M.color_masks(img, color_set, M.MASK_THRESHOLD)
-    individual = m.permute(1, 2, 0).cpu().numpy().astype(np.float64)
+    # float64 [H,W,K] on the host, as the reference returns it (np.zeros default dtype); widened on the device: the host
+    # cast of 41 MB costs more than moving it
+    individual = m.permute(1, 2, 0).to(torch.float64).cpu().numpy()
     return individual, img.cpu().permute((1, 2, 0))
 
 
 def render_semanticsegmentation_mask(cam, gs_environment, gs_object_list, color_set, height, width, pipe_settings,
                                      bg, debug):
-    img = render(cam, _semantic_scene(gs_environment, gs_object_list), pipe_settings, bg)["render"]
-    return (np.ascontiguousarray(img.cpu().permute((1, 2, 0))) * 255).astype("uint8")
+    img = _semantic_image(cam, gs_environment, gs_object_list, pipe_settings, bg)
+    rgb8 = M.pack_frames(color=img[None])["rgb"][0]            # (img * 255).astype(uint8) on the device, HWC
+    return rgb8.cpu().numpy()
 
 
 def assign_semantic_colors(gaussians_object_list, semantic_colors):

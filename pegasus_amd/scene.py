@@ -70,7 +70,12 @@ class Scene:
             random.shuffle(cams)
         self.train_cameras = {float(s): cams for s in resolution_scales}
         self.test_cameras = {float(s): [] for s in resolution_scales}
-        self.cameras_extent = float(np.linalg.norm(np.stack([np.asarray(c.camera_center.cpu()) for c in cams]).std(0))) if cams else 1.0
+        # scene radius as the training code expects it (spatial_lr_scale, prune thresholds): 1.1 x the largest distance of a
+        # camera centre from the mean centre
+        self.cameras_extent = 1.0
+        if cams:
+            centres = np.stack([np.asarray(c.camera_center.cpu(), dtype=np.float64) for c in cams])
+            self.cameras_extent = float(1.1 * np.linalg.norm(centres - centres.mean(0), axis=1).max())
         if self.loaded_iter:
             self.gaussians.load_ply(os.path.join(pc_dir, "iteration_" + str(self.loaded_iter), "point_cloud.ply"))
 

@@ -1,0 +1,25 @@
+#!/bin/bash
+# rocprofv3 counter passes over THE bench command (fused frames path, 32-view batches, C3) -- one counter group per pass,
+# no tracing flags -- then ONE report: gpurun_out/<name>.json (what bench.py reads as profiles/pmc.json) and
+# gpurun_out/<name>.txt (the human-readable table of the same numbers), so the two cannot diverge.
+#   scripts/pmc_profile.sh <out-name> [extra bench flags...]
+cd "$(dirname "$0")/.."
+REPO=$PWD
+name=${1:-pmc}; shift
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+BENCH_FLAGS="--steps 3 --warmup 1 --no-cpu-baseline --no-drop-in --profile-steps 1 --sync-steps $*"
+GROUPS_=("FETCH_SIZE" "WRITE_SIZE" "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"
+         "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE")
+dbs=()
+i=0
+for grp in "${GROUPS_[@]}"; do
+  i=$((i+1))
+  d=/tmp/pmc_${name}_$i
+  rm -rf $d
+  ( cd /tmp && timeout 600 rocprofv3 --pmc $grp -d $d -- python3 $REPO/bench.py $BENCH_FLAGS > /tmp/pmc_${name}_$i.log 2>&1 )
+  db=$(find $d -name "*.db" | head -1)
+  if [ -z "$db" ]; then echo "pass $i ($grp): no database; log tail:"; tail -5 /tmp/pmc_${name}_$i.log; fi
+  dbs+=("${db:-MISSING}")
+done
+python3 scripts/pmc_report.py gpurun_out/$name.json gpurun_out/$name.txt "python3 bench.py $BENCH_FLAGS" "${dbs[@]}"

@@ -173,3 +173,46 @@ def test_scene_directory_round_trip(tmp_path):
     with pytest.raises(ValueError):
         Camera(colmap_id=0, R=views[0].R_c2w, T=views[0].t_w2c, FoVx=1.0, FoVy=1.0, image=None, gt_alpha_mask=None,
                image_name="x", uid=0, data_device="cpu")
+
+
+def test_kept_activations_follow_the_model_on_cpu():
+    """gaussian_renderer keeps a model's activated parameters between render() calls (inference only).  The key must miss
+    on every edit the version counter sees, survive tensors without a version counter, and never reuse a slot after the
+    raw tensor's storage was swapped (advisor findings of round 2)."""
+    import numpy as np
+    import torch
+    from pegasus_amd import gaussian_renderer as GR
+    from pegasus_amd.gaussian_model import GaussianModel
+    rng = np.random.default_rng(0)
+    n = 50
+    mk = lambda: GaussianModel.from_arrays(rng.normal(size=(n, 3)), rng.normal(size=(n, 1, 3)), rng.normal(size=(n, 15, 3)),
+                                           rng.normal(size=(n, 1)), rng.normal(size=(n, 3)), rng.normal(size=(n, 4)),
+                                           device="cpu")
+    with torch.no_grad():
+        pc = mk()
+        a = GR._kept(pc, "get_opacity")
+        assert GR._kept(pc, "get_opacity") is a                          # unchanged model: the kept tensor itself
+        pc._opacity.add_(1.0)                                            # in-place edit: version counter moves
+        b = GR._kept(pc, "get_opacity")
+        assert b is not a and torch.equal(b, pc.get_opacity)
+        pc._opacity.data.add_(1.0)                                       # bypasses the version counter: documented blind spot
+        assert GR._kept(pc, "get_opacity") is b
+        GR.invalidate_activations(pc)                                    # ... with this remedy
+        assert torch.equal(GR._kept(pc, "get_opacity"), pc.get_opacity)
+        # storage swap A -> B -> A': the slot keeps A's storage alive, so A' cannot reappear at A's address under the same key
+        seen = GR._kept(pc, "get_scaling")
+        first_ptr = pc._scaling.data_ptr()
+        for _ in range(4):
+            pc._scaling.data = pc._scaling.data.clone() * 0.5
+            cur = GR._kept(pc, "get_scaling")
+            assert torch.equal(cur, pc.get_scaling)
+        assert pc._scaling.data_ptr() != first_ptr or torch.equal(seen, pc.get_scaling)
+        f = GR._kept(pc, "get_features")
+        pc._features_rest = pc._features_rest.clone()                   # re-assignment of one of the two sources
+        assert GR._kept(pc, "get_features") is not f
+    with torch.inference_mode():
+        pi = mk()                                                        # inference tensors: no version counter
+        out = GR._kept(pi, "get_rotation")
+        assert torch.equal(out, pi.get_rotation)
+    with torch.enable_grad():
+        assert GR._kept(pc, "get_opacity") is not GR._kept(pc, "get_opacity")   # autograd on: never kept

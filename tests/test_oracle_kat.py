@@ -250,3 +250,46 @@ def test_oracle_agrees_with_independent_dense_float64_renderer(oracle):
     assert np.abs(c64 - o["color"]).max() < 5e-5
     assert np.abs(d64 - o["out_depth"][0]).max() < 5e-5
     assert (o["radii"] > 0).sum() > 500
+
+
+def test_sh_colour_model_against_first_principles_basis(oracle):
+    """The colour model's basis pinned from first principles: oracle/dense_ref.py derives the real spherical harmonics
+    from associated Legendre recurrences and factorial normalisation (Condon-Shortley phase kept -- the 3DGS paper's
+    convention), sharing no constant with the product's table (pegasus_amd/sh_utils.py) or the C oracle's.  All three
+    must agree: a wrong sign or constant in one of them cannot hide."""
+    import numpy as np
+    from oracle.dense_ref import real_sh_basis
+    from pegasus_amd import graphics as G, scenes
+    from pegasus_amd.sh_utils import sh_basis, C0, C1
+    rng = np.random.default_rng(5)
+    dirs = rng.normal(size=(200, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    dirs = np.concatenate([dirs, np.eye(3), -np.eye(3)])
+    for deg in range(4):
+        mine = np.stack([real_sh_basis(deg, d) for d in dirs])
+        assert mine.shape[1] == (deg + 1) ** 2
+        np.testing.assert_allclose(mine, sh_basis(deg, dirs), atol=1e-14)
+    # closed forms of the first two bands, and orthonormality of the whole basis on the sphere (Monte-Carlo free: Lebedev-
+    # like check through the addition theorem  sum_m Y_lm(d)^2 = (2l+1)/(4 pi))
+    b = real_sh_basis(3, dirs[0])
+    assert abs(b[0] - 0.5 / np.sqrt(np.pi)) < 1e-15 and abs(C0 - 0.5 / np.sqrt(np.pi)) < 1e-15
+    np.testing.assert_allclose(b[1:4], np.sqrt(3 / (4 * np.pi)) * np.array([-dirs[0][1], dirs[0][2], -dirs[0][0]]), atol=1e-15)
+    assert abs(C1 - np.sqrt(3 / (4 * np.pi))) < 1e-15
+    for l, sl in ((0, slice(0, 1)), (1, slice(1, 4)), (2, slice(4, 9)), (3, slice(9, 16))):
+        for d in dirs[:20]:
+            assert abs((real_sh_basis(3, d)[sl] ** 2).sum() - (2 * l + 1) / (4 * np.pi)) < 1e-13
+    # the C oracle's per-Gaussian colour = max(basis . coefficients + 0.5, 0) with THIS basis
+    n = 64
+    R, t = G.look_at_opencv((0.0, 0.0, -3.0), (0.0, 0.0, 0.0), up=(0.0, -1.0, 0.0))
+    v = scenes.make_view(R, t, 64, 64, fovx=1.0, fovy=1.0)
+    means = rng.uniform(-0.8, 0.8, size=(n, 3)).astype(np.float32)
+    shs = rng.normal(0, 0.4, size=(n, 16, 3)).astype(np.float32)
+    o = oracle.forward(means, np.full(n, 0.5, np.float32), scales=np.full((n, 3), 0.05, np.float32),
+                       rotations=np.tile(np.array([1, 0, 0, 0], np.float32), (n, 1)), shs=shs, sh_degree=3,
+                       **v.raster_kwargs(), stage="preprocess")
+    seen = o["radii"] > 0
+    assert seen.sum() > 40
+    for i in np.nonzero(seen)[0]:
+        d = means[i].astype(np.float64) - v.camera_center.astype(np.float64)
+        want = np.maximum(real_sh_basis(3, d / np.linalg.norm(d)) @ shs[i].astype(np.float64) + 0.5, 0.0)
+        np.testing.assert_allclose(o["rgb"][i], want, atol=2e-6)
