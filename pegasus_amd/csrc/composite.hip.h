@@ -48,6 +48,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int HALF_ROWS = 8;     // rows per half tile (backward.hip.h's work unit)
 constexpr int WAVE_BATCH = 64;   // list entries staged per round
 constexpr uint32_t ITEMS_PER_TILE = 4;   // work items per 16x16 tile: its four 8x8 quarters
+constexpr int SEM_LDS_OBJECTS = 64;      // semantic colours kept in LDS by the fused walk (more objects: read from memory)
 #ifndef PGR_PAIR_UNROLL
 #define PGR_PAIR_UNROLL 4
 #endif
@@ -65,7 +66,9 @@ constexpr int PAIR_UNROLL = PGR_PAIR_UNROLL;   // entry pairs per trip of the co
 #ifdef PGR_COMP_STATS
 // debug build only: [0] list entries walked, [1] live entries after the skip test, [2] wave-entries evaluated,
 // [3] pixel-entries with the pixel still alive, [4] pixel-entries blended, [5] waves, [6] batches, [7] semantic wave-entries
-__device__ unsigned long long g_comp_stats[8];
+// [8] fused waves, [9] tail batches (scene pixels saturated, semantic walk only), [10] tail entries walked, [11] tail entries gathered (object entries),
+// [12] tail entries live after the skip test, [13] waves that enter the tail, [14] waves that walk to the last object entry
+__device__ unsigned long long g_comp_stats[16];
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -96,7 +99,8 @@ __device__ unsigned long long g_comp_stats[8];
 template <bool AUX, bool FUSED>
 __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t item, const SemanticDev& sem, int n_sem,
                                                   bool sem_background, float4* __restrict__ s_g, float4* __restrict__ s_c,
-                                                  float4* __restrict__ s_s, uint32_t* __restrict__ s_i) {
+                                                  float4* __restrict__ s_s, uint32_t* __restrict__ s_i,
+                                                  const float* __restrict__ s_col) {
     const CameraDev& cam = *ve.cam;
     const uint32_t* __restrict__ gauss_sorted = ve.gauss_sorted;
     const float4* __restrict__ splats = ve.splats;
@@ -169,6 +173,7 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
 
 #ifdef PGR_COMP_STATS
     unsigned long long st_walk = 0, st_live = 0, st_eval = 0, st_alive = 0, st_blend = 0, st_batches = 0, st_sem = 0;
+    unsigned long long st_tb = 0, st_tw = 0, st_tg = 0, st_tl = 0, st_tend = 0;
 #endif
     for (int base = 0; base < n; base += WAVE_BATCH) {
         if (alive == 0ull && (sem_alive == 0ull || base >= n_sem)) break;
@@ -189,8 +194,15 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
         const float4 co = make_float4(q0.z, q0.w, q1.x, q1.y);
         float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
         if (FUSED && oid > 0) {
-            const float* col = sem.colors + 3 * (size_t)(oid - 1);
-            cs = make_float4(gload(col), gload(col + 1), gload(col + 2), q2.w);      // .w = depth (> 0.2: doubles as "object entry")
+            // the colour table sits in LDS (s_col, filled once per wave): fetched from memory here, the three loads were a
+            // round trip per batch that the next batch's record requests had to queue behind (s_waitcnt vmcnt(0) in the ISA)
+            if (s_col) {
+                const float* col = s_col + 3 * (oid - 1);
+                cs = make_float4(col[0], col[1], col[2], q2.w);                          // .w = depth (> 0.2: doubles as "object entry")
+            } else {
+                const float* col = sem.colors + 3 * (size_t)(oid - 1);
+                cs = make_float4(gload(col), gload(col + 1), gload(col + 2), q2.w);
+            }
         }
         const bool live = have && (alive != 0ull || cs.w != 0.0f) &&
                           rect_may_contribute(make_cull_splat(p, co, q1.z, q1.w), bx0, by0, bx1, by1);
@@ -200,6 +212,8 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 #ifdef PGR_COMP_STATS
         st_walk += min(WAVE_BATCH, n - base); st_live += cnt; st_batches++;
+        if (FUSED && alive == 0ull) { st_tb++; st_tw += min(WAVE_BATCH, n_sem - base); st_tg += __popcll(__ballot(have)); st_tl += cnt;
+                                      if (base + WAVE_BATCH >= n_sem) st_tend = 1; }
 #endif
         if (live) {
             float* gq = s_gf + 12 * (pos >> 1) + (pos & 1);
@@ -319,6 +333,9 @@ finished:
         atomicAdd(&g_comp_stats[0], st_walk); atomicAdd(&g_comp_stats[1], st_live); atomicAdd(&g_comp_stats[2], st_eval);
         atomicAdd(&g_comp_stats[3], st_alive); atomicAdd(&g_comp_stats[4], st_blend); atomicAdd(&g_comp_stats[5], 1ull);
         atomicAdd(&g_comp_stats[6], st_batches); atomicAdd(&g_comp_stats[7], st_sem);
+        if (FUSED) { atomicAdd(&g_comp_stats[8], 1ull); atomicAdd(&g_comp_stats[9], st_tb); atomicAdd(&g_comp_stats[10], st_tw);
+                     atomicAdd(&g_comp_stats[11], st_tg); atomicAdd(&g_comp_stats[12], st_tl); atomicAdd(&g_comp_stats[13], st_tb ? 1ull : 0ull);
+                     atomicAdd(&g_comp_stats[14], st_tend); }
     }
 #endif
     if (inside) {
@@ -368,15 +385,24 @@ __global__ __launch_bounds__(WAVE) PGR_COMP_OCC void composite_quarter_kernel(co
     __shared__ float4 s_c[2 * PAIRS];
     __shared__ float4 s_s[FUSED ? 2 * PAIRS : 1];
     __shared__ uint32_t s_i[AUX ? 2 * PAIRS : 1];
+    __shared__ float s_col[FUSED ? 3 * SEM_LDS_OBJECTS : 1];
     if constexpr (FUSED) {
         const bool want_sem = ve.sem_color != nullptr;
         // object entries live in [0, n_sem).  readfirstlane: the value arrives through a vector load; everything derived
         // from it (the semantic masks, the loop exits) must stay on the scalar unit
         const int n_sem = want_sem ? __builtin_amdgcn_readfirstlane((int)ve.obj_last[item >> 2]) : 0;
-        if (n_sem > 0) composite_quarter<AUX, true>(ve, item, sem, n_sem, false, s_g, s_c, s_s, s_i);
-        else composite_quarter<AUX, false>(ve, item, sem, 0, want_sem, s_g, s_c, s_s, s_i);
+        if (n_sem > 0) {
+            const bool table = sem.k <= SEM_LDS_OBJECTS;
+            if (table) {
+                for (int i = threadIdx.x; i < 3 * sem.k; i += WAVE) s_col[i] = gload(sem.colors + i);
+                __syncthreads();
+            }
+            composite_quarter<AUX, true>(ve, item, sem, n_sem, false, s_g, s_c, s_s, s_i, table ? s_col : nullptr);
+        } else {
+            composite_quarter<AUX, false>(ve, item, sem, 0, want_sem, s_g, s_c, s_s, s_i, nullptr);
+        }
     } else {
-        composite_quarter<AUX, false>(ve, item, sem, 0, false, s_g, s_c, s_s, s_i);
+        composite_quarter<AUX, false>(ve, item, sem, 0, false, s_g, s_c, s_s, s_i, nullptr);
     }
 }
 

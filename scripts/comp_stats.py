@@ -18,7 +18,7 @@ fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotat
                      sh_degree=3, device="cuda:0")
 specs = [fr.view_spec(v) for v in views[:B]]
 fr.render_frames(specs, None, masks=False)
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 16)()
 if hasattr(handle, "pgr_debug_sort_stats"):
     handle.pgr_debug_sort_stats(out, 1)
     fr.render_frames(specs, None, masks=False)
@@ -38,3 +38,8 @@ print(f"fused semantic: {masks}; semantic wave-entries with their own blend {(ou
 print(f"{label}: per view: waves {waves:.0f}  batches {batches:.0f}  entries walked {walk/1e6:.2f} M  live after skip {live/1e6:.2f} M "
       f"({live/walk:.2%})  wave-entries evaluated {ev/1e6:.2f} M  pixel-entries: alive {alive/1e6:.1f} M "
       f"({alive/(ev*64):.2%} of lanes)  blended {blend/1e6:.1f} M ({blend/(ev*64):.2%})  live/batch {live/batches:.1f}")
+if masks:
+    fw, tb, tw, tg, tl, tin, tend = [out[i] / B for i in range(8, 15)]
+    print(f"fused quarters {fw:.0f} per view; {tin:.0f} enter the semantic tail (scene pixels saturated, objects-only walk continues), "
+          f"{tend:.0f} walk to the tile's last object entry; tail: {tb:.0f} batches, {tw/1e6:.3f} M entries walked, "
+          f"{tg/1e6:.3f} M object records gathered, {tl/1e6:.3f} M live after the skip test")
