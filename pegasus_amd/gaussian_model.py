@@ -7,6 +7,8 @@ The pose methods run on the device: ``apply_transformation`` is one pgr_compose_
 reference's GPU -> CPU -> scipy/e3nn -> GPU round trip (gaussian_model.py:499-546)."""
 from __future__ import annotations
 
+import copy
+
 import numpy as np
 import torch
 from torch import nn
@@ -170,9 +172,61 @@ class GaussianModel:
                                pose, xyz, rot, rest)
         self._xyz, self._rotation, self._features_rest = xyz, rot, rest
 
+    # The reference merges with six torch.vstack over the whole, growing scene per merged object
+    # (/root/reference/src/gs/gaussian_model.py:584-591) -- 3.4 GB of copies per frame of pegasus.py:255-264 on the 2 M-Gaussian
+    # scene (2.0 ms).  Here a scene that was deep-copied (what the frame loop does first) or merged into before owns row
+    # buffers with spare capacity, and a merge appends the new object's rows in place: the frame's composition copies the
+    # environment once and every object once.  `_rows[k] = [buffer, rows in use]`; an append is taken only if the attribute
+    # still IS the leading `rows in use` rows of its buffer, so a re-assigned, masked or aliased (copy.copy) attribute falls
+    # back to a fresh buffer.  Like vstack the result holds the old rows followed by the new ones; unlike vstack it shares
+    # storage with the tensor it replaced.
+    _ROW_ATTRS = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+
+    @staticmethod
+    def _headroom(n: int) -> int:
+        return n + max(n // 2, 1 << 16)
+
+    def _append_rows(self, k, cur, add):
+        if torch.is_grad_enabled() and (cur.requires_grad or add.requires_grad):
+            return torch.vstack((cur, add))
+        n, m = int(cur.shape[0]), int(add.shape[0])
+        rows = self.__dict__.setdefault("_rows", {})
+        slot = rows.get(k)
+        buf = slot[0] if slot else None
+        fits = (buf is not None and slot[1] == n and n + m <= buf.shape[0] and cur.data_ptr() == buf.data_ptr() and
+                cur.shape[1:] == buf.shape[1:] and cur.dtype == buf.dtype and cur.device == buf.device and cur.is_contiguous())
+        if not fits:
+            buf = torch.empty((self._headroom(n + m),) + tuple(cur.shape[1:]), dtype=cur.dtype, device=cur.device)
+            buf[:n].copy_(cur)
+        buf[n:n + m].copy_(add)
+        rows[k] = [buf, n + m]
+        return buf[:n + m]
+
     def merge_gaussians(self, gaussian):
-        for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
-            setattr(self, k, torch.vstack((getattr(self, k), getattr(gaussian, k))))
+        for k in self._ROW_ATTRS:
+            setattr(self, k, self._append_rows(k, getattr(self, k), getattr(gaussian, k)))
+
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(model): what PEGASUS's frame loop does with the environment before merging the objects into the copy
+        (pegasus.py:255-256).  Same result as the default -- every tensor cloned, everything else deep-copied -- with the row
+        attributes cloned into buffers that leave room for the merges that follow."""
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        rows = {}
+        for k, v in self.__dict__.items():
+            if k == "_rows":
+                continue
+            if (k in self._ROW_ATTRS and isinstance(v, torch.Tensor) and v.dim() >= 1 and not v.requires_grad and
+                    type(v) is torch.Tensor and v.is_contiguous()):
+                n = int(v.shape[0])
+                buf = torch.empty((self._headroom(n),) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+                buf[:n].copy_(v)
+                new.__dict__[k] = buf[:n]
+                rows[k] = [buf, n]
+            else:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        new.__dict__["_rows"] = rows
+        return new
 
     def mask_points(self, mask):
         if self.optimizer:

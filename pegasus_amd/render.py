@@ -13,10 +13,21 @@ from .gaussian_renderer import render
 from .sh_utils import RGB2SH
 
 
+def _to_host(t: torch.Tensor) -> torch.Tensor:
+    """``t.cpu()`` through page-locked memory: the reference fetches every image with .cpu() (render.py:19-20), and a
+    pageable destination halves the PCIe rate (10 MB of RGB + depth per frame, 41 MB of float64 masks).  The pinned block
+    comes from torch's caching host allocator and returns to it when the caller drops the tensor."""
+    if t.device.type != "cuda" or t.requires_grad:
+        return t.cpu()
+    out = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    out.copy_(t)
+    return out
+
+
 def render_rgb_and_depth(cam, gs_scene, pipe_settings, bg, debug=False):
     render_pkg = render(cam, gs_scene, pipe_settings, bg)
-    rgb_image = render_pkg["render"].cpu().permute((1, 2, 0))
-    depth_image = render_pkg["depth"].cpu().permute((1, 2, 0))
+    rgb_image = _to_host(render_pkg["render"]).permute((1, 2, 0))
+    depth_image = _to_host(render_pkg["depth"]).permute((1, 2, 0))
     return rgb_image, depth_image
 
 
@@ -112,15 +123,15 @@ def render_visib_mask(cam, gs_environment, gs_object_list, color_set, height, wi
     m = M.color_masks(img, color_set, M.MASK_THRESHOLD)
     # float64 [H,W,K] on the host, as the reference returns it (np.zeros default dtype); widened on the device: the host
     # cast of 41 MB costs more than moving it
-    individual = m.permute(1, 2, 0).to(torch.float64).cpu().numpy()
-    return individual, img.cpu().permute((1, 2, 0))
+    individual = _to_host(m.permute(1, 2, 0).to(torch.float64)).numpy()
+    return individual, _to_host(img).permute((1, 2, 0))
 
 
 def render_semanticsegmentation_mask(cam, gs_environment, gs_object_list, color_set, height, width, pipe_settings,
                                      bg, debug):
     img = _semantic_image(cam, gs_environment, gs_object_list, pipe_settings, bg)
     rgb8 = M.pack_frames(color=img[None])["rgb"][0]            # (img * 255).astype(uint8) on the device, HWC
-    return rgb8.cpu().numpy()
+    return _to_host(rgb8).numpy()
 
 
 def assign_semantic_colors(gaussians_object_list, semantic_colors):

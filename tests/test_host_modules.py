@@ -216,3 +216,54 @@ def test_kept_activations_follow_the_model_on_cpu():
         assert torch.equal(out, pi.get_rotation)
     with torch.enable_grad():
         assert GR._kept(pc, "get_opacity") is not GR._kept(pc, "get_opacity")   # autograd on: never kept
+
+
+def test_merge_gaussians_appends_in_place_and_equals_vstack():
+    """GaussianModel.merge_gaussians is the reference's six vstacks (/root/reference/src/gs/gaussian_model.py:584-591) in
+    result; a deep-copied scene (what pegasus.py:255-264 composes every frame) takes the merged rows into spare capacity
+    instead of re-copying the whole scene per object.  Aliases (copy.copy), masked and re-assigned attributes must fall back."""
+    import copy
+    import numpy as np
+    import torch
+    from pegasus_amd.gaussian_model import GaussianModel
+    rng = np.random.default_rng(0)
+    mk = lambda n: GaussianModel.from_arrays(rng.normal(size=(n, 3)), rng.normal(size=(n, 1, 3)), rng.normal(size=(n, 15, 3)),
+                                             rng.normal(size=(n, 1)), rng.normal(size=(n, 3)), rng.normal(size=(n, 4)), device="cpu")
+    rows = GaussianModel._ROW_ATTRS
+    with torch.no_grad():
+        env, a, b = mk(100), mk(30), mk(50)
+        env.meta_info = {"name": ["env"]}
+        env._features_dc_color = env._features_dc.clone()
+        scene = copy.deepcopy(env)
+        assert scene.meta_info == env.meta_info and scene.meta_info is not env.meta_info
+        assert torch.equal(scene._features_dc_color, env._features_dc_color)
+        assert scene._features_dc_color.data_ptr() != env._features_dc_color.data_ptr()
+        assert all(torch.equal(getattr(scene, k), getattr(env, k)) and getattr(scene, k).data_ptr() != getattr(env, k).data_ptr()
+                   for k in rows)
+        want = {k: torch.vstack((getattr(env, k), getattr(a, k), getattr(b, k))) for k in rows}
+        p0 = scene._xyz.data_ptr()
+        scene.merge_gaussians(a)
+        scene.merge_gaussians(b)
+        assert all(torch.equal(getattr(scene, k), want[k]) for k in rows)
+        assert scene._xyz.data_ptr() == p0                                   # appended, not re-copied
+        assert env._xyz.shape[0] == 100 and a._xyz.shape[0] == 30            # sources untouched
+        twin = copy.copy(scene)                                              # two models over the same buffers
+        scene.merge_gaussians(a)
+        twin.merge_gaussians(b)
+        assert torch.equal(scene._xyz, torch.vstack((want["_xyz"], a._xyz)))
+        assert torch.equal(twin._xyz, torch.vstack((want["_xyz"], b._xyz)))
+        keep = torch.ones(scene._xyz.shape[0], dtype=bool)
+        keep[:50] = False
+        scene.mask_points(keep)                                              # re-assigned attributes: fresh buffer on merge
+        before = scene._opacity.clone()
+        scene.merge_gaussians(b)
+        assert torch.equal(scene._opacity, torch.vstack((before, b._opacity)))
+        big = mk(5)                                                          # growth beyond the spare capacity
+        for _ in range(6):
+            big.merge_gaussians(a)
+        assert big._xyz.shape[0] == 5 + 6 * 30 and torch.equal(big._rotation[-30:], a._rotation)
+    p = torch.nn.Parameter(torch.zeros(4, 3))                                # autograd on + a parameter: plain vstack
+    m = mk(4)
+    m._xyz = p
+    m.merge_gaussians(a)
+    assert m._xyz.requires_grad and m._xyz.shape[0] == 34
