@@ -68,7 +68,8 @@ constexpr int PAIR_UNROLL = PGR_PAIR_UNROLL;   // entry pairs per trip of the co
 // [3] pixel-entries with the pixel still alive, [4] pixel-entries blended, [5] waves, [6] batches, [7] semantic wave-entries
 // [8] fused waves, [9] tail batches (scene pixels saturated, semantic walk only), [10] tail entries walked, [11] tail entries gathered (object entries),
 // [12] tail entries live after the skip test, [13] waves that enter the tail, [14] waves that walk to the last object entry
-__device__ unsigned long long g_comp_stats[16];
+// [15] longest wave in shader clocks, [16] its batches, [17..20] waves with > 16 / 32 / 64 / 96 batches, [21] sum of wave clocks
+__device__ unsigned long long g_comp_stats[24];
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -174,6 +175,7 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
 #ifdef PGR_COMP_STATS
     unsigned long long st_walk = 0, st_live = 0, st_eval = 0, st_alive = 0, st_blend = 0, st_batches = 0, st_sem = 0;
     unsigned long long st_tb = 0, st_tw = 0, st_tg = 0, st_tl = 0, st_tend = 0;
+    const unsigned long long st_t0 = __builtin_readcyclecounter();
 #endif
     for (int base = 0; base < n; base += WAVE_BATCH) {
         if (alive == 0ull && (sem_alive == 0ull || base >= n_sem)) break;
@@ -333,6 +335,11 @@ finished:
         atomicAdd(&g_comp_stats[0], st_walk); atomicAdd(&g_comp_stats[1], st_live); atomicAdd(&g_comp_stats[2], st_eval);
         atomicAdd(&g_comp_stats[3], st_alive); atomicAdd(&g_comp_stats[4], st_blend); atomicAdd(&g_comp_stats[5], 1ull);
         atomicAdd(&g_comp_stats[6], st_batches); atomicAdd(&g_comp_stats[7], st_sem);
+        { const unsigned long long dt = __builtin_readcyclecounter() - st_t0;
+          if (atomicMax(&g_comp_stats[15], dt) < dt) g_comp_stats[16] = st_batches;
+          if (st_batches > 16) atomicAdd(&g_comp_stats[17], 1ull); if (st_batches > 32) atomicAdd(&g_comp_stats[18], 1ull);
+          if (st_batches > 64) atomicAdd(&g_comp_stats[19], 1ull); if (st_batches > 96) atomicAdd(&g_comp_stats[20], 1ull);
+          atomicAdd(&g_comp_stats[21], dt); }
         if (FUSED) { atomicAdd(&g_comp_stats[8], 1ull); atomicAdd(&g_comp_stats[9], st_tb); atomicAdd(&g_comp_stats[10], st_tw);
                      atomicAdd(&g_comp_stats[11], st_tg); atomicAdd(&g_comp_stats[12], st_tl); atomicAdd(&g_comp_stats[13], st_tb ? 1ull : 0ull);
                      atomicAdd(&g_comp_stats[14], st_tend); }
@@ -480,7 +487,8 @@ __global__ void order_scan_kernel(uint32_t* __restrict__ state) {
 __global__ __launch_bounds__(256) void order_scatter_kernel(const ViewEntry* __restrict__ views, int tiles, int grid_x,
                                                             uint32_t* __restrict__ state,
                                                             uint32_t* __restrict__ work_order,
-                                                            uint4* __restrict__ sort_queue, uint32_t queue_stride) {
+                                                            uint4* __restrict__ sort_queue, uint32_t queue_stride,
+                                                            int merge_long_tiers) {
     __shared__ uint32_t wave_cnt[4][ORDER_BINS];
     __shared__ uint32_t base[ORDER_BINS];
     __shared__ uint32_t n_queue_s[SORT_TIERS], queue_base_s[SORT_TIERS];
@@ -498,7 +506,13 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const ViewEntry* __r
         const uint32_t len = r.y - r.x;
         x = xcd_of_tile(t, grid_x);
         bin = x * ORDER_CLASSES_USED + coarse_class(len);
-        if (len > 0u && !overflowed) { tier = sort_tier(len); queue_rank = atomicAdd(&n_queue_s[tier], 1u); }
+        if (len > 0u && !overflowed) {
+            tier = sort_tier(len);
+            // a launch of one or two views has a handful of lists per long tier: three launches that each wait for their
+            // longest list.  They all go to the open-ended tier's kernel, which sorts any length.
+            if (merge_long_tiers && tier > 0) tier = SORT_TIERS - 1;
+            queue_rank = atomicAdd(&n_queue_s[tier], 1u);
+        }
     }
     // ordered rank inside the wave, per bin
     uint32_t rank = 0;

@@ -35,6 +35,10 @@ static bool hip_ok(hipError_t e, const char* what) {
 
 static size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
+// Calls of one or two views (the drop-in GaussianRasterizer: one camera per call) cannot fill the chip; their launches are
+// latency-bound and get a few arrangements of their own (fewer, fuller launches).  Results never depend on it.
+constexpr int SMALL_BATCH_VIEWS = 2;
+
 // A/B switch for tests and measurements (read per call; results never depend on it)
 static bool block_cull_enabled() {
     const char* e = getenv("PGR_BLOCK_CULL");
@@ -329,15 +333,18 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     order_scan_kernel<<<1, 64, 0, stream>>>(order_state);
     const int items = n_views * L.tiles;
     const size_t qs = (size_t)items;              // queue stride
+    const bool merge_long = n_views <= SMALL_BATCH_VIEWS;
     order_scatter_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, L.grid_x, order_state, work_order, sort_queue,
-                                                 (uint32_t)items);
+                                                 (uint32_t)items, merge_long ? 1 : 0);
     const uint32_t* n_queue = order_state + ORDER_BINS;
     tile_sort_long_kernel<1024, 16, true><<<std::min(items, 512), 1024, 0, stream>>>(
         bin_table, L.tiles, sort_queue + 3 * qs, n_queue + 3);
-    tile_sort_long_kernel<1024, 8, false><<<std::min(items, 1024), 1024, 0, stream>>>(
-        bin_table, L.tiles, sort_queue + 2 * qs, n_queue + 2);
-    tile_sort_long_kernel<512, 8, false><<<std::min(items, 2048), 512, 0, stream>>>(
-        bin_table, L.tiles, sort_queue + qs, n_queue + 1);
+    if (!merge_long) {
+        tile_sort_long_kernel<1024, 8, false><<<std::min(items, 1024), 1024, 0, stream>>>(
+            bin_table, L.tiles, sort_queue + 2 * qs, n_queue + 2);
+        tile_sort_long_kernel<512, 8, false><<<std::min(items, 2048), 512, 0, stream>>>(
+            bin_table, L.tiles, sort_queue + qs, n_queue + 1);
+    }
     tile_sort_kernel<<<items, SORT_THREADS, 0, stream>>>(bin_table, L.tiles, sort_queue, n_queue);
     mark(4);
     // ---- stage 4: compositing of every (view, tile, quarter) work item in ONE launch; with `semantic` the same
@@ -635,8 +642,8 @@ int32_t pgr_pack_frames(const float* color_b3hw, const float* depth_bhw, const u
 #ifdef PGR_COMP_STATS
 extern "C" int32_t pgr_debug_comp_stats(unsigned long long* out, int32_t reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -4;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pgr::g_comp_stats), 128) != hipSuccess) return -4;
-    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(pgr::g_comp_stats), z, 128) != hipSuccess) return -4; }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pgr::g_comp_stats), 192) != hipSuccess) return -4;
+    if (reset) { unsigned long long z[24] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(pgr::g_comp_stats), z, 192) != hipSuccess) return -4; }
     return 0;
 }
 #endif
