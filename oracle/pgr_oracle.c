@@ -9,6 +9,7 @@
 #include "pgr_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -316,22 +317,45 @@ int pgr_oracle_preprocess(const PgrOracleIn *in, PgrOracleOut *out, int num_thre
     return 0;
 }
 
-/* stable LSD radix sort of (key,value) pairs over bits [0,nbits) -- SURVEY.md section 8a row a8 */
-static void radix_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t n, int nbits)
+/* stable LSD radix sort of (key,value) pairs over bits [0,nbits) -- SURVEY.md section 8a row a8.
+ * Every pass is parallel over contiguous chunks of the input: per-chunk digit histograms, one exclusive scan in
+ * (digit, chunk) order -- which is what keeps the pass stable -- and a scatter in which every chunk owns its cursors.
+ * Same permutation as the serial form for any number of threads. */
+static void radix_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t n, int nbits, int num_threads)
 {
     if (n <= 1) return;
     uint64_t *k2 = (uint64_t *)malloc((size_t)n * sizeof(uint64_t));
     uint32_t *v2 = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
     uint64_t *ka = keys, *kb = k2;
     uint32_t *va = vals, *vb = v2;
+    int chunks = num_threads < 1 ? 1 : (num_threads > 32 ? 32 : num_threads);    /* a scatter pass is memory-bound long before 32 */
+    if ((int64_t)chunks > n / 4096 + 1) chunks = (int)(n / 4096 + 1);
+    int64_t *hist = (int64_t *)malloc((size_t)chunks * 256 * sizeof(int64_t));
+    const int64_t per = (n + chunks - 1) / chunks;
     for (int shift = 0; shift < nbits; shift += 8) {
-        int64_t hist[257] = {0};
-        for (int64_t i = 0; i < n; ++i) hist[((ka[i] >> shift) & 0xFF) + 1]++;
-        for (int b = 0; b < 256; ++b) hist[b + 1] += hist[b];
-        for (int64_t i = 0; i < n; ++i) {
-            const int64_t p = hist[(ka[i] >> shift) & 0xFF]++;
-            kb[p] = ka[i];
-            vb[p] = va[i];
+#pragma omp parallel for schedule(static) num_threads(chunks)
+        for (int c = 0; c < chunks; ++c) {
+            int64_t *h = hist + (size_t)c * 256;
+            memset(h, 0, 256 * sizeof(int64_t));
+            const int64_t lo = (int64_t)c * per, hi = lo + per < n ? lo + per : n;
+            for (int64_t i = lo; i < hi; ++i) h[(ka[i] >> shift) & 0xFF]++;
+        }
+        int64_t acc = 0;
+        for (int b = 0; b < 256; ++b)
+            for (int c = 0; c < chunks; ++c) {
+                const int64_t v = hist[(size_t)c * 256 + b];
+                hist[(size_t)c * 256 + b] = acc;
+                acc += v;
+            }
+#pragma omp parallel for schedule(static) num_threads(chunks)
+        for (int c = 0; c < chunks; ++c) {
+            int64_t *h = hist + (size_t)c * 256;
+            const int64_t lo = (int64_t)c * per, hi = lo + per < n ? lo + per : n;
+            for (int64_t i = lo; i < hi; ++i) {
+                const int64_t p = h[(ka[i] >> shift) & 0xFF]++;
+                kb[p] = ka[i];
+                vb[p] = va[i];
+            }
         }
         uint64_t *tk = ka; ka = kb; kb = tk;
         uint32_t *tv = va; va = vb; vb = tv;
@@ -340,6 +364,7 @@ static void radix_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t n, int nbit
         memcpy(keys, ka, (size_t)n * sizeof(uint64_t));
         memcpy(vals, va, (size_t)n * sizeof(uint32_t));
     }
+    free(hist);
     free(k2);
     free(v2);
 }
@@ -449,7 +474,11 @@ int pgr_oracle_forward(const PgrOracleIn *in, PgrOracleOut *out, int num_threads
     int32_t *tt = o.tiles_touched ? o.tiles_touched : (int32_t *)calloc((size_t)n, 4);
     o.xy = xy; o.depth = depth; o.conic_opacity = conop; o.rgb = rgb; o.radii = radii; o.tiles_touched = tt;
 
+    const int timing = getenv("PGR_ORACLE_TIMING") != NULL;
+    double t_[8]; int ti_ = 0;
+    t_[ti_++] = omp_get_wtime();
     int rc = pgr_oracle_preprocess(in, &o, num_threads);
+    t_[ti_++] = omp_get_wtime();
 
     /* a6: inclusive scan of the per-Gaussian instance counts (cull_mode 1: only the tiles that may contribute) */
     int64_t total = 0;
@@ -490,6 +519,7 @@ int pgr_oracle_forward(const PgrOracleIn *in, PgrOracleOut *out, int num_threads
         for (int32_t i = 0; i < n; ++i) { total += kept[i]; offs[i] = total; }
     }
     out->num_instances = total;
+    t_[ti_++] = omp_get_wtime();
 
     uint64_t *keys = NULL;
     uint32_t *vals = NULL;
@@ -520,13 +550,16 @@ int pgr_oracle_forward(const PgrOracleIn *in, PgrOracleOut *out, int num_threads
                     ++off;
                 }
         }
+        t_[ti_++] = omp_get_wtime();
         /* a8: stable sort over bits [0, 32 + ceil(log2 tiles)) */
         int tbits = 0;
         while ((1 << tbits) < tiles) ++tbits;
-        radix_sort_pairs(keys, vals, total, 32 + tbits);
+        radix_sort_pairs(keys, vals, total, 32 + tbits, num_threads);
 
+        t_[ti_++] = omp_get_wtime();
         /* a9: tile ranges */
         ranges = out->ranges ? out->ranges : (uint32_t *)calloc((size_t)tiles * 2, 4);
+#pragma omp parallel for schedule(static) num_threads(num_threads)
         for (int64_t k = 0; k < total; ++k) {
             const uint32_t t = (uint32_t)(keys[k] >> 32);
             if (k == 0 || (uint32_t)(keys[k - 1] >> 32) != t) ranges[2 * t] = (uint32_t)k;
@@ -536,6 +569,7 @@ int pgr_oracle_forward(const PgrOracleIn *in, PgrOracleOut *out, int num_threads
     free(offs);
     free(kept);
 
+    t_[ti_++] = omp_get_wtime();
     /* a10: compositor, every tile (empty tiles produce bg colour, zero depth, T = 1) */
     if (rc == 0) {
         uint32_t maxlen = 0;
@@ -555,6 +589,12 @@ int pgr_oracle_forward(const PgrOracleIn *in, PgrOracleOut *out, int num_threads
         }
     }
 
+    t_[ti_++] = omp_get_wtime();
+    if (timing) {
+        fprintf(stderr, "pgr_oracle_forward (%d threads):", num_threads);
+        for (int k = 1; k < ti_; ++k) fprintf(stderr, " %.3f", t_[k] - t_[k - 1]);
+        fprintf(stderr, " s  [preprocess, count+scan, emission, sort, ranges, composite]\n");
+    }
     if (keys && keys != out->keys_sorted) free(keys);
     if (vals && vals != out->gauss_sorted) free(vals);
     if (ranges && ranges != out->ranges) free(ranges);

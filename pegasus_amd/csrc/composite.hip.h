@@ -38,6 +38,11 @@ static_assert(sizeof(ViewEntry) == 96, "ViewEntry layout");
 // Fused semantic pass (same for every view of a batch): which Gaussians are objects and what colour they carry.
 struct SemanticDev {
     const int32_t* object_id;    // [n] 0 = environment, k = object k
+    const uint8_t* object_u8;    // [n - n_env] the object ids of the object Gaussians as bytes (batch header, written per
+                                 // batch by pack_object_ids_kernel when k <= 255), or NULL: the fused walk looks an id up
+                                 // per object entry, and a 4-byte gather from the 8 MB int32 array pulled a whole line from
+                                 // HBM for it (PMC, round 3: +41 MB fetched per view); the byte table of a 2 M-Gaussian
+                                 // scene is 0.64 MB and stays in the L2s
     const float* colors;         // [K,3] the rgb value object k's Gaussians carry: max(C0*RGB2SH(c_k) + 0.5, 0)
     int32_t n_env;               // Gaussians with index < n_env are environment
     int32_t k;
@@ -163,7 +168,7 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
                 const float4* rec = splats + (size_t)g * 3;
                 q0 = gload_quad(rec); q1 = gload_quad(rec + 1); q2 = gload_quad(rec + 2);
                 have = true;
-                if (is_obj) oid = gload(sem.object_id + g);
+                if (is_obj) oid = sem.object_u8 ? (int32_t)gload(sem.object_u8 + (g - (uint32_t)sem.n_env)) : gload(sem.object_id + g);
             }
         }
     };
@@ -417,6 +422,12 @@ template <bool AUX, bool FUSED>
 inline void launch_composite(uint32_t slots, hipStream_t stream, const ViewEntry* views, uint32_t items_per_view,
                              const uint32_t* work_order, SemanticDev sem) {
     composite_quarter_kernel<AUX, FUSED><<<slots, WAVE, 0, stream>>>(views, items_per_view, work_order, sem);
+}
+
+// object ids of the object Gaussians as one byte each (see SemanticDev::object_u8)
+__global__ void pack_object_ids_kernel(const int32_t* __restrict__ object_id, int n_env, int n, uint8_t* __restrict__ out) {
+    const int i = n_env + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i - n_env] = (uint8_t)object_id[i];
 }
 
 // ---- work order --------------------------------------------------------------------------------

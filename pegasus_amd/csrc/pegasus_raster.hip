@@ -119,7 +119,7 @@ static ViewWs carve(char* ws, const Layout& L) {
 
 // Batch header placed in front of the per-view slices.
 struct BatchLayout {
-    size_t tables, cams, status, tile_counts, order_state, work_order, long_list, tie_inv, vis, views, total;
+    size_t tables, cams, status, tile_counts, order_state, work_order, long_list, tie_inv, vis, obj_u8, views, total;
     int n_groups, vis_words;
     size_t view_table_off, bin_table_off, pre_table_off, tables_bytes;   // inside `tables` (one H2D copy)
     size_t order_slots;
@@ -153,6 +153,7 @@ static BatchLayout make_batch_layout(const Layout& L, int n_views, size_t n_scen
     B.n_groups = (int)((n_scene + WAVE - 1) / WAVE);
     B.vis_words = (n_views + 31) / 32;
     B.vis = take((size_t)B.n_groups * B.vis_words * 4);
+    B.obj_u8 = take(n_scene);                  // object ids as bytes (fused semantic pass)
     B.views = off;
     B.per_view = align_up(L.total);
     B.total = off + (size_t)n_views * B.per_view;
@@ -353,8 +354,17 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     // walk also produces the objects-only semantic image
     const uint32_t items_per_view = ITEMS_PER_TILE * (uint32_t)L.tiles;
     const uint32_t slots = (uint32_t)B.order_slots;
-    SemanticDev sd{nullptr, nullptr, 0, 0};
-    if (want_sem) sd = SemanticDev{semantic->object_id, semantic->colors, semantic->n_env, semantic->k_objects};
+    SemanticDev sd{nullptr, nullptr, nullptr, 0, 0};
+    if (want_sem) {
+        const uint8_t* ids_u8 = nullptr;
+        if (semantic->k_objects <= 255 && semantic->n_env < N) {
+            auto* dst = reinterpret_cast<uint8_t*>(ws + B.obj_u8);
+            const int n_obj = N - semantic->n_env;
+            pack_object_ids_kernel<<<(n_obj + 255) / 256, 256, 0, stream>>>(semantic->object_id, semantic->n_env, N, dst);
+            ids_u8 = dst;
+        }
+        sd = SemanticDev{semantic->object_id, ids_u8, semantic->colors, semantic->n_env, semantic->k_objects};
+    }
     if (want_aux && want_sem)
         launch_composite<true, true>(slots, stream, view_table, items_per_view, work_order, sd);
     else if (want_aux)

@@ -25,6 +25,7 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t gload(const uint32_t* p) { return *(const PGR_GLOBAL uint32_t*)p; }
+__device__ __forceinline__ uint8_t gload(const uint8_t* p) { return *(const PGR_GLOBAL uint8_t*)p; }
 __device__ __forceinline__ int32_t gload(const int32_t* p) { return *(const PGR_GLOBAL int32_t*)p; }
 __device__ __forceinline__ float gload(const float* p) { return *(const PGR_GLOBAL float*)p; }
 __device__ __forceinline__ uint64_t gload(const uint64_t* p) { return *(const PGR_GLOBAL uint64_t*)p; }

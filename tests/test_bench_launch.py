@@ -70,3 +70,33 @@ def test_single_rank_stub_has_no_gather():
     assert p.returncode == 0, p.stderr[-2000:]
     assert line["n_gpus"] == 1 and line["config"]["gather"]["mode"].startswith("off")
     assert line["config"]["distributed"]["launcher"] == "single process"
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_real_renderer_two_ranks_on_one_device_rehearsal(gpu_device):
+    """The N > 1 code path with the REAL renderer: two ranks share the box's one GPU (gloo gather through host memory --
+    RCCL refuses two ranks on one device), small scene.  Checks the launcher, per-rank sharding, pack + gather + the
+    received-bytes check, and that the line is flagged as a rehearsal."""
+    p, line = _run([sys.executable, "bench.py", "--gpus", "2", "--share-devices", "--backend", "gloo", "--scale", "0.03",
+                    "--steps", "2", "--warmup", "1", "--batch", "4", "--views", "8", "--slots", "2", "--no-drop-in"], timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert line["n_gpus"] == 2 and "rehearsal" in line and line["config"]["distributed"]["backend"] == "gloo"
+    g = line["config"]["gather"]
+    assert g["check"] == "ok" and g["bytes_per_rank_and_batch"] == 4 * 800 * 800 * (3 + 2 + 1)
+    assert g["views_per_s_render_only"] > g["views_per_s_with_gather"] > 0
+    assert [d["device"] for d in line["config"]["distributed"]["devices"]] == ["cuda:0", "cuda:0"]
+    assert line["roofline"]["kernel"] in ("composite", "preprocess", "bin_count", "bin_scatter", "tile_sort")
+
+
+@pytest.mark.gpu
+def test_dynamic_sequence_bench_line(gpu_device):
+    """bench.py --dynamic (configs[4] as SURVEY.md section 8d writes it: poses from the reference's trajectory fixture) at a
+    small scale: runs, names the sequence, and carries the posed CPU baseline."""
+    p, line = _run([sys.executable, "bench.py", "--workload", "c5", "--dynamic", "--scale", "0.02", "--steps", "2", "--warmup", "1",
+                    "--batch", "4", "--views", "200", "--no-drop-in", "--cpu-budget-s", "2"], timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "simulation_steps.json" in line["config"]["sequence"] and line["config"]["objects"] == 20
+    assert line["cpu_baseline"]["value"] > 0 and line["value"] > 0
