@@ -6,6 +6,8 @@
 // a wave64 v_mul/v_mov issues in ~2.6 cycles, v_fma_f32 3.9, v_pk_fma_f32 4.7 (two FMAs), v_exp_f32 8.1 and a
 // v_cmp 4-6; the inner loop below is ~75 such cycles per (wave, list entry) and SQ counters show the VALU >90 % busy.
 #pragma once
+#include <type_traits>
+
 #include "cull.hip.h"
 #include "pgr_common.h"
 
@@ -248,6 +250,26 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
         // PAIR_UNROLL pairs per trip.  The LDS byte offsets of the trip live in VGPRs the compiler cannot see through
         // (it would otherwise keep them on the scalar unit and pay a v_mov per ds_read: 3-4 of the ~36 VALU instructions
         // of a pair); inside a trip every address is one of them + an immediate.
+        // The fused kernel holds the pair loop three times and picks one per batch (scalar):
+        //   RIDE     every parked entry is an object's and no environment entry has blended yet (`pure`): the semantic image
+        //            advances with the scene image -- same weight, same stop mask -- so the loop is the plain loop plus two
+        //            packed FMAs per valid entry, with NO per-entry bookkeeping; Ts and sem_alive are set once, behind it;
+        //   PLAIN    no object entry parked, or the semantic pixels all saturated: nothing to do for the semantic image
+        //            (a batch of environment entries ends the object-only state up front: conservative, and `pure` is only
+        //            ever a licence for a shortcut whose result is bitwise the general path's);
+        //   GENERAL  mixed batches: object bit, `pure`, second set of masks per entry.
+        // The general loop is bound by SCALAR issue (226 scalar + 41 branch instructions per 8-entry trip against 214 vector
+        // ones; SQ counters: 0.79 of the VALU issue slots where the plain loop reaches 0.91), so the batches that do not
+        // need its bookkeeping do not run it.
+        const unsigned long long parked_bits = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+        constexpr int MODE_PLAIN = 0, MODE_RIDE = 1, MODE_GENERAL = 2;
+        int mode = MODE_PLAIN;
+        if (FUSED && objbits != 0ull) mode = (pure && objbits == parked_bits) ? MODE_RIDE : MODE_GENERAL;
+        if (FUSED && mode == MODE_PLAIN && cnt > 0) pure = false;
+        bool all_done = false;
+        auto pair_loop = [&](auto mode_tag) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool SEM = MODE == MODE_GENERAL;
         uint32_t og = 0, oc = 0;
         asm volatile("" : "+v"(og), "+v"(oc));
         for (int k0 = 0; k0 < pairs; k0 += PAIR_UNROLL, og += PAIR_UNROLL * 48u, oc += PAIR_UNROLL * 32u) {
@@ -279,9 +301,9 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
                 // power <= 0 and alpha >= 1/255: the entry counts for this pixel (in either image)
                 const unsigned long long hit = m_pw[u] & __builtin_amdgcn_ballot_w64(!(alpha < ALPHA_MIN));
                 // (scalar branch) about a fifth of the parked entries reach no pixel that is still alive
-                const bool obj_entry = FUSED && ((objbits >> (2 * k + u)) & 1ull);
+                const bool obj_entry = SEM && ((objbits >> (2 * k + u)) & 1ull);
                 if (const unsigned long long valid = alive & hit; valid != 0ull) {
-                    if (FUSED && !obj_entry) pure = false;   // an environment entry: the two images part ways here
+                    if (SEM && !obj_entry) pure = false;     // an environment entry: the two images part ways here
                     const float4 c = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_c) + oc + (2 * ku + u) * 16);
                     const float test_T = fmaf(-alpha, T, T);
                     const unsigned long long stop = valid & __builtin_amdgcn_ballot_w64(test_T < T_EPS);
@@ -298,7 +320,15 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
                     Cbd = __builtin_elementwise_fma((f32x2){c.z, c.w}, wv, Cbd);
                     T = bl ? test_T : T;
                     if (AUX) last = bl ? s_i[2 * k + u] : last;
-                    if (FUSED && pure && obj_entry) {        // same weight, same stop mask: two FMAs are the whole blend
+                    if (MODE == MODE_RIDE) {                 // every entry of this batch rides: no test, state set behind the loop
+                        const float4 sc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_s) + oc + (2 * ku + u) * 16);
+#ifdef PGR_COMP_STATS
+                        st_sem += 1ull << 32;
+#endif
+                        Srg = __builtin_elementwise_fma((f32x2){sc.x, sc.y}, wv, Srg);
+                        Sbd = __builtin_elementwise_fma((f32x2){sc.z, sc.w}, wv, Sbd);
+                    }
+                    if (SEM && pure && obj_entry) {          // same weight, same stop mask: two FMAs are the whole blend
                         const float4 sc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_s) + oc + (2 * ku + u) * 16);
 #ifdef PGR_COMP_STATS
                         st_sem += 1ull << 32;
@@ -309,7 +339,7 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
                         sem_alive = alive;
                     }
                 }
-                if (FUSED && !pure) {
+                if (SEM && !pure) {
                     // wave-uniform (scalar) test: is this entry an object's?
                     if (const unsigned long long valid = sem_alive & hit; obj_entry && valid != 0ull) {
                         const float4 sc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_s) + oc + (2 * ku + u) * 16);
@@ -329,12 +359,19 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
                     }
                 }
             }
-            if ((alive | sem_alive) == 0ull) goto finished;
+            if (MODE == MODE_RIDE ? alive == 0ull : (alive | sem_alive) == 0ull) { all_done = true; return; }
             }
         }
+        };
+        if (mode == MODE_GENERAL) pair_loop(std::integral_constant<int, MODE_GENERAL>{});
+        else if (mode == MODE_RIDE) {
+            pair_loop(std::integral_constant<int, MODE_RIDE>{});
+            Ts = T;                     // the object-only state: the semantic image has blended exactly what the scene image has
+            sem_alive = alive;
+        } else pair_loop(std::integral_constant<int, MODE_PLAIN>{});
+        if (all_done) break;
         __syncthreads();
     }
-finished:
 #ifdef PGR_COMP_STATS
     if (lane == 0) {
         atomicAdd(&g_comp_stats[0], st_walk); atomicAdd(&g_comp_stats[1], st_live); atomicAdd(&g_comp_stats[2], st_eval);
