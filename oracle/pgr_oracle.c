@@ -329,6 +329,7 @@ static void radix_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t n, int nbit
     uint64_t *ka = keys, *kb = k2;
     uint32_t *va = vals, *vb = v2;
     int chunks = num_threads < 1 ? 1 : (num_threads > 32 ? 32 : num_threads);    /* a scatter pass is memory-bound long before 32 */
+    if (getenv("PGR_ORACLE_SORT_THREADS")) chunks = atoi(getenv("PGR_ORACLE_SORT_THREADS")) > 0 ? atoi(getenv("PGR_ORACLE_SORT_THREADS")) : 1;
     if ((int64_t)chunks > n / 4096 + 1) chunks = (int)(n / 4096 + 1);
     int64_t *hist = (int64_t *)malloc((size_t)chunks * 256 * sizeof(int64_t));
     const int64_t per = (n + chunks - 1) / chunks;
