@@ -90,6 +90,10 @@ def parse(argv=None):
     ap.add_argument("--share-devices", action="store_true",
                     help="REHEARSAL: allow more ranks than HIP devices (rank r uses device r mod count; needs --backend gloo, "
                          "RCCL refuses two ranks on one GPU); the JSON line is flagged and is not a result")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="REHEARSAL: initialise the process group and run the gather path even with ONE rank (under torchrun "
+                         "--nproc-per-node 1): RCCL initialisation, the gather of uint8 / 16-bit-as-bytes frames and the "
+                         "collectives of the timing protocol on the real backend, without a second GPU")
     ap.add_argument("--stub-renderer", action="store_true",
                     help="TEST ONLY: exercise launch / sharding / gather / timing with a deterministic CPU frame source "
                          "(no rasterizer, gloo); the JSON line is flagged invalid")
@@ -341,7 +345,8 @@ def run_worker(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = "gloo" if args.stub_renderer else args.backend
-    rehearsal = args.stub_renderer or args.share_devices or (world > 1 and backend != "nccl")
+    use_dist = world > 1 or args.force_dist
+    rehearsal = args.stub_renderer or args.share_devices or args.force_dist or (world > 1 and backend != "nccl")
     dev = torch.device("cpu")
     if not args.stub_renderer:
         if not torch.cuda.is_available():
@@ -353,8 +358,11 @@ def run_worker(args):
             raise SystemExit("--share-devices needs --backend gloo (RCCL refuses two ranks on one GPU)")
         torch.cuda.set_device(local_rank % n_dev)
         dev = torch.device("cuda", local_rank % n_dev)
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -365,13 +373,13 @@ def run_worker(args):
     if dev.type == "cuda":
         p = torch.cuda.get_device_properties(dev)
         me.update(name=p.name, total_memory_gb=round(p.total_memory / 2**30, 1), pci_bus_id=getattr(p, "pci_bus_id", None))
-    if world > 1:
+    if use_dist:
         devices = [None] * world
         dist.all_gather_object(devices, me)
     else:
         devices = [me]
 
-    gather_on = world > 1 and (args.gather if args.gather is not None else True)
+    gather_on = use_dist and (args.gather if args.gather is not None else True)
     eng = (StubEngine if args.stub_renderer else RealEngine)(args, rank, world, dev)
     if args.facade:
         if world != 1 or eng.stub:
@@ -436,17 +444,17 @@ def run_worker(args):
     def timed(first, count, gather):
         """EXACTLY `count` steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
         eng.sync()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         eng.sync()
         t0 = time.perf_counter()
         run_steps(first, count, gather)
         eng.sync()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         eng.sync()
         el = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             te = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             el = float(te.item())
@@ -460,7 +468,7 @@ def run_worker(args):
     # ---- gather check (N > 1, outside the timed region): one more batch through the same pack + gather; rank 0 compares
     # the byte sums of what it RECEIVED from every rank with the sums those ranks computed on what they SENT
     gather_check = None
-    if world > 1 and gather_on:
+    if use_dist and gather_on:
         from pegasus_amd import view_shard as VS
         i_chk = args.warmup + args.steps
         token = eng.step_blocking(i_chk)
@@ -485,9 +493,8 @@ def run_worker(args):
             raise SystemExit("bench.py: gathered frames differ from what the ranks sent (gather check failed)")
 
     if rank != 0:
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()
         return 0
 
     total_views = args.steps * B * world
@@ -500,7 +507,7 @@ def run_worker(args):
     launcher = ("self: python bench.py --gpus N started torch.distributed.run as a child process"
                 if os.environ.get("PGR_BENCH_LAUNCHER") == "self" else
                 ("external torchrun (WORLD_SIZE in the environment)" if env_world else "single process"))
-    dist_info = {"world_size": world, "backend": ("nccl (RCCL)" if backend == "nccl" else backend) if world > 1 else None,
+    dist_info = {"world_size": world, "backend": ("nccl (RCCL)" if backend == "nccl" else backend) if use_dist else None,
                  "launcher": launcher, "devices": devices}
     gather_info = {"mode": "off (frames stay on the rank that rendered them)"}
     if gather_on:
@@ -518,14 +525,14 @@ def run_worker(args):
                     config={"workload": eng.label, "views_per_step": B, "parallelism": f"view-shard x{world}",
                             "distributed": dist_info, "gather": gather_info})
         print(json.dumps(line))
-        if world > 1:
+        if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return 0
 
     _finish_real_line(args, eng, line, value, world, dist_info, gather_info, rehearsal)
     print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return 0
@@ -643,8 +650,8 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
                 "parallelism": f"view-shard x{world}", "distributed": dist_info, "gather": gather_info},
         roofline=roofline, cpu_baseline=cpu, drop_in=drop_in)
     if rehearsal:
-        line["rehearsal"] = ("NOT a result: ranks share devices and/or the gather runs on gloo through host memory; "
-                             "only the launch, sharding and gather logic is exercised")
+        line["rehearsal"] = ("NOT a result: ranks share devices, the gather runs on gloo through host memory, or a one-rank "
+                             "process group was forced; only the launch, sharding, collective and gather logic is exercised")
 
 
 def _cpu_baseline(args, eng):

@@ -600,10 +600,19 @@ __global__ void color_masks_kernel(const float* __restrict__ img, size_t P, cons
     img += (size_t)blockIdx.y * 3 * P;
     masks += (size_t)blockIdx.y * (size_t)k * P;
     const float r = img[p], g = img[P + p], b = img[2 * P + p];
+    // A wave whose 64 pixels are all farther than thr from colour c along ONE channel (the background, other objects'
+    // pixels) skips the squares and the square root: dist >= |d_i| (1 - 2^-23) in fp32 -- the sum of non-negative terms and
+    // the correctly rounded root are monotone, sqrt(fl(x^2)) is within an ulp of |x| -- so |d_i| > thr (1 + 2^-20) decides.
+    const float far = thr * 1.000001f;
     for (int c = 0; c < k; ++c) {
         const float d0 = r - colors[3 * c], d1 = g - colors[3 * c + 1], d2 = b - colors[3 * c + 2];
-        const float dist = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
-        masks[(size_t)c * P + p] = dist <= thr ? 1 : 0;
+        const bool surely_out = fabsf(d0) > far || fabsf(d1) > far || fabsf(d2) > far;
+        uint8_t m = 0;
+        if (__ballot(!surely_out) != 0ull) {
+            const float dist = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+            m = dist <= thr ? 1 : 0;
+        }
+        masks[(size_t)c * P + p] = m;
     }
 }
 

@@ -97,10 +97,11 @@ class BopSceneWriter:
         import torch
         from . import masks as M
         n = frames["color"].shape[0] if n is None else n
-        # GPU: uint8 HWC / uint16 millimetres per frame, then ONE device->host copy per kind and batch
-        q = [M.quantize_frame(frames["color"][i], frames["depth"][i, 0]) for i in range(n)]
-        rgb8 = torch.stack([a for a, _ in q]).cpu().numpy()
-        mm = torch.stack([b for _, b in q]).cpu().numpy().view(np.uint16)
+        # GPU: uint8 HWC / uint16 millimetres for the whole batch in one launch (pgr_pack_frames), then ONE device->host copy
+        # per kind and batch
+        packed = M.pack_frames(color=frames["color"][:n], depth=frames["depth"][:n])
+        rgb8 = packed["rgb"].cpu().numpy()
+        mm = packed["depth_mm"].cpu().numpy().view(np.uint16)
         mk = (frames["masks"][:n] * 255).cpu().numpy() if "masks" in frames else None
         futures = []
         for i in range(n):

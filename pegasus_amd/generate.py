@@ -27,7 +27,6 @@ def main():
 
     import torch
     from . import bop_pose, scenes
-    from .compose import pose_table
     from .dataset_writer import BopSceneWriter
     from .frames import FrameRenderer
     if not torch.cuda.is_available():
@@ -47,21 +46,12 @@ def main():
         vs = views[b0:b0 + args.batch]
         poses, m2w = None, [{k + 1: np.eye(4) for k in range(fr.K)}] * len(vs)
         if args.dynamic and fr.K:
-            from scipy.spatial.transform import Rotation as Rot
-            tables, m2w = [], []
-            for j in range(len(vs)):
-                s, pairs, rec = b0 + j, [], {}
-                for k in range(fr.K):
-                    T = np.eye(4)
-                    T[:3, :3] = Rot.from_euler("z", 0.05 * s * (1 + 0.1 * k)).as_matrix()
-                    T[:3, 3] = [0.0, 0.0, 0.03 * abs(np.sin(0.2 * s + k))]
-                    pairs.append((T, centers[k]))
-                    Cp, Cm = np.eye(4), np.eye(4)
-                    Cp[:3, 3], Cm[:3, 3] = centers[k], -centers[k]
-                    rec[k + 1] = Cp @ T @ Cm
-                tables.append(pose_table(pairs))
-                m2w.append(rec)
-            poses = np.stack(tables)
+            # time step s of the recorded drop (the reference's trajectory fixture, pegasus_amd/trajectory.py)
+            from . import trajectory as TJ
+            if b0 == 0:
+                seq_tables, seq_motion = TJ.sequence_poses(TJ.load_fixture(), centers, 200)
+            idx = [(b0 + j) % 200 for j in range(len(vs))]
+            poses, m2w = seq_tables[idx], [seq_motion[i] for i in idx]
         t1 = time.perf_counter()
         frames = fr.render_frames([fr.view_spec(v) for v in vs], poses=poses)
         torch.cuda.synchronize()

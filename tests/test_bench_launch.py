@@ -100,3 +100,18 @@ def test_dynamic_sequence_bench_line(gpu_device):
     assert p.returncode == 0, p.stderr[-3000:]
     assert "simulation_steps.json" in line["config"]["sequence"] and line["config"]["objects"] == 20
     assert line["cpu_baseline"]["value"] > 0 and line["value"] > 0
+
+
+@pytest.mark.gpu
+def test_one_rank_process_group_on_rccl(gpu_device):
+    """What can be rehearsed of the RCCL path on a one-GPU box: a ONE-rank process group on the real backend (`--force-dist`):
+    RCCL initialisation in this environment, all_gather_object / barrier / all_reduce of the timing protocol, the asynchronous
+    gather of uint8 and 16-bit-as-bytes frames and its check -- every collective call the N-rank run makes, with N = 1."""
+    p, line = _run([sys.executable, "bench.py", "--force-dist", "--backend", "nccl", "--scale", "0.03", "--steps", "2", "--warmup", "1",
+                    "--batch", "4", "--views", "8", "--slots", "2", "--no-drop-in", "--no-cpu-baseline"], timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = line["config"]["distributed"]
+    assert d["backend"] == "nccl (RCCL)" and d["world_size"] == 1 and line["n_gpus"] == 1 and "rehearsal" in line
+    g = line["config"]["gather"]
+    assert g["check"] == "ok" and g["bytes_per_rank_and_batch"] == 4 * 800 * 800 * (3 + 2 + 1)
+    assert g["views_per_s_with_gather"] > 0 and g["views_per_s_render_only"] > 0
