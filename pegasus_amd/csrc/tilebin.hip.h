@@ -453,9 +453,9 @@ __device__ unsigned int g_sort_rec_n;
 // NB = number of buckets (multiple of THREADS; THREADS*E = one per key of capacity).  DIRECT: sorted indices go
 // straight to global memory (4-B scattered stores into an L2-resident list) instead of through an LDS image -- the
 // 16384-key tier has no LDS left for one.
-// lds: THREADS*E*8 + NB*4 + 128 bytes (NB >= THREADS*E unless DIRECT).  Returns false (LDS free for reuse, nothing
+// lds: KEYS*8 + NB*4 + 128 bytes (NB >= THREADS*E unless DIRECT; KEYS = the most keys a call may hold, THREADS*E by default).  Returns false (LDS free for reuse, nothing
 // written) when the list is rejected.
-template <int THREADS, int E, int NB = THREADS * E, bool DIRECT = false>
+template <int THREADS, int E, int NB = THREADS * E, bool DIRECT = false, int KEYS = THREADS * E>
 __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds, const uint2* __restrict__ bucket,
                                                  uint32_t* __restrict__ out, int n, int n_env,
                                                  uint32_t* __restrict__ obj_last, uint32_t pos_offset = 0,
@@ -463,8 +463,9 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
     constexpr int CAP = THREADS * E, WAVES = THREADS / WAVE, CH = NB / (WAVES * WAVE);   // 64-bucket chunks per wave
     static_assert(NB % (WAVES * WAVE) == 0 && (DIRECT || NB >= CAP), "bucket count");
     static_assert((4 + WAVES) * 4 <= 128, "s_misc must fit the 128 bytes the callers reserve behind the counters");
-    uint64_t* s_keys = reinterpret_cast<uint64_t*>(lds);                       // [CAP]
-    uint32_t* s_hist = reinterpret_cast<uint32_t*>(lds + (size_t)CAP * 8);     // [NB], later the sorted indices
+    static_assert(KEYS <= CAP, "key image");
+    uint64_t* s_keys = reinterpret_cast<uint64_t*>(lds);                       // [KEYS] (n <= KEYS <= CAP)
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(lds + (size_t)KEYS * 8);    // [NB], later the sorted indices
     uint32_t* s_misc = s_hist + NB;                                            // [0] min [1] max [2] sum k^2 [4..] wave totals
     const int t = threadIdx.x, lane = t & (WAVE - 1), wave = t / WAVE;
 #ifdef PGR_SORT_TIMING
@@ -645,8 +646,13 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
 // coarse bucket piles up or the list needs more than PART_MAX_SEGMENTS segments; the caller then merges LDS-sorted
 // chunks through L2.
 constexpr int SORT_LARGE_THREADS = 1024;
-constexpr int SORT_LARGE_MAX = SORT_LARGE_THREADS * 16;     // 16384
-constexpr int SORT_LARGE_BUCKETS = 4096;
+constexpr int SORT_LARGE_MAX = SORT_LARGE_THREADS * 16;     // 16384: register capacity of a 1024-thread workgroup at 16 keys each
+// The open-ended tier sorts up to SORT_LARGE_KEYS keys in one LDS image: 8 B per key + 8192 buckets = 157 KiB of the CU's
+// 160.  (Round 3: 4096 buckets under 16384 keys put 2-4 keys into a bucket, and the serial ranking loop inside the buckets
+// was 45 % of such a list's cycles -- 54 % of the 5 M-Gaussian scene's keys sit in these lists.  Twice the buckets for
+// 2 % fewer keys; lists of 16001..16384 keys take the partition path with the longer ones.)
+constexpr int SORT_LARGE_KEYS = 16000;
+constexpr int SORT_LARGE_BUCKETS = 8192;
 constexpr int PART_BUCKETS = 4096;
 constexpr int PART_MAX_SEGMENTS = 63;
 
@@ -656,7 +662,7 @@ __device__ __forceinline__ bool partition_sort_long(unsigned char* __restrict__ 
                                                     uint32_t* __restrict__ out, int n, int n_env,
                                                     uint32_t* __restrict__ obj_last, const int32_t* __restrict__ tie,
                                                     const uint32_t* __restrict__ inv) {
-    constexpr int CAP = THREADS * E, HALF = CAP / 2, WAVES = THREADS / WAVE, CH = PART_BUCKETS / (WAVES * WAVE);
+    constexpr int CAP = SORT_LARGE_KEYS, HALF = CAP / 2, WAVES = THREADS / WAVE, CH = PART_BUCKETS / (WAVES * WAVE);
     static_assert(PART_BUCKETS % (WAVES * WAVE) == 0, "bucket count");
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(lds);         // [PART_BUCKETS] counts -> starts -> cursors
     uint32_t* s_misc = s_hist + PART_BUCKETS;                    // [0] min [1] max [2] largest bucket [4..] wave totals
@@ -725,7 +731,7 @@ __device__ __forceinline__ bool partition_sort_long(unsigned char* __restrict__ 
         const uint32_t a = s_cut[g];
         if (a >= (uint32_t)n) break;
         const int n_seg = (int)(s_cut[g + 1] - a);
-        if (!bucket_sort_tile<THREADS, E, SORT_LARGE_BUCKETS, true>(lds, alt + a, out + a, n_seg, n_env, obj_last, a, tie))
+        if (!bucket_sort_tile<THREADS, E, SORT_LARGE_BUCKETS, true, SORT_LARGE_KEYS>(lds, alt + a, out + a, n_seg, n_env, obj_last, a, tie))
             merge_sort_tile<THREADS, E>(reinterpret_cast<uint64_t*>(lds), alt + a, out + a, n_seg, nullptr, n_env, obj_last, a,
                                         tie, inv);
         __syncthreads();
@@ -819,7 +825,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? PGR_T1_WAVES : 4)) void 
     constexpr int CAP = THREADS * E;
     static_assert(!LAST || CAP == SORT_LARGE_MAX, "the open-ended tier");
     // bucket sort image: 12 B per key, or (last tier) keys + 4096 counters = 144 KiB; the merge sort's padded keys fit
-    constexpr size_t LDS_BYTES = LAST ? (size_t)CAP * 8 + SORT_LARGE_BUCKETS * 4 + 128 : (size_t)CAP * 12 + 128;
+    constexpr size_t LDS_BYTES = LAST ? (size_t)SORT_LARGE_KEYS * 8 + SORT_LARGE_BUCKETS * 4 + 128 : (size_t)CAP * 12 + 128;
     static_assert((size_t)THREADS * (E + 1) * 8 <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "lds");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     __shared__ uint32_t s_cut[LAST ? PART_MAX_SEGMENTS + 3 : 1];
@@ -832,8 +838,8 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? PGR_T1_WAVES : 4)) void 
             if constexpr (!LAST) {
                 if (!bucket_sort_tile<THREADS, E>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
                     merge_sort_tile<THREADS, E>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
-            } else if (n <= CAP) {
-                if (!bucket_sort_tile<THREADS, E, SORT_LARGE_BUCKETS, true>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+            } else if (n <= SORT_LARGE_KEYS) {
+                if (!bucket_sort_tile<THREADS, E, SORT_LARGE_BUCKETS, true, SORT_LARGE_KEYS>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
                     merge_sort_tile<THREADS, E>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
             } else if (partition_sort_long<THREADS, E>(lds, s_cut, bucket, reinterpret_cast<uint2*>(alt), out, n, oo.n_env,
                                                        oo.last, oo.tie, oo.inv)) {
