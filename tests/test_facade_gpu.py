@@ -206,3 +206,78 @@ def test_render_facade_activation_cache_follows_the_model(gpu_device):
                                           cloud.scaling, cloud.rotation, device=dev)
         e = render(cam, fresh, pipe, bg)["render"]
         assert torch.equal(d, e)                                   # what an uncached model with the same values renders
+
+
+@pytest.mark.gpu
+def test_semantic_wrappers_follow_objects_cameras_and_backgrounds(gpu_device):
+    """render_visib_mask / render_semanticsegmentation_mask share one objects-only scene and one render per (scene, camera,
+    background) (round 3).  Whatever is kept must be dropped the moment an object moves, is re-assigned or re-coloured, the
+    camera changes or the background changes -- every result below is compared with the same call on a cold cache."""
+    import copy
+    import sys
+    from argparse import ArgumentParser
+    import torch
+    root = str(Path(__file__).resolve().parents[1])
+    for p in (root, root + "/compat"):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from gaussian_renderer import GaussianModel
+    from scene.cameras import Camera
+    from arguments import PipelineParams
+    from pegasus_amd import masks, render as prender, scenes
+    dev = gpu_device
+    rng = np.random.default_rng(4)
+    env_c = scenes.ground_plane(rng, 8000, 1.0, np.log(0.006), 0.4, 0.1, 0.005)
+    obj_c = [scenes.rigid_transform(scenes.box_object(rng, 4000, (0.1, 0.12, 0.16), np.log(0.004), 0.3, 0.2, k + 1),
+                                    np.eye(3), np.array([0.15 * k - 0.08, 0.05 * k, 0.09])) for k in range(2)]
+    mk = lambda c: GaussianModel.from_arrays(c.xyz, c.features_dc, c.features_rest, c.opacity, c.scaling, c.rotation, device=dev)
+    views = scenes.scene_c3(scale=0.001, n_views=2, width=320, height=240)[1]
+    cams = [Camera(colmap_id=i, R=v.R_c2w, T=v.t_w2c, FoVx=v.fovx, FoVy=v.fovy, image=None, image_width=v.width,
+                   image_height=v.height, gt_alpha_mask=None, image_name=str(i), uid=i, data_device=str(dev))
+            for i, v in enumerate(views)]
+    H, W = views[0].height, views[0].width
+    pipe = PipelineParams(ArgumentParser())
+    with torch.no_grad():
+        env, objs = mk(env_c), {k + 1: mk(c) for k, c in enumerate(obj_c)}
+        colors = torch.from_numpy(masks.generate_colors(len(objs))).to(dev)
+        prender.assign_semantic_colors(objs, colors)
+        bg = torch.zeros(3, device=dev)
+
+        def both(cam, background, cold):
+            if cold:
+                prender._kept_scene.clear()
+            vis, seg = prender.render_visib_mask(cam, env, objs, colors, H, W, pipe, background)
+            sem = prender.render_semanticsegmentation_mask(cam, env, objs, colors, H, W, pipe, background, False)
+            return vis.copy(), seg.clone(), sem.copy()
+
+        def same(a, b):
+            return np.array_equal(a[0], b[0]) and torch.equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+        first = both(cams[0], bg, cold=True)
+        assert first[0].sum() > 100
+        np.testing.assert_array_equal(first[2], (np.ascontiguousarray(first[1].numpy()) * 255).astype("uint8"))
+        assert same(both(cams[0], bg, cold=False), first)                    # warm == cold
+        other_cam = both(cams[1], bg, cold=False)                           # another camera on the warm scene
+        assert same(other_cam, both(cams[1], bg, cold=True)) and not same(other_cam, first)
+        white = torch.ones(3, device=dev)                                   # another background tensor
+        w_warm = both(cams[0], white, cold=False)
+        assert same(w_warm, both(cams[0], white, cold=True)) and not torch.equal(w_warm[1], first[1])
+        bg.fill_(0.25)                                                      # the SAME background tensor, edited in place
+        e_warm = both(cams[0], bg, cold=False)
+        assert same(e_warm, both(cams[0], bg, cold=True)) and not torch.equal(e_warm[1], first[1])
+        bg.zero_()
+        objs[1].apply_translation_on_xyz(torch.tensor([0.05, 0.0, 0.02], device=dev))       # an object moves (re-assignment)
+        moved = both(cams[0], bg, cold=False)
+        assert same(moved, both(cams[0], bg, cold=True)) and not np.array_equal(moved[0], first[0])
+        objs[2]._xyz.add_(torch.tensor([0.0, -0.04, 0.0], device=dev))                       # ... and one in place
+        moved2 = both(cams[0], bg, cold=False)
+        assert same(moved2, both(cams[0], bg, cold=True)) and not np.array_equal(moved2[0], moved[0])
+        objs[1]._opacity = objs[1]._opacity - 4.0                                            # nearly transparent now
+        faint = both(cams[0], bg, cold=False)
+        assert same(faint, both(cams[0], bg, cold=True)) and faint[0][..., 0].sum() < moved2[0][..., 0].sum()
+        swapped = torch.flip(colors, dims=[0]).contiguous()                                  # objects re-coloured
+        prender.assign_semantic_colors(objs, swapped)
+        recol = both(cams[0], bg, cold=False)
+        assert same(recol, both(cams[0], bg, cold=True)) and not torch.equal(recol[1], faint[1])
+        # the objects keep the paint, as the reference's callers expect (render.py:51-52)
+        assert torch.equal(objs[2]._features_dc, objs[2]._features_dc_semantics.expand_as(objs[2]._features_dc))
