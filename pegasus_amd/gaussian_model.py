@@ -186,7 +186,7 @@ class GaussianModel:
     def _headroom(n: int) -> int:
         return n + max(n // 2, 1 << 16)
 
-    def _append_rows(self, k, cur, add):
+    def _append_rows(self, k, cur, add, pending=None):
         if torch.is_grad_enabled() and (cur.requires_grad or add.requires_grad):
             return torch.vstack((cur, add))
         n, m = int(cur.shape[0]), int(add.shape[0])
@@ -198,13 +198,24 @@ class GaussianModel:
         if not fits:
             buf = torch.empty((self._headroom(n + m),) + tuple(cur.shape[1:]), dtype=cur.dtype, device=cur.device)
             buf[:n].copy_(cur)
-        buf[n:n + m].copy_(add)
+        if pending is None:
+            buf[n:n + m].copy_(add)
+        else:
+            pending.append((buf[n:n + m], add))
         rows[k] = [buf, n + m]
         return buf[:n + m]
 
     def merge_gaussians(self, gaussian):
+        pending = []                                     # the six row copies of a merge go out as ONE multi-tensor launch
         for k in self._ROW_ATTRS:
-            setattr(self, k, self._append_rows(k, getattr(self, k), getattr(gaussian, k)))
+            setattr(self, k, self._append_rows(k, getattr(self, k), getattr(gaussian, k), pending))
+        if pending:
+            dst, src = [d for d, _ in pending], [a for _, a in pending]
+            if all(d.dtype == a.dtype and d.device == a.device for d, a in pending):
+                torch._foreach_copy_(dst, src)
+            else:
+                for d, a in pending:
+                    d.copy_(a)
 
     def __deepcopy__(self, memo):
         """copy.deepcopy(model): what PEGASUS's frame loop does with the environment before merging the objects into the copy
@@ -212,7 +223,7 @@ class GaussianModel:
         attributes cloned into buffers that leave room for the merges that follow."""
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
-        rows = {}
+        rows, dst, src = {}, [], []
         for k, v in self.__dict__.items():
             if k == "_rows":
                 continue
@@ -220,11 +231,18 @@ class GaussianModel:
                     type(v) is torch.Tensor and v.is_contiguous()):
                 n = int(v.shape[0])
                 buf = torch.empty((self._headroom(n),) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
-                buf[:n].copy_(v)
+                dst.append(buf[:n]); src.append(v)
                 new.__dict__[k] = buf[:n]
                 rows[k] = [buf, n]
             else:
                 new.__dict__[k] = copy.deepcopy(v, memo)
+        if dst:
+            with torch.no_grad():
+                if len({(t.device, t.dtype) for t in dst}) == 1:
+                    torch._foreach_copy_(dst, src)            # the six row attributes in one launch
+                else:
+                    for d, a in zip(dst, src):
+                        d.copy_(a)
         new.__dict__["_rows"] = rows
         return new
 
