@@ -23,6 +23,15 @@ for seed in range(first, first + count):
     if not np.array_equal(g["n_contrib"][ok], o["n_contrib"][ok]): fails.append("n_contrib")
     err = (np.abs(g["color"] - o["color"]) / np.maximum(1.0, np.abs(o["color"])))[:, ok].max(initial=0)
     if err > 1e-4: fails.append(f"colour {err:.2e}")
+    o0 = oracle.forward(**act, sh_degree=deg, **view.raster_kwargs(bg), num_threads=8, scale_modifier=mod, cull_mode=0)   # reference-style lists
+    ok0 = ~o0["ambig"].astype(bool) & np.isfinite(o0["color"]).all(axis=0) & np.isfinite(o0["out_depth"][0])
+    if not np.array_equal(g["radii"], o0["radii"]): fails.append("radii vs reference-style")
+    err0 = (np.abs(g["color"] - o0["color"]) / np.maximum(1.0, np.abs(o0["color"])))[:, ok0].max(initial=0)
+    if err0 > 1e-4: fails.append(f"colour vs reference-style lists {err0:.2e}")
+    from test_gpu_parity import _last_blended
+    if not np.array_equal(_last_blended(g["gauss_sorted"], g["ranges"], g["n_contrib"], view.width, view.height)[ok0],
+                          _last_blended(o0["gauss_sorted"], o0["ranges"], o0["n_contrib"], view.width, view.height)[ok0]):
+        fails.append("last blended Gaussian vs reference-style lists")
     if fails:
         bad += 1
         print(f"seed {seed}: n {act['means3d'].shape[0]} {view.width}x{view.height} deg {deg} mod {mod}: {fails}")
