@@ -562,3 +562,22 @@ def test_c2_against_reference_style_lists(oracle, gpu_device):
     lo = _last_blended(o0["gauss_sorted"], o0["ranges"], o0["n_contrib"], v.width, v.height)
     np.testing.assert_array_equal(lg[~amb], lo[~amb])
     assert (lg >= 0).mean() > 0.02
+
+
+def test_hip_agrees_with_independent_dense_float64_renderer(gpu_device):
+    """The HIP path against the second, independently written restatement directly (oracle/dense_ref.py: numpy float64, no
+    tiles, no lists, every Gaussian against every pixel in global depth order, its own SH basis derived from Legendre
+    recurrences) -- not through the C oracle: an error the oracle and the kernels shared (they were developed together)
+    would show here."""
+    from helpers import gpu_forward
+    from oracle.dense_ref import dense_forward
+    for seed, deg, bg in ((21, 3, (0.1, 0.3, 0.5)), (22, 1, (0.0, 0.0, 0.0))):
+        cloud, views = scenes.scene_c1(seed=seed, n=1500)
+        v = scenes.make_view(views[0].R_c2w.T, views[0].t_w2c, 96, 80, fovx=views[0].fovx, fovy=views[0].fovy)
+        act = cloud.activated()
+        g = gpu_forward(act, v, sh_degree=deg, bg=bg, device=str(gpu_device), fetch_intermediates=False)
+        c64, d64 = dense_forward(sh_degree=deg, **{k: np.asarray(a, np.float64) for k, a in act.items()}, **v.raster_kwargs(bg))
+        # float64 vs float32 arithmetic: differences are rounding only, except where a threshold decision flips
+        dc, dd = np.abs(g["color"] - c64), np.abs(g["out_depth"][0] - d64)
+        assert np.quantile(dc, 0.999) < 5e-5 and np.quantile(dd, 0.999) < 5e-5, (seed, dc.max(), dd.max())
+        assert (dc > 1e-3).mean() < 1e-3 and (g["radii"] > 0).sum() > 500
