@@ -189,6 +189,8 @@ class GaussianModel:
     def _append_rows(self, k, cur, add, pending=None):
         if torch.is_grad_enabled() and (cur.requires_grad or add.requires_grad):
             return torch.vstack((cur, add))
+        if cur.numel() == 0 and cur.shape[1:] != add.shape[1:]:       # a model without rows yet takes the incoming layout
+            cur = add.new_empty((0,) + tuple(add.shape[1:]))
         n, m = int(cur.shape[0]), int(add.shape[0])
         rows = self.__dict__.setdefault("_rows", {})
         slot = rows.get(k)
