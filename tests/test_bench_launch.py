@@ -11,6 +11,15 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return str(p)
+
+
 def _run(cmd, env=None, timeout=300):
     e = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
@@ -38,7 +47,7 @@ def test_gpus_2_launches_two_ranks_by_itself_and_gathers():
 
 def test_outer_torchrun_and_no_gather():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29611", "bench.py", "--gpus", "2", "--stub-renderer", "--steps", "2", "--warmup", "0",
+           "--master-port", _free_port(), "bench.py", "--gpus", "2", "--stub-renderer", "--steps", "2", "--warmup", "0",
            "--batch", "3", "--no-gather", "--sync-steps"]
     p, line = _run(cmd)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -48,7 +57,7 @@ def test_outer_torchrun_and_no_gather():
 
 def test_world_size_mismatch_is_refused():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29612", "bench.py", "--gpus", "4", "--stub-renderer", "--steps", "1", "--warmup", "0"]
+           "--master-port", _free_port(), "bench.py", "--gpus", "4", "--stub-renderer", "--steps", "1", "--warmup", "0"]
     p, line = _run(cmd)
     assert p.returncode != 0 and line is None
     assert "WORLD_SIZE=2 but --gpus 4" in p.stderr
