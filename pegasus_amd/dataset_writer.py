@@ -94,7 +94,6 @@ class BopSceneWriter:
             batch_futures.append(self._pool.submit(self._write, path, image))
 
     def add_batch(self, frames: dict, scene_gt: dict, scene_camera: dict, n: int = None):
-        import torch
         from . import masks as M
         n = frames["color"].shape[0] if n is None else n
         # GPU: uint8 HWC / uint16 millimetres for the whole batch in one launch (pgr_pack_frames), then ONE device->host copy

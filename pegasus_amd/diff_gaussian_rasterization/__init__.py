@@ -18,7 +18,7 @@ torch's current stream, and memory comes from torch's caching allocator.  No CPU
 from __future__ import annotations
 
 import ctypes as C
-from typing import NamedTuple, Optional
+from typing import NamedTuple
 
 import torch
 from torch import nn

@@ -11,7 +11,6 @@ import copy
 
 import numpy as np
 import torch
-from torch import nn
 
 from . import compose
 from .ply_io import read_ply_vertices, write_ply_vertices

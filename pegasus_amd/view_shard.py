@@ -8,7 +8,7 @@ own xGMI links concurrently).  Backend-agnostic: the same code runs on gloo in t
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, List, Optional, Sequence
+from typing import Callable, Dict, List, Optional
 
 import torch
 import torch.distributed as dist
