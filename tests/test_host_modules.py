@@ -267,3 +267,62 @@ def test_merge_gaussians_appends_in_place_and_equals_vstack():
     m._xyz = p
     m.merge_gaussians(a)
     assert m._xyz.requires_grad and m._xyz.shape[0] == 34
+
+
+def test_network_gui_round_trip_over_loopback():
+    """The viewer socket of the reference's GUI branch (/root/reference/pegasus.py:85,249-279): a loopback client sends one
+    camera request and reads the answer -- init / try_connect / receive / send as the loop calls them, `conn` as the module
+    attribute the loop tests and resets."""
+    import json
+    import socket
+    import struct
+    import sys
+    from pathlib import Path
+    import numpy as np
+    import torch
+    root = str(Path(__file__).resolve().parents[1])
+    for p in (root, root + "/compat"):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from gaussian_renderer import network_gui
+    network_gui.device = "cpu"
+    network_gui.conn = None
+    network_gui.init("127.0.0.1", 0)                       # port 0: any free port
+    network_gui.try_connect()
+    assert network_gui.conn is None                        # nobody there yet; the loop just carries on
+    client = socket.create_connection(("127.0.0.1", network_gui.port))
+    for _ in range(100):
+        network_gui.try_connect()
+        if network_gui.conn is not None:
+            break
+    assert network_gui.conn is not None
+    rng = np.random.default_rng(0)
+    view, proj = rng.normal(size=(4, 4)), rng.normal(size=(4, 4))
+    req = dict(resolution_x=64, resolution_y=48, train=0, fov_y=0.7, fov_x=0.9, z_near=0.01, z_far=100.0, shs_python=0,
+               rot_scale_python=1, keep_alive=1, scaling_modifier=0.5, view_matrix=view.reshape(-1).tolist(),
+               view_projection_matrix=proj.reshape(-1).tolist())
+    body = json.dumps(req).encode()
+    client.sendall(struct.pack("<i", len(body)) + body)
+    cam, train, shs_py, cov_py, keep, mod = network_gui.receive()
+    assert (cam.image_width, cam.image_height, train, shs_py, cov_py, keep, mod) == (64, 48, False, False, True, True, 0.5)
+    want_view = view.astype(np.float32).copy(); want_view[:, 1] *= -1; want_view[:, 2] *= -1
+    want_proj = proj.astype(np.float32).copy(); want_proj[:, 1] *= -1
+    np.testing.assert_array_equal(cam.world_view_transform.numpy(), want_view)
+    np.testing.assert_array_equal(cam.full_proj_transform.numpy(), want_proj)
+    np.testing.assert_allclose(cam.camera_center.numpy(), np.linalg.inv(want_view.astype(np.float64))[3, :3], rtol=1e-4, atol=1e-5)
+    image = bytes(range(256)) * 36                         # 64 x 48 x 3 bytes
+    network_gui.send(image, "/data/scene")
+    got = b""
+    while len(got) < len(image) + 4 + 11:
+        got += client.recv(65536)
+    assert got[:len(image)] == image
+    assert struct.unpack("<i", got[len(image):len(image) + 4])[0] == 11 and got[len(image) + 4:] == b"/data/scene"
+    # a request without a resolution carries no camera; the answer is the check string alone
+    req.update(resolution_x=0, resolution_y=0)
+    body = json.dumps(req).encode()
+    client.sendall(struct.pack("<i", len(body)) + body)
+    assert network_gui.receive()[0] is None
+    network_gui.send(None, "x")
+    assert client.recv(16) == struct.pack("<i", 1) + b"x"
+    client.close()
+    network_gui.conn = None                                # what the loop does after a dropped connection
