@@ -46,6 +46,11 @@ static bool block_cull_enabled() {
 }
 
 
+static bool records_enabled() {      // PGR_BIN_RECORDS=0: the scatter walk re-evaluates every candidate (A/B, tests)
+    const char* e = getenv("PGR_BIN_RECORDS");
+    return !(e && e[0] == '0');
+}
+
 static Layout make_layout(int32_t n, int32_t width, int32_t height, int64_t max_instances) {
     Layout L{};
     const size_t N = (size_t)(n > 0 ? n : 0), I = (size_t)(max_instances > 0 ? max_instances : 0);
@@ -253,6 +258,10 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     auto* pres = reinterpret_cast<PreOut*>(hs + B.pre_table_off);
     auto* h_status = reinterpret_cast<uint32_t*>(hs + B.tables_bytes);
     bool want_aux = false, want_sem = false;
+    // the count walk's verdicts live where the sort's outputs will (alt, gauss_sorted: contiguous, dead until the sort)
+    const size_t verdict_room = (L.total - L.alt) / (VERDICT_REGION_WORDS * 4);
+    const int verdict_groups = L.tiles <= BIN_LDS_TILES && records_enabled()
+                                   ? (int)std::min<size_t>(verdict_room, (size_t)(N + WAVE - 1) / WAVE) : 0;
     for (int v = 0; v < n_views; ++v) {
         vw[v] = carve(ws + B.views + (size_t)v * B.per_view, L);
         vw[v].cam = cams_dev + v;          // cameras of a batch are contiguous: preprocess walks them
@@ -273,7 +282,8 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         bins[v] = BinView{vw[v].crects, vw[v].splats, vw[v].tile_count, vw[v].rel, vw[v].ranges,
                           vw[v].counters, vw[v].bucket, vw[v].gauss_sorted, vw[v].alt, vw[v].obj_last,
                           semantic ? semantic->n_env : -1, scene->tie_index,
-                          scene->tie_index ? reinterpret_cast<const uint32_t*>(ws + B.tie_inv) : nullptr};
+                          scene->tie_index ? reinterpret_cast<const uint32_t*>(ws + B.tie_inv) : nullptr,
+                          reinterpret_cast<uint2*>(vw[v].alt)};
         // radii and the reference-style 3-sigma rectangles are per-view OUTPUTS: written only when the caller asks for
         // radii (12 N bytes per view the frame path never reads; pgr_workspace_view's `rects` is valid only then)
         pres[v] = PreOut{vw[v].splats, outs[v].radii ? vw[v].rects : nullptr, vw[v].crects, outs[v].radii};
@@ -320,12 +330,12 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     if (!hip_ok(hipMemsetAsync(ws + B.tile_counts, 0, (size_t)n_views * L.tiles * 8, stream), "memset tile counts"))
         return fail(PGR_ERR_LAUNCH_FAILURE);
     bin_kernel<false><<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(bin_table, N, grid_x, L.tiles, W, H, vis,
-                                                                               B.vis_words);
+                                                                               B.vis_words, verdict_groups);
     tile_scan_kernel<<<n_views, 1024, 0, stream>>>(bin_table, L.tiles, (uint32_t)max_instances);
     mark(2);
     // ---- stage 2: scatter (depth bits, index) into the tiles' slices
     bin_kernel<true><<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(bin_table, N, grid_x, L.tiles, W, H, vis,
-                                                                              B.vis_words);
+                                                                              B.vis_words, verdict_groups);
     mark(3);
     // ---- stage 3: work order (XCD streams, longest lists first) + per-tile (depth, index) sort
     if (!hip_ok(hipMemsetAsync(order_state, 0, ORDER_STATE_WORDS * 4, stream), "memset order state") ||

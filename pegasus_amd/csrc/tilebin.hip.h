@@ -21,6 +21,8 @@
 //
 // Everything is integer/bit work: bit-exact against the oracle's sorted lists.
 #pragma once
+#include <type_traits>
+
 #include "cull.hip.h"
 #include "pgr_common.h"
 
@@ -58,6 +60,10 @@ struct BinView {                 // per-view pointers used by the binning kernel
     // them back to positions through tie_inv.  NULL = the position is the tie index.
     const int32_t* tie_index;
     const uint32_t* tie_inv;
+    // What the count walk found, kept for the scatter walk (see bin_kernel): a fixed region per 64-Gaussian group (its 64
+    // depths + one ballot per window of candidates), in the space the sort only needs AFTER the scatter walk (alt +
+    // gauss_sorted).
+    uint2* records;
 };
 
 
@@ -109,11 +115,21 @@ __device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v) {
 // iteration from ~180 to ~85.
 //   SCATTER = false: lds[] = tile histogram; flushed with one coalesced reserving atomic per touched tile.
 //   SCATTER = true : lds[] = write cursors (range start + this chunk's reserved offset).
+// The count walk leaves what it found behind, ONE BIT PER CANDIDATE: per window of a group's walk the ballot of the
+// predicate (8 bytes per 64 candidates, ~1 MB per view), in front of them the group's 64 depths (256 contiguous bytes
+// instead of 64 words at a 48-byte stride).  Every 64-Gaussian group owns a fixed 768-byte region (64 depths + 62 ballots:
+// up to 3 968 candidates; a group with more is simply evaluated twice as before), so there is nothing to reserve and
+// nothing to look up: region = group index x 768 B, in the space the sort only needs after the scatter walk (alt +
+// gauss_sorted).  The scatter walk then repeats the candidate enumeration -- same groups, same windows -- but takes the
+// verdict from the bit instead of evaluating the predicate again, skips windows without a set bit, and reads neither the
+// splat records nor their strided depths.
 constexpr int BIN_WAVES = BIN_THREADS / WAVE;
 constexpr int BIN_STAGE_WORDS = WAVE * 12 + WAVE;         // per wave: 64 x 3 float4 + 64 head words
 __host__ __device__ inline size_t bin_lds_bytes(int tiles) {
     return ((size_t)(tiles < BIN_LDS_TILES ? tiles : BIN_LDS_TILES) + 3) / 4 * 16 + (size_t)BIN_WAVES * BIN_STAGE_WORDS * 4 + 16;
 }
+constexpr uint32_t VERDICT_WINDOWS = 62;                               // ballots per group region
+constexpr uint32_t VERDICT_REGION_WORDS = 192;                         // 4-byte words: 64 depths + 2 x 62 (+ 4 unused)
 
 // vis: blockcull.hip.h's visibility words (NULL = all visible); a 64-Gaussian group whose bit is clear has no rectangle
 // to read (the preprocess did not write one).
@@ -122,10 +138,12 @@ __host__ __device__ inline size_t bin_lds_bytes(int tiles) {
 // of iterations, and a static split left most waves of a workgroup waiting for its slowest one.  A group's rectangles and
 // records are fetched with all loads in flight at once (a visible group's Gaussians are nearly all visible, so the
 // records do not wait for the rectangle).
+//
+// verdict_groups: how many groups have a region (0: none -- more tiles than one LDS pass holds, or PGR_BIN_RECORDS=0).
 template <bool SCATTER>
 __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restrict__ views, int n, int grid_x,
                                                           int tiles, int W, int H, const uint32_t* __restrict__ vis,
-                                                          int vis_words) {
+                                                          int vis_words, int verdict_groups) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const BinView& bv = views[blockIdx.y];
     if (SCATTER && gload(bv.counters + 1)) return;   // overflow: reported by the host, nothing may be written past the buffers
@@ -164,71 +182,111 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restr
                 if (ticket >= (uint32_t)GROUPS || ((vis_bits >> ticket) & 1ull)) return ticket;
             }
         };
-        struct Fetched { uint2 r; float4 q0, q1; float depth; };
-        auto fetch = [&](uint32_t ticket) {
-            Fetched f;
-            const int i = begin + (int)ticket * WAVE + lane;
-            const int ic = i < end ? i : end - 1;
-            f.r = gload(bv.rects + ic);
-            f.q0 = gload(bv.splats + (size_t)ic * 3);
-            f.q1 = gload(bv.splats + (size_t)ic * 3 + 1);
-            f.depth = SCATTER ? gload(reinterpret_cast<const float*>(bv.splats + (size_t)ic * 3 + 2) + 3) : 0.0f;
-            if (i >= end) f.r = make_uint2(0u, 0u);
-            return f;
-        };
         for (uint32_t ticket = take_ticket(); ticket < (uint32_t)GROUPS; ticket = take_ticket()) {
             const int base = begin + (int)ticket * WAVE;
-            const Fetched cur = fetch(ticket);
-            const uint2 r = cur.r;
+            const bool has_region = base / WAVE < verdict_groups;
+            uint32_t* const region = reinterpret_cast<uint32_t*>(bv.records) + (size_t)(base / WAVE) * VERDICT_REGION_WORDS;
+            uint64_t* const ballots = reinterpret_cast<uint64_t*>(region + WAVE);
+            const int i = base + lane;
+            const int ic = i < end ? i : end - 1;
+            uint2 r = gload(bv.rects + ic);
+            float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+            float depth = 0.0f;
+            uint64_t my_ballot = 0;                  // scatter walk: lane l = the verdicts of window l
+            if (SCATTER && has_region) {             // (requested before the candidate count says whether they were written)
+                depth = __uint_as_float(gload(region + lane));
+                if (lane < (int)VERDICT_WINDOWS) my_ballot = gload(ballots + lane);
+            } else {
+                q0 = gload(bv.splats + (size_t)ic * 3);
+                q1 = gload(bv.splats + (size_t)ic * 3 + 1);
+                if (SCATTER || has_region) depth = gload(reinterpret_cast<const float*>(bv.splats + (size_t)ic * 3 + 2) + 3);
+            }
+            if (i >= end) r = make_uint2(0u, 0u);
             const int w = (int)(r.y & 0xffff) - (int)(r.x & 0xffff), h = (int)(r.y >> 16) - (int)(r.x >> 16);
             const uint32_t area = (w > 0 && h > 0) ? (uint32_t)(w * h) : 0u;
-            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
-            if (area) {
-                const CullSplat cs = make_cull_splat(make_float2(cur.q0.x, cur.q0.y), make_float4(cur.q0.z, cur.q0.w, cur.q1.x, cur.q1.y),
-                                                     cur.q1.z, cur.q1.w);
-                s0 = make_float4(cs.mx, cs.my, cs.A, cs.B);
-                s1 = make_float4(cs.C, cs.rBC, cs.rBA, cs.tau);
-                s2 = make_float4(__uint_as_float(cs.flags | ((uint32_t)w << 2)), __uint_as_float(r.x), 1.0f / (float)w, cur.depth);
-            }
-            stage[lane * 3 + 0] = s0; stage[lane * 3 + 1] = s1; stage[lane * 3 + 2] = s2;
-            __builtin_amdgcn_wave_barrier();
             const uint32_t incl = wave_inclusive_scan(area);
             const uint32_t excl = incl - area;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
-            uint32_t carry_key = 0;        // owner of the candidate just before the window: (start + 1) << 6 | lane
-            for (uint32_t c0 = 0; c0 < total; c0 += WAVE) {
-                heads[lane] = 0u;
-                asm volatile("" ::: "memory");
-                if (area && excl - c0 < (uint32_t)WAVE) heads[excl - c0] = ((excl + 1u) << 6) | (uint32_t)lane;
-                asm volatile("" ::: "memory");
-                uint32_t key = wave_inclusive_max(heads[lane]);     // same wave: LDS ops are ordered
-                asm volatile("" ::: "memory");
-                key = key ? key : carry_key;
-                carry_key = (uint32_t)__builtin_amdgcn_readlane((int)key, WAVE - 1);
-                const uint32_t c = c0 + (uint32_t)lane;
-                const int g = (int)(key & 63u);
-                const uint32_t k = c - ((key >> 6) - 1u);
-                const float4 o2 = stage[g * 3 + 2];
-                const uint32_t fw = __float_as_uint(o2.x), rlo = __float_as_uint(o2.y);
-                const int ow = (int)(fw >> 2);
-                // ty = k / w: reciprocal estimate, then an exact +-1 correction
-                int ty = (int)(((float)k + 0.5f) * o2.z);
-                int tx = (int)k - ty * ow;
-                if (tx < 0) { --ty; tx += ow; } else if (tx >= ow) { ++ty; tx -= ow; }
-                const int x = (int)(rlo & 0xffff) + tx, y = (int)(rlo >> 16) + ty;
-                const int t = y * grid_x + x - lo;
-                bool pass = c < total && (unsigned)t < (unsigned)span;
-                if (pass) {
-                    const float4 o0 = stage[g * 3 + 0], o1 = stage[g * 3 + 1];
-                    CullSplat cs;
-                    cs.mx = o0.x; cs.my = o0.y; cs.A = o0.z; cs.B = o0.w;
-                    cs.C = o1.x; cs.rBC = o1.y; cs.rBA = o1.z; cs.tau = o1.w; cs.flags = fw & 3u;
-                    pass = tile_may_contribute(cs, x, y, W, H);
+            const bool bits = has_region && total <= VERDICT_WINDOWS * (uint32_t)WAVE;   // same verdict in both walks
+            if (SCATTER && has_region && !bits) {
+                q0 = gload(bv.splats + (size_t)ic * 3);
+                q1 = gload(bv.splats + (size_t)ic * 3 + 1);
+                depth = gload(reinterpret_cast<const float*>(bv.splats + (size_t)ic * 3 + 2) + 3);
+            }
+            // one group's walk, compiled per combination of FROM_BITS (scatter walk: verdicts are read) and WRITE_BITS
+            // (count walk: verdicts are kept): the loop bodies are free of mode branches (one body with run-time flags:
+            // scatter walk 22.5 -> 27 us)
+            auto walk = [&](auto from_bits_c, auto write_bits_c) {
+                constexpr bool FROM_BITS = decltype(from_bits_c)::value, WRITE_BITS = decltype(write_bits_c)::value;
+                float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
+                if (area) {
+                    uint32_t flags = 0;
+                    if (!FROM_BITS) {
+                        const CullSplat cs = make_cull_splat(make_float2(q0.x, q0.y), make_float4(q0.z, q0.w, q1.x, q1.y), q1.z, q1.w);
+                        s0 = make_float4(cs.mx, cs.my, cs.A, cs.B);
+                        s1 = make_float4(cs.C, cs.rBC, cs.rBA, cs.tau);
+                        flags = cs.flags;
+                    }
+                    s2 = make_float4(__uint_as_float(flags | ((uint32_t)w << 2)), __uint_as_float(r.x), 1.0f / (float)w, depth);
                 }
-                if (pass) {
-                    const uint32_t slot = atomicAdd(&lds[t], 1u);
-                    if (SCATTER) gstore(bv.bucket + slot, make_uint2(__float_as_uint(o2.w), (uint32_t)(base + g)));
+                if (!FROM_BITS) { stage[lane * 3 + 0] = s0; stage[lane * 3 + 1] = s1; }
+                stage[lane * 3 + 2] = s2;
+                __builtin_amdgcn_wave_barrier();
+                if (WRITE_BITS && total) gstore(region + lane, __float_as_uint(depth));
+                uint32_t carry_key = 0;        // owner of the candidate just before the window: (start + 1) << 6 | lane
+                uint32_t it = 0;
+                for (uint32_t c0 = 0; c0 < total; c0 += WAVE, ++it) {
+                    uint64_t verdicts = ~0ull;
+                    if (FROM_BITS) {
+                        const uint32_t vlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_ballot, (int)it);
+                        const uint32_t vhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_ballot >> 32), (int)it);
+                        verdicts = ((uint64_t)vhi << 32) | vlo;
+                    }
+                    heads[lane] = 0u;
+                    asm volatile("" ::: "memory");
+                    if (area && excl - c0 < (uint32_t)WAVE) heads[excl - c0] = ((excl + 1u) << 6) | (uint32_t)lane;
+                    asm volatile("" ::: "memory");
+                    uint32_t key = wave_inclusive_max(heads[lane]);     // same wave: LDS ops are ordered
+                    asm volatile("" ::: "memory");
+                    key = key ? key : carry_key;
+                    carry_key = (uint32_t)__builtin_amdgcn_readlane((int)key, WAVE - 1);
+                    if (FROM_BITS && verdicts == 0ull) continue;          // nothing of this window is listed
+                    const uint32_t c = c0 + (uint32_t)lane;
+                    const int g = (int)(key & 63u);
+                    const uint32_t k = c - ((key >> 6) - 1u);
+                    const float4 o2 = stage[g * 3 + 2];
+                    const uint32_t fw = __float_as_uint(o2.x), rlo = __float_as_uint(o2.y);
+                    const int ow = (int)(fw >> 2);
+                    // ty = k / w: reciprocal estimate, then an exact +-1 correction
+                    int ty = (int)(((float)k + 0.5f) * o2.z);
+                    int tx = (int)k - ty * ow;
+                    if (tx < 0) { --ty; tx += ow; } else if (tx >= ow) { ++ty; tx -= ow; }
+                    const int x = (int)(rlo & 0xffff) + tx, y = (int)(rlo >> 16) + ty;
+                    const int t = y * grid_x + x - lo;
+                    bool pass = c < total && (unsigned)t < (unsigned)span;
+                    if (FROM_BITS) {
+                        pass = pass && ((verdicts >> lane) & 1ull);
+                    } else if (pass) {
+                        const float4 o0 = stage[g * 3 + 0], o1 = stage[g * 3 + 1];
+                        CullSplat cs;
+                        cs.mx = o0.x; cs.my = o0.y; cs.A = o0.z; cs.B = o0.w;
+                        cs.C = o1.x; cs.rBC = o1.y; cs.rBA = o1.z; cs.tau = o1.w; cs.flags = fw & 3u;
+                        pass = tile_may_contribute(cs, x, y, W, H);
+                    }
+                    if (WRITE_BITS) {
+                        const uint64_t m = __ballot(pass);
+                        if (lane == 0) gstore(ballots + it, m);
+                    }
+                    if (pass) {
+                        const uint32_t slot = atomicAdd(&lds[t], 1u);
+                        if (SCATTER) gstore(bv.bucket + slot, make_uint2(__float_as_uint(o2.w), (uint32_t)(base + g)));
+                    }
                 }
+            };
+            if (SCATTER) {
+                if (bits) walk(std::true_type{}, std::false_type{}); else walk(std::false_type{}, std::false_type{});
+            } else {
+                if (bits) walk(std::false_type{}, std::true_type{}); else walk(std::false_type{}, std::false_type{});
             }
         }
         __syncthreads();

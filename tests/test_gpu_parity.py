@@ -334,6 +334,47 @@ def test_fused_semantic_pass_is_bit_identical(gpu_device):
         assert torch.equal(f2[k], ref[k]), k
 
 
+def test_count_walk_verdicts_every_mode(oracle, gpu_device, monkeypatch):
+    """The scatter walk takes the count walk's verdicts (one bit per candidate tile) where a group has a region and
+    evaluates the predicate itself where it has none; the lists must not depend on which: (a) groups with more
+    candidates than a region holds (huge splats) next to ordinary ones, (b) the same with the verdicts switched off,
+    (c) an instance capacity so small that only some of the groups get a region."""
+    import torch
+    from pegasus_amd import rasterizer
+    # (a) 20 k splats blown up 6x at 512x512: thousands of candidates per 64-Gaussian group for most groups, few for some
+    cloud, views = scenes.scene_c1(seed=21, n=20_000)
+    cloud.scaling[:10_000] += np.float32(np.log(6.0))
+    v = scenes.make_view(views[0].R_c2w.T, views[0].t_w2c, 512, 512, fovx=views[0].fovx, fovy=views[0].fovy)
+    g, o = _run_both(oracle, cloud, v, gpu_device)
+    assert o["num_instances"] > 500_000
+    _check_all(g, o)
+    # (b) verdicts off: the very same lists
+    monkeypatch.setenv("PGR_BIN_RECORDS", "0")
+    g0, _ = _run_both(oracle, cloud, v, gpu_device)
+    monkeypatch.delenv("PGR_BIN_RECORDS")
+    for k in ("gauss_sorted", "ranges", "color", "n_contrib"):
+        np.testing.assert_array_equal(g0[k], g[k], err_msg=k)
+    # (c) 200 k one-tile splats, most of them outside the view: fewer instances than Gaussians, and a capacity that just
+    # holds them -> regions for about a third of the groups only
+    rng = np.random.default_rng(5)
+    n = 200_000
+    cloud2 = scenes.box_object(rng, n, (8.0, 8.0, 1.0), math.log(0.004), 0.4, 0.1, object_id=1)
+    g2, o2 = _run_both(oracle, cloud2, views[0], gpu_device)
+    need = int(o2["num_instances"])
+    assert 1000 < need < n // 3, need
+    dev = torch.device(gpu_device)
+    for key in list(rasterizer._WS.capacity_hint):
+        if key[1] == n:
+            rasterizer._WS.capacity_hint[key] = need + 64
+    for kk in [k for k in rasterizer._WS.buf if isinstance(k, tuple) and len(k) == 2 and isinstance(k[1], tuple)]:
+        rasterizer._WS.buf.pop(kk)
+    g3, _ = _run_both(oracle, cloud2, views[0], gpu_device)
+    assert rasterizer.last_forward_info()["used_max_instances"] == need + 64
+    assert (need + 64) * 12 // 768 < (n + 63) // 64        # fewer regions than groups
+    _check_all(g2, o2)
+    _check_all(g3, o2)
+
+
 def test_large_image_many_tiles(oracle, gpu_device):
     """More than 16384 tiles: the binning kernels sweep the tile space in several LDS passes."""
     cloud, _ = scenes.scene_c1(seed=12, n=6000)
