@@ -326,16 +326,25 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     mark(1);
     // ---- stage 1: per-chunk LDS tile histograms + slice reservation, then the tile scan (device only)
     const int grid_x = (W + TILE - 1) / TILE;
-    const size_t lds = bin_lds_bytes(L.tiles);
+    const bool few_views = n_views <= SMALL_BATCH_VIEWS;
+    const size_t lds = bin_lds_bytes(L.tiles, few_views ? BIN_THREADS_SMALL : BIN_THREADS);
     if (!hip_ok(hipMemsetAsync(ws + B.tile_counts, 0, (size_t)n_views * L.tiles * 8, stream), "memset tile counts"))
         return fail(PGR_ERR_LAUNCH_FAILURE);
-    bin_kernel<false><<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(bin_table, N, grid_x, L.tiles, W, H, vis,
-                                                                               B.vis_words, verdict_groups);
+    if (few_views)
+        bin_kernel<false, BIN_THREADS_SMALL><<<dim3(L.n_chunks, n_views), BIN_THREADS_SMALL, lds, stream>>>(
+            bin_table, N, grid_x, L.tiles, W, H, vis, B.vis_words, verdict_groups);
+    else
+        bin_kernel<false, BIN_THREADS><<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(
+            bin_table, N, grid_x, L.tiles, W, H, vis, B.vis_words, verdict_groups);
     tile_scan_kernel<<<n_views, 1024, 0, stream>>>(bin_table, L.tiles, (uint32_t)max_instances);
     mark(2);
     // ---- stage 2: scatter (depth bits, index) into the tiles' slices
-    bin_kernel<true><<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(bin_table, N, grid_x, L.tiles, W, H, vis,
-                                                                              B.vis_words, verdict_groups);
+    if (few_views)
+        bin_kernel<true, BIN_THREADS_SMALL><<<dim3(L.n_chunks, n_views), BIN_THREADS_SMALL, lds, stream>>>(
+            bin_table, N, grid_x, L.tiles, W, H, vis, B.vis_words, verdict_groups);
+    else
+        bin_kernel<true, BIN_THREADS><<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(
+            bin_table, N, grid_x, L.tiles, W, H, vis, B.vis_words, verdict_groups);
     mark(3);
     // ---- stage 3: work order (XCD streams, longest lists first) + per-tile (depth, index) sort
     if (!hip_ok(hipMemsetAsync(order_state, 0, ORDER_STATE_WORDS * 4, stream), "memset order state") ||

@@ -123,10 +123,14 @@ __device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v) {
 // gauss_sorted).  The scatter walk then repeats the candidate enumeration -- same groups, same windows -- but takes the
 // verdict from the bit instead of evaluating the predicate again, skips windows without a set bit, and reads neither the
 // splat records nor their strided depths.
-constexpr int BIN_WAVES = BIN_THREADS / WAVE;
 constexpr int BIN_STAGE_WORDS = WAVE * 12 + WAVE;         // per wave: 64 x 3 float4 + 64 head words
-__host__ __device__ inline size_t bin_lds_bytes(int tiles) {
-    return ((size_t)(tiles < BIN_LDS_TILES ? tiles : BIN_LDS_TILES) + 3) / 4 * 16 + (size_t)BIN_WAVES * BIN_STAGE_WORDS * 4 + 16;
+// One- and two-view calls launch 488 workgroups (C3) on 256 CUs and last as long as their heaviest chunk (7x the mean number
+// of candidates in a C3 view): 16 waves per chunk instead of 8 -- count walk 44.7 -> 33.1 us, scatter walk 58.4 -> 51.1 us
+// for a single view.  (Several workgroups per chunk, each with its own `rel` row: the scatter walk gains what the count
+// walk loses to the extra zero-fills and flushes of 2 500 tile counters -- 2 parts 43 / 45 us, 4 parts 55 / 38: dropped.)
+constexpr int BIN_THREADS_SMALL = 1024;
+__host__ __device__ inline size_t bin_lds_bytes(int tiles, int threads) {
+    return ((size_t)(tiles < BIN_LDS_TILES ? tiles : BIN_LDS_TILES) + 3) / 4 * 16 + (size_t)(threads / WAVE) * BIN_STAGE_WORDS * 4 + 16;
 }
 constexpr uint32_t VERDICT_WINDOWS = 62;                               // ballots per group region
 constexpr uint32_t VERDICT_REGION_WORDS = 192;                         // 4-byte words: 64 depths + 2 x 62 (+ 4 unused)
@@ -140,11 +144,12 @@ constexpr uint32_t VERDICT_REGION_WORDS = 192;                         // 4-byte
 // records do not wait for the rectangle).
 //
 // verdict_groups: how many groups have a region (0: none -- more tiles than one LDS pass holds, or PGR_BIN_RECORDS=0).
-template <bool SCATTER>
-__global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restrict__ views, int n, int grid_x,
+template <bool SCATTER, int THREADS>
+__global__ __launch_bounds__(THREADS) void bin_kernel(const BinView* __restrict__ views, int n, int grid_x,
                                                           int tiles, int W, int H, const uint32_t* __restrict__ vis,
                                                           int vis_words, int verdict_groups) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    constexpr int BIN_WAVES = THREADS / WAVE;
     const BinView& bv = views[blockIdx.y];
     if (SCATTER && gload(bv.counters + 1)) return;   // overflow: reported by the host, nothing may be written past the buffers
     const int chunk = blockIdx.x;
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restr
     static_assert(GROUPS == WAVE, "one visibility bit per lane of a wave");
     for (int lo = 0; lo < tiles; lo += BIN_LDS_TILES) {
         const int span = min(BIN_LDS_TILES, tiles - lo);
-        for (int t = threadIdx.x; t < span; t += BIN_THREADS)
+        for (int t = threadIdx.x; t < span; t += THREADS)
             lds[t] = SCATTER ? gload(bv.ranges + lo + t).x + gload(bv.rel + (size_t)chunk * tiles + lo + t) : 0u;
         if (wave == 0) {
             const int b = begin + lane * WAVE;
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_kernel(const BinView* __restr
         }
         __syncthreads();
         if (!SCATTER) {
-            for (int t = threadIdx.x; t < span; t += BIN_THREADS) {
+            for (int t = threadIdx.x; t < span; t += THREADS) {
                 const uint32_t cnt = lds[t];
                 gstore(bv.rel + (size_t)chunk * tiles + lo + t, cnt ? gatomic_add(bv.tile_count + lo + t, cnt) : 0u);
             }
