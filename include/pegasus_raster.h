@@ -22,6 +22,9 @@
  *   - The library never allocates or frees device memory and never touches the default stream:
  *     all work is enqueued on `stream` (a hipStream_t passed as void*).
  *   - Re-entrant, no global state.  One call = one stream = one workspace.
+ *   - Environment switches for A/B measurements and tests, read per call; results NEVER depend on them:
+ *     PGR_BLOCK_CULL=0 (no per-block view culling), PGR_BIN_RECORDS=0 (the scatter walk of the binning evaluates the
+ *     tight-list predicate itself instead of reading the count walk's verdicts).
  *   - Return value: 0 = enqueued; negative = PgrStatus.  pgr_status_string() names a code.
  */
 #ifndef PEGASUS_RASTER_H
