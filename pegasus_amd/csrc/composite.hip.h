@@ -76,7 +76,7 @@ constexpr int PAIR_UNROLL = PGR_PAIR_UNROLL;   // entry pairs per trip of the co
 // [8] fused waves, [9] tail batches (scene pixels saturated, semantic walk only), [10] tail entries walked, [11] tail entries gathered (object entries),
 // [12] tail entries live after the skip test, [13] waves that enter the tail, [14] waves that walk to the last object entry
 // [15] longest wave in shader clocks, [16] its batches, [17..20] waves with > 16 / 32 / 64 / 96 batches, [21] sum of wave clocks
-__device__ unsigned long long g_comp_stats[24];
+__device__ unsigned long long g_comp_stats[32];
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -182,6 +182,7 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
 #ifdef PGR_COMP_STATS
     unsigned long long st_walk = 0, st_live = 0, st_eval = 0, st_alive = 0, st_blend = 0, st_batches = 0, st_sem = 0;
     unsigned long long st_tb = 0, st_tw = 0, st_tg = 0, st_tl = 0, st_tend = 0;
+    unsigned long long st_mode_b[3] = {0, 0, 0}, st_mode_e[3] = {0, 0, 0};     // batches / parked entries per pair-loop mode
     const unsigned long long st_t0 = __builtin_readcyclecounter();
 #endif
     for (int base = 0; base < n; base += WAVE_BATCH) {
@@ -266,6 +267,9 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
         int mode = MODE_PLAIN;
         if (FUSED && objbits != 0ull) mode = (pure && objbits == parked_bits) ? MODE_RIDE : MODE_GENERAL;
         if (FUSED && mode == MODE_PLAIN && cnt > 0) pure = false;
+#ifdef PGR_COMP_STATS
+        if (FUSED && cnt > 0) { st_mode_b[mode] += 1; st_mode_e[mode] += (unsigned long long)cnt; }
+#endif
         bool all_done = false;
         auto pair_loop = [&](auto mode_tag) __attribute__((always_inline)) {
         constexpr int MODE = decltype(mode_tag)::value;
@@ -384,7 +388,8 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
           atomicAdd(&g_comp_stats[21], dt); }
         if (FUSED) { atomicAdd(&g_comp_stats[8], 1ull); atomicAdd(&g_comp_stats[9], st_tb); atomicAdd(&g_comp_stats[10], st_tw);
                      atomicAdd(&g_comp_stats[11], st_tg); atomicAdd(&g_comp_stats[12], st_tl); atomicAdd(&g_comp_stats[13], st_tb ? 1ull : 0ull);
-                     atomicAdd(&g_comp_stats[14], st_tend); }
+                     atomicAdd(&g_comp_stats[14], st_tend);
+                     for (int m = 0; m < 3; ++m) { atomicAdd(&g_comp_stats[22 + m], st_mode_b[m]); atomicAdd(&g_comp_stats[25 + m], st_mode_e[m]); } }
     }
 #endif
     if (inside) {

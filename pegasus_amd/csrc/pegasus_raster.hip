@@ -673,8 +673,8 @@ int32_t pgr_pack_frames(const float* color_b3hw, const float* depth_bhw, const u
 #ifdef PGR_COMP_STATS
 extern "C" int32_t pgr_debug_comp_stats(unsigned long long* out, int32_t reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -4;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pgr::g_comp_stats), 192) != hipSuccess) return -4;
-    if (reset) { unsigned long long z[24] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(pgr::g_comp_stats), z, 192) != hipSuccess) return -4; }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pgr::g_comp_stats), 256) != hipSuccess) return -4;
+    if (reset) { unsigned long long z[32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(pgr::g_comp_stats), z, 256) != hipSuccess) return -4; }
     return 0;
 }
 #endif

@@ -18,7 +18,7 @@ fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotat
                      sh_degree=3, device="cuda:0")
 specs = [fr.view_spec(v) for v in views[:B]]
 fr.render_frames(specs, None, masks=False)
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 32)()
 if hasattr(handle, "pgr_debug_sort_stats"):
     handle.pgr_debug_sort_stats(out, 1)
     fr.render_frames(specs, None, masks=False)
@@ -43,3 +43,7 @@ if masks:
     print(f"fused quarters {fw:.0f} per view; {tin:.0f} enter the semantic tail (scene pixels saturated, objects-only walk continues), "
           f"{tend:.0f} walk to the tile's last object entry; tail: {tb:.0f} batches, {tw/1e6:.3f} M entries walked, "
           f"{tg/1e6:.3f} M object records gathered, {tl/1e6:.3f} M live after the skip test")
+    names = ("PLAIN", "RIDE", "GENERAL")
+    mb, me = [out[22 + m] / B for m in range(3)], [out[25 + m] / B for m in range(3)]
+    print("fused quarters, batches with parked entries per pair-loop mode: " +
+          ", ".join(f"{n} {b:.0f} batches / {e / 1e6:.3f} M entries" for n, b, e in zip(names, mb, me)))

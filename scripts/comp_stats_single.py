@@ -12,7 +12,7 @@ cloud, views, label = bench.build_workload(sys.argv[1] if len(sys.argv) > 1 else
 act = cloud.activated()
 fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"], cloud.object_id, device="cuda:0",
                      spatial_order=False)
-out = (C.c_ulonglong * 24)()
+out = (C.c_ulonglong * 32)()
 for v in views[:4]:
     R.forward_views(fr.means3d, fr.opacities, [fr.view_spec(v)], shs=fr.shs, scales=fr.scales, rotations=fr.rotations, sh_degree=3)
     handle.pgr_debug_comp_stats(out, 1)
