@@ -133,16 +133,26 @@ __device__ __forceinline__ bool block_is_culled(const BlockBounds& b, const Came
     // (2) the whole box in front of it, with positive homogeneous w: pixel coordinates are linear-fractional in the
     // position, so their range over the box is the corners' range too
     if (!(zmin - eps_z > NEAR_Z) || !(wmin > 0.01f)) return false;
-    // radius bound: ceil(3 sqrt(lambda_max)), lambda_max <= trace(cov2D) + 0.32, trace(cov2D) <= sig2 * |W|_F^2 *
-    // (|J row 0|^2 + |J row 1|^2) + 0.6 with |J row 0|^2 <= (fx / tz)^2 (1 + (1.3 tanfovx)^2) (x/z is clamped there)
-    float wn = 0.0f;
+    // radius bound: ceil(3 sqrt(lambda1)) with lambda1 <= lambda_max(cov2D) + 0.32 (the 0.1 floor under the root), and
+    //   lambda_max(cov2D) <= |J|_2^2 |W|_2^2 lambda_max(Sigma) + 0.3,   lambda_max(Sigma) <= trace(Sigma) <= sig2,
+    //   |W|_2^2 <= largest absolute row sum of W^T W (Gershgorin; exactly 1 for a rigid view matrix -- the Frobenius norm
+    //             used here before says 3),
+    //   |J|_2^2 = lambda_max(J J^T) <= max(a, b) + |c| with a = fx^2 (1 + tx^2) / z^2, b = fy^2 (1 + ty^2) / z^2,
+    //             c = fx fy tx ty / z^2, |tx| <= 1.3 tanfovx, |ty| <= 1.3 tanfovy (x/z, y/z are clamped there), z >= zmin
+    //             (the sum of both rows' norms used before says a + b).
+    float m00 = 0.f, m01 = 0.f, m02 = 0.f, m11 = 0.f, m12 = 0.f, m22 = 0.f;       // W^T W, W[r][c] = vm[4 c + r]
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) wn = fmaf(vm[4 * c + r], vm[4 * c + r], wn);
+    for (int r = 0; r < 3; ++r) {
+        const float w0 = vm[r], w1 = vm[4 + r], w2 = vm[8 + r];
+        m00 = fmaf(w0, w0, m00); m01 = fmaf(w0, w1, m01); m02 = fmaf(w0, w2, m02);
+        m11 = fmaf(w1, w1, m11); m12 = fmaf(w1, w2, m12); m22 = fmaf(w2, w2, m22);
+    }
+    const float wn = fmaxf(fmaxf(fabsf(m00) + fabsf(m01) + fabsf(m02), fabsf(m01) + fabsf(m11) + fabsf(m12)),
+                           fabsf(m02) + fabsf(m12) + fabsf(m22));
     const float lx = 1.3f * cam.tanfovx, ly = 1.3f * cam.tanfovy;
     const float zr = 1.0f / (zmin - eps_z);
-    const float jn = (cam.focal_x * cam.focal_x * (1.0f + lx * lx) + cam.focal_y * cam.focal_y * (1.0f + ly * ly)) * zr * zr;
+    const float fx2 = cam.focal_x * cam.focal_x * (1.0f + lx * lx), fy2 = cam.focal_y * cam.focal_y * (1.0f + ly * ly);
+    const float jn = (fmaxf(fx2, fy2) + fabsf(cam.focal_x * cam.focal_y) * lx * ly) * zr * zr;
     const float tr2 = 1.02f * b.sig2 * wn * jn + 0.92f;
     const float rmax = 3.0f * sqrtf(tr2) * 1.001f + 2.0f;
     if (!(rmax < 1.0e9f)) return false;
