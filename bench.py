@@ -622,6 +622,17 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
             if "valu_busy" in k:
                 roofline["valu_issue"] = {"busy_frac": k["valu_busy"], "lds_busy_frac": k.get("lds_busy"), "kernel": kern,
                                           "definition": pmc.get("busy_definition")}
+                # the whole path as an instruction budget: vector wave-instructions per view of every kernel one frames
+                # batch launches (the other two compositor variants in the file belong to the profiled / raster-only passes)
+                per_view = {name: kk["valu_insts_per_launch"] / B for name, kk in pmc["kernels"].items()
+                            if "valu_insts_per_launch" in kk and (not name.startswith("composite_quarter_kernel") or name == kern)}
+                total = sum(per_view.values())
+                roofline["valu_issue"]["path"] = {
+                    "wave_insts_per_view": round(total), "wave_insts_per_s": round(total * value / world, 1),
+                    "peak_wave_insts_per_s": 1024 * 2.4e9 / 4, "frac": round(total * value / world / (1024 * 2.4e9 / 4), 4),
+                    "share": {name: round(v / total, 3) for name, v in sorted(per_view.items(), key=lambda kv: -kv[1]) if v / total >= 0.005},
+                    "definition": "SQ_INSTS_VALU per 32-view launch / 32, summed over the kernels of one frames batch; "
+                                  "x frames/s = vector wave-instructions issued per second, against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"}
     except (OSError, ValueError, KeyError):
         pass
 
