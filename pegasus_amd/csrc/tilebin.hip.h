@@ -532,7 +532,7 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
     uint32_t* s_misc = s_hist + NB;                                            // [0] min [1] max [2] sum k^2 [4..] wave totals
     const int t = threadIdx.x, lane = t & (WAVE - 1), wave = t / WAVE;
 #ifdef PGR_SORT_TIMING
-    constexpr int TIER_ = THREADS == 256 ? 0 : (THREADS == 512 ? 1 : 2);
+    constexpr int TIER_ = THREADS == 256 ? 0 : (THREADS == 512 ? 1 : (E == 8 ? 2 : 3));
     unsigned long long t_prev_ = __builtin_readcyclecounter(), ts_[9] = {};
     const unsigned long long t_start_ = t_prev_;
 #endif

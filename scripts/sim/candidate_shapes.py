@@ -81,3 +81,12 @@ xl = np.floor((x[gi] + lo - 1.0 - (T - 1)) / T); xr = np.floor((x[gi] + hi + 1.0
 wrow = np.where(ok_row, np.clip(np.minimum(xr, b_maxx[gi]) - np.maximum(xl, b_minx[gi]), 0, None), 0)
 print(f"  {'exact interval per tile row (+-1 px)':38s} {wrow.sum() / 1e6:7.2f} M candidates   listed / candidates = {listed / wrow.sum():.2f}"
       f"   ({len(gi) / 1e6:.2f} M (splat, row) pairs to compute)")
+# the same restricted to splats of at most 4 tile rows (and 15 columns), whose per-row (offset, width) pairs fit one 32-bit word
+small = (bh <= 4) & (bw <= 15)
+per_splat = np.bincount(gi, weights=wrow, minlength=len(x))
+mixed = np.where(small, per_splat, box)
+print(f"  {'row intervals for boxes of <= 4 rows only':38s} {mixed.sum() / 1e6:7.2f} M candidates   listed / candidates = {listed / mixed.sum():.2f}"
+      f"   ({small.mean():.3f} of the splats, {box[small].sum() / box.sum():.2f} of today's candidates)")
+for hh in (1, 2, 3, 4):
+    m = bh == hh
+    print(f"    boxes of {hh} rows: {m.mean():.3f} of the splats, today {box[m].sum() / 1e6:.2f} M -> {per_splat[m].sum() / 1e6:.2f} M")

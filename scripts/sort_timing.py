@@ -26,7 +26,7 @@ n = handle.pgr_debug_sort_timing(buf.ctypes.data_as(C.c_void_p), cap)
 rec = buf[:n].astype(np.float64)
 names = ["load+zero", "min/max", "hist atomics", "totals", "scan", "scatter keys", "rank", "output", "obj marker"]
 print(label, "records", n)
-for tier, tname in enumerate(["256 thr (<=2048)", "512 thr (<=4096)", "1024 thr (>4096)"]):
+for tier, tname in enumerate(["256 thr (<=2048)", "512 thr (<=4096)", "1024 thr x 8 (<=8192; segments of partitioned lists too)", "1024 thr x 16 (longer)"]):
     r = rec[rec[:, 9] == tier]
     if not len(r):
         continue
