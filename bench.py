@@ -97,6 +97,13 @@ def parse(argv=None):
                     help="TEST ONLY: exercise launch / sharding / gather / timing with a deterministic CPU frame source "
                          "(no rasterizer, gloo); the JSON line is flagged invalid")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed repeats of the K steps inside this one invocation (BASELINE.md section 4: >= 5 repeats, "
+                         "median + min): value / ms_per_step are the MEDIAN repeat, min / max / every repeat ride along")
+    ap.add_argument("--data-points", default="default", choices=["default", "all"],
+                    help="default = ['rgb','depth','seg_vis'] (+ the semantic image the masks come from); all adds 'seg_sil', "
+                         "the K per-object silhouette masks (/root/reference/pegasus.py:491, src/gs/render.py:36-65), as one "
+                         "layered batch pass per step inside the timed region")
     ap.add_argument("--profile-steps", type=int, default=0,
                     help="batches measured per-stage with HIP events (0 = the same batches as the timed steps)")
     return ap.parse_args(argv)
@@ -201,6 +208,10 @@ class RealEngine:
         self.n_slots = max(1, args.slots)
         self.frame_sets = [fr.alloc_frames(B, self.H, self.W, masks=self.with_masks) for _ in range(self.n_slots)]
         self.frames = self.frame_sets[0]
+        self.with_sil = args.data_points == "all" and self.with_masks
+        if self.with_sil:
+            for f in self.frame_sets:
+                f["sil"] = torch.empty((B, fr.K, self.H, self.W), dtype=torch.uint8, device=dev)
         # dynamic sequence: the whole trajectory exists before rendering starts (the reference simulates first,
         # /root/reference/pegasus.py:216 then :247); time step s -> rank s mod world, poses composed absolutely per step
         self.pose_seq = self.m2w_seq = None
@@ -241,6 +252,17 @@ class RealEngine:
             return fr.render_batch_async(self.batch_views(i), self.frame_sets[slot], masks=self.with_masks, slot=slot)
         h = fr.render_frames_async(self.batch_views(i), self.frame_sets[slot], masks=self.with_masks, slot=slot,
                                    poses=self.batch_poses(i))
+        if self.with_sil:                     # 'seg_sil': all K silhouettes of the batch, one layered pass on its own stream
+            _, hs = fr.render_silhouettes(self.batch_views(i), out=self.frame_sets[slot]["sil"], poses=self.batch_poses(i),
+                                          slot=slot, wait=False)
+            frames_h = h
+
+            class _Both:
+                def wait(_self):
+                    f = frames_h.wait()
+                    hs.wait()
+                    return f
+            h = _Both()
         self.batch_records(i)                 # BOP scene_gt / scene_camera entries of the batch (host, overlapped)
         return h
 
@@ -250,16 +272,23 @@ class RealEngine:
             return fr.render_batch(self.batch_views(i), self.frames, masks=self.with_masks, **kw)
         kw.pop("sem_stage_ms", None)
         poses = self.batch_poses(i)
+        if self.with_sil and kw.get("stage_ms") is None:
+            fr.render_silhouettes(self.batch_views(i), out=self.frames["sil"], poses=poses)
         if poses is not None and kw.get("stage_ms") is None:      # (the profiling entry point has no posed variant:
             kw.pop("stage_ms", None)                              #  stage times are taken on the unposed scene)
             return fr.render_frames(self.batch_views(i), self.frames, masks=self.with_masks, poses=poses, **kw)
         return fr.render_frames(self.batch_views(i), self.frames, masks=self.with_masks, **kw)
 
-    def pack(self, fr_set):
-        """What leaves the GPU for a finished batch: NEW tensors (the frame set is re-rendered while they travel)."""
+    def record_bytes(self):
         from pegasus_amd import masks as M
-        return M.pack_frames(color=fr_set["color"][:self.B], depth=fr_set["depth"][:self.B],
-                             masks=fr_set["masks"][:self.B] if "masks" in fr_set else None)
+        return M.record_layout(self.H, self.W, self.fr.K if self.with_masks else 0)["bytes"]
+
+    def pack(self, fr_set, out):
+        """What leaves the GPU for a finished batch: ONE uint8 record per frame, written straight into `out` (a
+        preallocated [B, record_bytes] device tensor -- the frame set is re-rendered while the records travel)."""
+        from pegasus_amd import masks as M
+        return M.pack_records(color=fr_set["color"][:self.B], depth=fr_set["depth"][:self.B],
+                              masks=fr_set["masks"][:self.B] if "masks" in fr_set else None, out=out)
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -312,8 +341,25 @@ class StubEngine:
     def step_blocking(self, i, **kw):
         return self.frame_ids(i)
 
-    def pack(self, ids):
-        return self.frames_of(ids, self.torch)
+    def record_bytes(self):
+        from pegasus_amd import masks as M
+        return M.record_layout(self.H, self.W, 8)["bytes"]
+
+    @classmethod
+    def records_of(cls, ids, torch, H=4, W=5):
+        """The stub's frames as records in the product's layout (host-only layout query of the library)."""
+        from pegasus_amd import masks as M
+        lay = M.record_layout(H, W, 8)
+        f = cls.frames_of(ids, torch)
+        rec = torch.zeros((len(ids), lay["bytes"]), dtype=torch.uint8)
+        rec[:, :3 * H * W] = f["rgb"].reshape(len(ids), -1)
+        rec[:, lay["off_depth"]:lay["off_depth"] + 2 * H * W] = f["depth_mm"].reshape(len(ids), -1).view(torch.uint8)
+        rec[:, lay["off_masks"]:lay["off_masks"] + H * W] = f["mask_bits"].reshape(len(ids), -1)
+        return rec
+
+    def pack(self, ids, out):
+        out.copy_(self.records_of(ids, self.torch, self.H, self.W))
+        return out
 
     def sync(self):
         pass
@@ -391,32 +437,43 @@ def run_worker(args):
                           "drop_in": d}))
         return 0
     B, n_slots = eng.B, eng.n_slots
-    gather_state = {"inflight": None, "bytes": 0, "batches": 0}
-
-    def to_wire(local):
-        return {k: t.cpu() for k, t in local.items()} if (backend == "gloo" and not eng.stub) else local
-
-    def finish_inflight():
-        if gather_state["inflight"] is not None:
-            finish, works = gather_state["inflight"]
-            for w_ in works:
-                w_.wait()
-            out = finish()
-            gather_state["inflight"] = None
-            return out
-        return None
+    # ---- the one exchange of the path (N > 1): per batch ONE gather of ONE uint8 record per frame, between buffers that
+    # exist before the first batch (pegasus_amd/view_shard.py FrameGather).  Rank r's local frame i is global frame
+    # i * world + r, so the root's rank-major receive buffer is the global order under a transposed view: nothing is
+    # reordered, copied or allocated per batch.
+    fg = stage = None
+    gstat = {"host_s": 0.0, "batches": 0}
+    if gather_on:
+        from pegasus_amd import view_shard as VS
+        host_wire = backend == "gloo"              # gloo moves host memory: rehearsals and CPU tests only
+        fg = VS.FrameGather(cap=B, record_bytes=eng.record_bytes(), device="cpu" if host_wire else dev, dst=0, depth=2,
+                            pin_memory=host_wire and not eng.stub)
+        if host_wire and not eng.stub:             # device-side staging of the rehearsal: pack on the GPU, copy to pinned
+            stage = [torch.empty((B, eng.record_bytes()), dtype=torch.uint8, device=dev) for _ in range(2)]
 
     def gather_finished(token, gather):
-        """Pack a finished batch on the GPU and start its gather to rank 0 (grouped send/recv on RCCL: the peers stream
-        over their own xGMI links); the previous batch's gather is completed first, so one is in flight."""
+        """Pack a finished batch into this slot's send buffer and start its gather to rank 0 (grouped send/recv on RCCL:
+        the peers stream over their own xGMI links).  Two slots: one gather is in flight beside the batch being packed."""
         if not gather:
             return
-        from pegasus_amd import view_shard as VS
-        finish_inflight()
-        local = to_wire(eng.pack(token))
-        gather_state["bytes"] = sum(t.numel() * t.element_size() for t in local.values())
-        gather_state["batches"] += 1
-        gather_state["inflight"] = VS.gather_frames(local, B * world, dst=0, async_op=True)
+        t0 = time.perf_counter()
+        slot = gstat["batches"] & 1
+        fg.finish(slot)                            # the gather that last used this slot's buffers (two batches ago)
+        if stage is not None:
+            eng.pack(token, stage[slot])
+            fg.send_buffer(slot).copy_(stage[slot], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        else:
+            eng.pack(token, fg.send_buffer(slot))
+        fg.start(slot)
+        gstat["batches"] += 1
+        gstat["host_s"] += time.perf_counter() - t0
+
+    def finish_inflight():
+        if fg is not None:
+            t0 = time.perf_counter()
+            fg.finish_all()
+            gstat["host_s"] += time.perf_counter() - t0
 
     def run_steps(first, count, gather):
         """`count` steps as an `n_slots`-deep software pipeline: batch i is enqueued (no host sync) while batch i-1
@@ -441,7 +498,8 @@ def run_worker(args):
         finish_inflight()
 
     def timed(first, count, gather):
-        """EXACTLY `count` steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+        """EXACTLY `count` steps bracketed by barrier + synchronize on both sides.  Returns (MAX over ranks, every
+        rank's own elapsed seconds between the two barriers' inner synchronisations)."""
         eng.sync()
         if use_dist:
             dist.barrier()
@@ -449,42 +507,51 @@ def run_worker(args):
         t0 = time.perf_counter()
         run_steps(first, count, gather)
         eng.sync()
+        own = time.perf_counter() - t0             # this rank's own work, before it waits for the others
         if use_dist:
             dist.barrier()
         eng.sync()
         el = time.perf_counter() - t0
+        per_rank = [own]
         if use_dist:
             te = torch.tensor([el], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             el = float(te.item())
-        return el
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, own)
+        return el, per_rank
 
     eng.settle(run_steps)
     run_steps(0, args.warmup, gather_on)
-    elapsed = timed(args.warmup, args.steps, gather_on)
-    elapsed_render_only = timed(args.warmup, args.steps, False) if gather_on else None
+    repeats = max(1, args.repeats)
+    gstat.update(host_s=0.0, batches=0)
+    runs = [timed(args.warmup, args.steps, gather_on) for _ in range(repeats)]
+    gather_host_s = gstat["host_s"] / repeats
+    order = sorted(range(repeats), key=lambda r: runs[r][0])
+    med = order[(repeats - 1) // 2]                # the median repeat (lower middle for an even count)
+    elapsed, per_rank = runs[med]
+    elapsed_render_only = timed(args.warmup, args.steps, False)[0] if gather_on else None
 
     # ---- gather check (N > 1, outside the timed region): one more batch through the same pack + gather; rank 0 compares
     # the byte sums of what it RECEIVED from every rank with the sums those ranks computed on what they SENT
     gather_check = None
     if use_dist and gather_on:
-        from pegasus_amd import view_shard as VS
         i_chk = args.warmup + args.steps
         token = eng.step_blocking(i_chk)
         eng.sync()
-        local = to_wire(eng.pack(token))
+        gstat["batches"] = 0
+        gather_finished(token, True)
+        recv = fg.finish(0)
+        eng.sync()
         sums = [None] * world
-        dist.all_gather_object(sums, _checksums(local))
-        got = VS.gather_frames(local, B * world, dst=0)
+        dist.all_gather_object(sums, int(fg.send_buffer(0).to(torch.int64).sum().item()))
         if rank == 0:
-            ok = True
-            for r in range(world):
-                idx = VS.shard_indices(B * world, r, world)
-                ok = ok and _checksums({k: got[k][idx] for k in got}) == sums[r]
-            if eng.stub:                              # the stub's frames are a function of their global id: check content too
+            ok = all(int(recv[r].to(torch.int64).sum().item()) == sums[r] for r in range(world))
+            if eng.stub:                              # the stub's frames are a function of their global id: check content too,
+                glob = fg.global_view(0)              # through the (rank, i) -> global id rule g = i * world + r
                 ids = [((i_chk * B + k) * world + r) for k in range(B) for r in range(world)]
-                want = StubEngine.frames_of(ids, torch)
-                ok = ok and all(torch.equal(got[k], want[k]) for k in want)
+                want = StubEngine.records_of(ids, torch, eng.H, eng.W).view(B, world, -1)
+                ok = ok and torch.equal(glob, want)
             gather_check = "ok" if ok else "MISMATCH"
         flag = torch.tensor([0 if (rank != 0 or gather_check == "ok") else 1], device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(flag)
@@ -498,10 +565,17 @@ def run_worker(args):
 
     total_views = args.steps * B * world
     value = total_views / elapsed
+    all_el = [r[0] for r in runs]
     line = {
         "metric": None, "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        # >= 5 repeats, median + min.  value / ms_per_step are the MEDIAN repeat of `steps` steps
+        "repeats": repeats, "value_min": round(total_views / max(all_el), 3), "value_max": round(total_views / min(all_el), 3),
+        "ms_per_step_all": [round(e / args.steps * 1e3, 4) for e in all_el],
+        # every rank's own time for the median repeat (before the closing barrier): a straggler shows here
+        "per_rank_s": {"min": round(min(per_rank), 6), "max": round(max(per_rank), 6), "rank0": round(per_rank[0], 6),
+                       "all": [round(x, 6) for x in per_rank]},
     }
     launcher = ("self: python bench.py --gpus N started torch.distributed.run as a child process"
                 if os.environ.get("PGR_BENCH_LAUNCHER") == "self" else
@@ -511,12 +585,18 @@ def run_worker(args):
     gather_info = {"mode": "off (frames stay on the rank that rendered them)"}
     if gather_on:
         gather_info = {
-            "mode": "every batch's packed frames gathered to rank 0 inside the timed region, one gather in flight",
-            "payload": "uint8 RGB [H,W,3] + uint16 depth mm [H,W] + K masks as bit planes (ceil(K/8) bytes per pixel)",
-            "bytes_per_rank_and_batch": gather_state["bytes"],
+            "mode": "ONE collective per batch inside the timed region: every rank's [B, record] uint8 send buffer gathered into "
+                    "rank 0's preallocated [world, B, record] buffer (rank-major = global order under a transposed view: frame "
+                    "g = i * world + r); two buffer slots, one gather in flight; nothing allocated or reordered per batch",
+            "payload": "one record per frame: uint8 RGB [H,W,3] | uint16 depth mm [H,W] | K masks as bit planes (ceil(K/8) bytes per pixel)",
+            "bytes_per_rank_and_batch": fg.bytes_per_rank_and_batch,
             "views_per_s_with_gather": round(value, 3),
             "views_per_s_render_only": round(total_views / elapsed_render_only, 3),
-            "inbound_to_root_gb_per_s": round(gather_state["bytes"] * (world - 1) * args.steps / elapsed / 1e9, 2),
+            "inbound_to_root_gb_per_s": round(fg.bytes_per_rank_and_batch * (world - 1) * args.steps / elapsed / 1e9, 2),
+            # rank 0's host time inside pack + gather calls per step (enqueue of the pack kernel, completion of the gather
+            # two batches back, start of this one), mean over the repeats
+            "rank0_gather_host_ms_per_step": round(gather_host_s / args.steps * 1e3, 4),
+            "rank0_gather_host_frac_of_step": round(gather_host_s / elapsed, 4),
             "check": gather_check,
         }
     if eng.stub:

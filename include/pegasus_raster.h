@@ -14,6 +14,11 @@
  *   pgr_color_masks        <- the colour-distance masks /root/reference/src/gs/render.py:60-63,89-93
  *   pgr_quantize_frame     <- (img*255).astype(uint8), (depth*1000).astype(uint16):
  *                             /root/reference/pegasus.py:347,355
+ *   pgr_pack_records       <- the same casts for a whole batch + the K masks as bit planes, ONE record per frame: what the
+ *                             writer threads of /root/reference/pegasus.py:346-358 consume / what the gather to the root
+ *                             rank carries
+ *   pgr_forward_layers_async <- render_silhouette_mask, /root/reference/src/gs/render.py:36-65 (every object rendered
+ *                             ALONE and thresholded), for all objects and a batch of cameras in one pipeline pass
  *
  * Conventions
  *   - Every pointer in PgrScene / PgrCamera / PgrOutputs is a DEVICE address of a contiguous
@@ -37,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PGR_ABI_VERSION 1
+#define PGR_ABI_VERSION 2
 #define PGR_TILE_SIZE 16
 
 typedef enum PgrStatus {
@@ -66,10 +71,22 @@ typedef struct PgrScene {
                                     (depth, index): where two depths are EXACTLY equal the smaller tie_index comes
                                     first.  A scene stored in another order than the caller's (FrameRenderer's Morton
                                     layout) passes the caller's indices here and renders the caller's image bit for bit. */
+    const uint32_t *tie_inv;     /* [n] inverse permutation of tie_index (tie_inv[tie_index[i]] = i), or NULL = the library
+                                    rebuilds it in its workspace on every call.  A per-SCENE constant: pgr_scene_prepare
+                                    computes it once into caller-owned memory. */
 } PgrScene;
 
 /* The fields of GaussianRasterizationSettings that describe one view.  Scalars are host values;
  * the four small tensors stay on the device exactly as PEGASUS's Camera holds them. */
+/* The depth image's blend rule.  The reference's rasterizer is the absent fork `depth-diff-gaussian-rasterization`
+ * (/root/reference/setup.sh:19); the widely used fork of that name writes the un-normalised expected depth, which the
+ * in-tree evidence is consistent with (/root/reference/pegasus.py:355 scales it to millimetres as is) -- but the rule
+ * itself is unverified (SURVEY.md section 8a "Depth variant"), so it is a switch:
+ *   PGR_DEPTH_EXPECTED    depth = sum_i T_i alpha_i z_i                      (default; no background term)
+ *   PGR_DEPTH_NORMALIZED  depth = sum_i T_i alpha_i z_i / (1 - T_final)      (sum_i T_i alpha_i = 1 - T_final; 0 where
+ *                                                                             nothing was blended) */
+typedef enum PgrDepthMode { PGR_DEPTH_EXPECTED = 0, PGR_DEPTH_NORMALIZED = 1 } PgrDepthMode;
+
 typedef struct PgrCamera {
     int32_t image_width, image_height;
     float tanfovx, tanfovy;
@@ -77,6 +94,7 @@ typedef struct PgrCamera {
     const float *projmatrix;     /* device [16], full_proj_transform  (transposed storage) */
     const float *campos;         /* device [3] */
     const float *bg;             /* device [3] */
+    int32_t depth_mode;          /* PgrDepthMode; applies to depth and sem_depth of this view */
 } PgrCamera;
 
 typedef struct PgrOutputs {
@@ -88,6 +106,11 @@ typedef struct PgrOutputs {
     float *sem_color;            /* [3,H,W]  the objects-only semantic render: REQUIRED on every view of a call that
                                     passes a PgrSemantic (PGR_ERR_INVALID_ARGUMENT otherwise), ignored without one */
     float *sem_depth;            /* [1,H,W]  optional, only with sem_color */
+    uint8_t *sem_masks;          /* [K,H,W]  optional: the K colour-distance masks of the semantic image
+                                    (pgr_color_masks of sem_color against PgrSemantic::mask_colors, bit for bit), written by
+                                    the compositor's epilogue from the pixel it holds in registers -- needs
+                                    PgrSemantic::mask_colors.  In a LAYERED call (pgr_forward_layers_async) the one output:
+                                    [n_layers,H,W], plane k = layer k's image against mask_colors[k]. */
 } PgrOutputs;
 
 /* Fused semantic pass: PEGASUS renders the objects alone, painted in flat semantic colours, to derive masks
@@ -100,6 +123,11 @@ typedef struct PgrSemantic {
                                     max(C0 * RGB2SH(c_k) + 0.5, 0), evaluated in fp32 in that order */
     int32_t n_env;               /* Gaussians [0, n_env) are the environment */
     int32_t k_objects;
+    const uint8_t *object_id_u8; /* device [n - n_env]: object_id[n_env + j] as a byte, or NULL = the library packs it in
+                                    its workspace on every call (k_objects <= 255).  Per-scene constant: pgr_scene_prepare */
+    const float *mask_colors;    /* device [k_objects,3]: the colours the masks are thresholded against (the c_k of
+                                    /root/reference/src/gs/render.py:60-63,89-93), or NULL = no sem_masks output */
+    float mask_threshold;        /* L2 distance, the reference's 0.1 */
 } PgrSemantic;                   /* checked before anything is enqueued: object_id, colors non-NULL, n_env >= 0,
                                     k_objects > 0, outs[v].sem_color non-NULL for every view */
 
@@ -182,6 +210,37 @@ int32_t pgr_forward_posed_async(const PgrScene *scene, const PgrSemantic *semant
                                 size_t workspace_bytes, int64_t max_instances_per_view, void *host_scratch,
                                 size_t host_scratch_size, void *stream);
 int32_t pgr_batch_status(const void *host_scratch, int32_t n_views, int64_t *num_instances);
+
+/* Per-SCENE constants the batch calls would otherwise rebuild on every call (round 3: invert_tie_index_kernel and
+ * pack_object_ids_kernel, 24 us + 76 MB of traffic per batch of the 2 M-Gaussian scene): the inverse of
+ * PgrScene::tie_index and the object ids of the object Gaussians as bytes.  Enqueues the work on `stream`, writes into
+ * caller-owned `cache` (device, pgr_scene_cache_bytes(n) bytes) and returns the two device pointers to put into
+ * PgrScene::tie_inv / PgrSemantic::object_id_u8 (NULL where the input is absent: scene->tie_index == NULL, semantic ==
+ * NULL, or k_objects > 255).  Valid until the scene's tie_index / object ids change. */
+size_t pgr_scene_cache_bytes(int32_t n);
+int32_t pgr_scene_prepare(const PgrScene *scene, const PgrSemantic *semantic, void *cache, size_t cache_bytes,
+                          const uint32_t **tie_inv, const uint8_t **object_id_u8, void *stream);
+
+/* Layered render = silhouette masks (/root/reference/src/gs/render.py:36-65: every object rendered ALONE over an empty
+ * environment and thresholded against its semantic colour -- the reference does one deepcopy + merge + render per object
+ * and camera).  One pipeline pass renders n_layers images per view: a Gaussian with layer_id k > 0 is composited into
+ * image k only (per-(tile, layer) lists: the binning treats the n_layers images as one image of n_layers x grid_y tile
+ * rows; projection, lists and blending of a layer are those of rendering its Gaussians alone), and the compositor's
+ * epilogue writes outs[v].sem_masks[k-1] = || pixel - mask_colors[k-1] ||_2 <= mask_threshold.  No colour image is
+ * written (outs[v].color / depth may be NULL).  layer_id must be non-decreasing along the scene (PEGASUS merges object
+ * after object); Gaussians with layer_id 0 are dropped.  `posed` as in pgr_forward_posed_async (may be NULL). */
+typedef struct PgrLayers {
+    const int32_t *layer_id;     /* device [n] */
+    int32_t n_layers;
+    const float *mask_colors;    /* device [n_layers,3] */
+    float mask_threshold;
+} PgrLayers;
+size_t pgr_layers_workspace_bytes(int32_t n, int32_t width, int32_t height, int64_t max_instances_per_view,
+                                  int32_t n_views, int32_t n_layers);
+int32_t pgr_forward_layers_async(const PgrScene *scene, const PgrLayers *layers, const PgrPosedObjects *posed,
+                                 int32_t n_views, const PgrCamera *cameras, const PgrOutputs *outs, void *workspace,
+                                 size_t workspace_bytes, int64_t max_instances_per_view, void *host_scratch,
+                                 size_t host_scratch_size, void *stream);
 
 /* Profiling twin of pgr_forward_batch (bench / rocprof only): records HIP events on `stream` at the
  * stage boundaries (each stage runs for all views before the next starts), synchronises, and writes the
@@ -289,6 +348,21 @@ int32_t pgr_quantize_frame(const float *img_chw, const float *depth_hw, int32_t 
 int32_t pgr_pack_frames(const float *color_b3hw, const float *depth_bhw, const uint8_t *masks_bkhw, int32_t n_images,
                         int32_t k, int32_t width, int32_t height, uint8_t *rgb_bhwc, uint16_t *depth_mm_bhw,
                         uint8_t *mask_bits_bhwj, void *stream);
+
+/* One RECORD per frame -- everything that leaves the GPU for a finished frame, contiguous, so that a batch is one buffer
+ * for the disk writers and ONE collective for the gather to the root rank (3.84 MB per 800x800
+ * frame at K <= 8):
+ *   [0, 3P)                       uint8 rgb HWC   = uint8(color * 255)      (wraps, no clamp; pegasus.py:347)
+ *   [off_depth, off_depth + 2P)   uint16 depth mm = uint16(depth * 1000)    (pegasus.py:355), little endian
+ *   [off_masks, off_masks + J P)  mask bit planes, J = ceil(k / 8) bytes per pixel: bit (m % 8) of byte m / 8 = mask m
+ * with P = width x height and the three offsets / the record size rounded up to 16 bytes (pgr_frame_record_layout).
+ * records: device uint8, record b at records + b * record_stride (record_stride >= layout.bytes, a multiple of 16). */
+typedef struct PgrRecordLayout {
+    int64_t off_rgb, off_depth, off_masks, bytes;
+} PgrRecordLayout;
+int32_t pgr_frame_record_layout(int32_t width, int32_t height, int32_t k, PgrRecordLayout *layout);
+int32_t pgr_pack_records(const float *color_b3hw, const float *depth_bhw, const uint8_t *masks_bkhw, int32_t n_images,
+                         int32_t k, int32_t width, int32_t height, uint8_t *records, int64_t record_stride, void *stream);
 
 #ifdef __cplusplus
 }

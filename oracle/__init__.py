@@ -42,7 +42,7 @@ class _In(C.Structure):
         ("viewmatrix", C.c_float * 16), ("projmatrix", C.c_float * 16),
         ("campos", C.c_float * 3), ("bg", C.c_float * 3), ("cull_mode", C.c_int32),
         ("object_id", C.c_void_p), ("poses", C.c_void_p), ("k_objects", C.c_int32),
-        ("tie_index", C.c_void_p),
+        ("tie_index", C.c_void_p), ("depth_mode", C.c_int32),
     ]
 
 
@@ -105,7 +105,8 @@ def _ptr(a):
 
 def _make_in(means3d, opacities, *, scales=None, rotations=None, cov3d_precomp=None, shs=None,
              colors_precomp=None, sh_degree=0, scale_modifier=1.0, width, height, tanfovx, tanfovy,
-             viewmatrix, projmatrix, campos, bg, cull_mode=0, object_id=None, poses=None, tie_index=None):
+             viewmatrix, projmatrix, campos, bg, cull_mode=0, object_id=None, poses=None, tie_index=None,
+             depth_mode=0):
     means3d = _f32(means3d).reshape(-1, 3)
     n = means3d.shape[0]
     keep = dict(means3d=means3d, opacities=_f32(opacities).reshape(-1) if n or opacities is not None else None,
@@ -126,6 +127,7 @@ def _make_in(means3d, opacities, *, scales=None, rotations=None, cov3d_precomp=N
     i.campos = (C.c_float * 3)(*_f32(campos).reshape(3))
     i.bg = (C.c_float * 3)(*_f32(bg).reshape(3))
     i.cull_mode = int(cull_mode)
+    i.depth_mode = int(depth_mode)
     if object_id is not None:      # posed objects: poses [K, 20] (pegasus_amd.compose.pose_table)
         keep["object_id"] = np.ascontiguousarray(np.asarray(object_id, dtype=np.int32))
         keep["poses"] = _f32(poses).reshape(-1, 20)

@@ -6,6 +6,9 @@
  *
  * Build: gcc -O2 -std=c11 -ffp-contract=off -fno-fast-math -mfma -fopenmp -shared -fPIC
  */
+#if !defined(_OPENMP) && !defined(_POSIX_C_SOURCE)
+#define _POSIX_C_SOURCE 199309L      /* clock_gettime for the timing stamps of a build without -fopenmp */
+#endif
 #include "pgr_oracle.h"
 
 #include <math.h>
@@ -14,6 +17,10 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+#define pgr_wtime() omp_get_wtime()
+#else
+#include <time.h>
+static double pgr_wtime(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 #endif
 
 const char *pgr_oracle_version(void) { return "pgr-oracle 1.1 (spec rev 2: tight lists)"; }
@@ -329,7 +336,8 @@ static void radix_sort_pairs(uint64_t *keys, uint32_t *vals, int64_t n, int nbit
     uint64_t *ka = keys, *kb = k2;
     uint32_t *va = vals, *vb = v2;
     int chunks = num_threads < 1 ? 1 : (num_threads > 32 ? 32 : num_threads);    /* a scatter pass is memory-bound long before 32 */
-    if (getenv("PGR_ORACLE_SORT_THREADS")) chunks = atoi(getenv("PGR_ORACLE_SORT_THREADS")) > 0 ? atoi(getenv("PGR_ORACLE_SORT_THREADS")) : 1;
+    const char *sort_threads = getenv("PGR_ORACLE_SORT_THREADS");
+    if (sort_threads) { const int st = atoi(sort_threads); chunks = st > 0 ? st : 1; }
     if ((int64_t)chunks > n / 4096 + 1) chunks = (int)(n / 4096 + 1);
     int64_t *hist = (int64_t *)malloc((size_t)chunks * 256 * sizeof(int64_t));
     const int64_t per = (n + chunks - 1) / chunks;
@@ -438,7 +446,15 @@ static void composite_tile(const PgrOracleIn *in, PgrOracleOut *out, const float
                 out->out_color[1 * P + pix] = fmaf(T, in->bg[1], Cg);
                 out->out_color[2 * P + pix] = fmaf(T, in->bg[2], Cb);
             }
-            if (out->out_depth) out->out_depth[pix] = D;
+            if (out->out_depth) {
+                /* depth rule switch: un-normalised expected depth, or divided by the blended weights' total 1 - T */
+                float d = D;
+                if (in->depth_mode == 1) {
+                    const float wsum = 1.0f - T;
+                    d = wsum > 0.0f ? D / wsum : 0.0f;
+                }
+                out->out_depth[pix] = d;
+            }
             if (out->final_T) out->final_T[pix] = T;
             if (out->n_contrib) out->n_contrib[pix] = last;
             if (out->ambig) out->ambig[pix] = amb;
@@ -477,9 +493,9 @@ int pgr_oracle_forward(const PgrOracleIn *in, PgrOracleOut *out, int num_threads
 
     const int timing = getenv("PGR_ORACLE_TIMING") != NULL;
     double t_[8]; int ti_ = 0;
-    t_[ti_++] = omp_get_wtime();
+    t_[ti_++] = pgr_wtime();
     int rc = pgr_oracle_preprocess(in, &o, num_threads);
-    t_[ti_++] = omp_get_wtime();
+    t_[ti_++] = pgr_wtime();
 
     /* a6: inclusive scan of the per-Gaussian instance counts (cull_mode 1: only the tiles that may contribute) */
     int64_t total = 0;
@@ -520,7 +536,7 @@ int pgr_oracle_forward(const PgrOracleIn *in, PgrOracleOut *out, int num_threads
         for (int32_t i = 0; i < n; ++i) { total += kept[i]; offs[i] = total; }
     }
     out->num_instances = total;
-    t_[ti_++] = omp_get_wtime();
+    t_[ti_++] = pgr_wtime();
 
     uint64_t *keys = NULL;
     uint32_t *vals = NULL;
@@ -551,13 +567,13 @@ int pgr_oracle_forward(const PgrOracleIn *in, PgrOracleOut *out, int num_threads
                     ++off;
                 }
         }
-        t_[ti_++] = omp_get_wtime();
+        t_[ti_++] = pgr_wtime();
         /* a8: stable sort over bits [0, 32 + ceil(log2 tiles)) */
         int tbits = 0;
         while ((1 << tbits) < tiles) ++tbits;
         radix_sort_pairs(keys, vals, total, 32 + tbits, num_threads);
 
-        t_[ti_++] = omp_get_wtime();
+        t_[ti_++] = pgr_wtime();
         /* a9: tile ranges */
         ranges = out->ranges ? out->ranges : (uint32_t *)calloc((size_t)tiles * 2, 4);
 #pragma omp parallel for schedule(static) num_threads(num_threads)
@@ -570,7 +586,7 @@ int pgr_oracle_forward(const PgrOracleIn *in, PgrOracleOut *out, int num_threads
     free(offs);
     free(kept);
 
-    t_[ti_++] = omp_get_wtime();
+    t_[ti_++] = pgr_wtime();
     /* a10: compositor, every tile (empty tiles produce bg colour, zero depth, T = 1) */
     if (rc == 0) {
         uint32_t maxlen = 0;
@@ -590,7 +606,7 @@ int pgr_oracle_forward(const PgrOracleIn *in, PgrOracleOut *out, int num_threads
         }
     }
 
-    t_[ti_++] = omp_get_wtime();
+    t_[ti_++] = pgr_wtime();
     if (timing) {
         fprintf(stderr, "pgr_oracle_forward (%d threads):", num_threads);
         for (int k = 1; k < ti_; ++k) fprintf(stderr, " %.3f", t_[k] - t_[k - 1]);

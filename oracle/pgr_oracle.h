@@ -74,6 +74,9 @@ typedef struct PgrOracleIn {
     int32_t k_objects;
     const int32_t *tie_index;       /* [n] permutation or NULL: exact depth ties are broken by tie_index instead of the
                                        position (include/pegasus_raster.h PgrScene::tie_index) */
+    int32_t depth_mode;             /* 0 = out_depth = sum T alpha z (the default: SURVEY.md section 8a "Depth variant");
+                                       1 = that sum / (1 - T_final), 0 where nothing was blended
+                                       (include/pegasus_raster.h PgrDepthMode) */
 } PgrOracleIn;
 #define PGR_POSE_STRIDE 20
 

@@ -8,7 +8,11 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libpegasus_raster.so"
+import os
+
+# PGR_LIB: an alternative build of the library (stats / timing / variant builds of the measurement scripts load theirs
+# from build_variants/ instead of overwriting the product .so)
+LIB_PATH = Path(os.environ.get("PGR_LIB") or Path(__file__).resolve().parent / "csrc" / "libpegasus_raster.so")
 
 PGR_OK = 0
 PGR_ERR_INVALID_ARGUMENT = -1
@@ -25,7 +29,7 @@ class PgrScene(C.Structure):
         ("means3d", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
         ("cov3d_precomp", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
         ("sh_degree", C.c_int32), ("sh_stride", C.c_int32), ("scale_modifier", C.c_float),
-        ("tie_index", C.c_void_p),
+        ("tie_index", C.c_void_p), ("tie_inv", C.c_void_p),
     ]
 
 
@@ -33,16 +37,32 @@ class PgrCamera(C.Structure):
     _fields_ = [
         ("image_width", C.c_int32), ("image_height", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
         ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("bg", C.c_void_p),
+        ("depth_mode", C.c_int32),
     ]
 
 
 class PgrOutputs(C.Structure):
     _fields_ = [("color", C.c_void_p), ("depth", C.c_void_p), ("radii", C.c_void_p), ("final_T", C.c_void_p),
-                ("n_contrib", C.c_void_p), ("sem_color", C.c_void_p), ("sem_depth", C.c_void_p)]
+                ("n_contrib", C.c_void_p), ("sem_color", C.c_void_p), ("sem_depth", C.c_void_p),
+                ("sem_masks", C.c_void_p)]
 
 
 class PgrSemantic(C.Structure):
-    _fields_ = [("object_id", C.c_void_p), ("colors", C.c_void_p), ("n_env", C.c_int32), ("k_objects", C.c_int32)]
+    _fields_ = [("object_id", C.c_void_p), ("colors", C.c_void_p), ("n_env", C.c_int32), ("k_objects", C.c_int32),
+                ("object_id_u8", C.c_void_p), ("mask_colors", C.c_void_p), ("mask_threshold", C.c_float)]
+
+
+class PgrLayers(C.Structure):
+    _fields_ = [("layer_id", C.c_void_p), ("n_layers", C.c_int32), ("mask_colors", C.c_void_p),
+                ("mask_threshold", C.c_float)]
+
+
+class PgrRecordLayout(C.Structure):
+    _fields_ = [("off_rgb", C.c_int64), ("off_depth", C.c_int64), ("off_masks", C.c_int64), ("bytes", C.c_int64)]
+
+
+PGR_DEPTH_EXPECTED = 0
+PGR_DEPTH_NORMALIZED = 1
 
 
 class PgrPosedObjects(C.Structure):
@@ -89,6 +109,16 @@ SYMBOLS = {
                                             C.c_int32, C.POINTER(PgrCamera), C.POINTER(PgrOutputs), C.c_void_p,
                                             C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pgr_batch_status": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
+    "pgr_scene_cache_bytes": (C.c_size_t, [C.c_int32]),
+    "pgr_scene_prepare": (C.c_int32, [C.POINTER(PgrScene), C.POINTER(PgrSemantic), C.c_void_p, C.c_size_t,
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),
+    "pgr_layers_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32]),
+    "pgr_forward_layers_async": (C.c_int32, [C.POINTER(PgrScene), C.POINTER(PgrLayers), C.POINTER(PgrPosedObjects),
+                                             C.c_int32, C.POINTER(PgrCamera), C.POINTER(PgrOutputs), C.c_void_p,
+                                             C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pgr_frame_record_layout": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(PgrRecordLayout)]),
+    "pgr_pack_records": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_void_p, C.c_int64, C.c_void_p]),
     "pgr_forward_batch_profiled": (C.c_int32, [C.POINTER(PgrScene), C.POINTER(PgrSemantic), C.c_int32,
                                                C.POINTER(PgrCamera),
                                                C.POINTER(PgrOutputs), C.c_void_p, C.c_size_t, C.c_int64,
@@ -138,7 +168,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.pgr_abi_version() != 1:
+        if handle.pgr_abi_version() != 2:
             raise RasterizerLibraryError("libpegasus_raster.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -34,8 +34,9 @@ struct alignas(16) ViewEntry {
     float* sem_color;            // fused semantic pass: [3,H,W] objects-only image in semantic colours (or NULL)
     float* sem_depth;            // [H,W] objects-only depth (or NULL)
     const uint32_t* obj_last;    // [tiles] 1 + position of the last object entry of each sorted list (tile sort)
+    uint8_t* sem_masks;          // [K,H,W] colour-distance masks of the semantic image / (layered call) of the layers, or NULL
 };
-static_assert(sizeof(ViewEntry) == 96, "ViewEntry layout");
+static_assert(sizeof(ViewEntry) == 112, "ViewEntry layout");
 
 // Fused semantic pass (same for every view of a batch): which Gaussians are objects and what colour they carry.
 struct SemanticDev {
@@ -48,7 +49,28 @@ struct SemanticDev {
     const float* colors;         // [K,3] the rgb value object k's Gaussians carry: max(C0*RGB2SH(c_k) + 0.5, 0)
     int32_t n_env;               // Gaussians with index < n_env are environment
     int32_t k;
+    const float* mask_colors;    // [K,3] colours the masks are thresholded against (NULL: no masks)
+    float mask_thr;
+    int32_t layer_tiles;         // LAYERED kernel: tiles of one layer (work item's tile index = layer * layer_tiles + tile)
 };
+
+// One pixel against colours [c0, c1): masks[c, pix] = || (r,g,b) - colors[c] ||_2 <= thr with the arithmetic of
+// color_masks_kernel below, bit for bit (same expression tree; the wave-wide shortcut only skips work whose result is
+// known).  Every lane of the wave calls it; `inside` lanes store.
+__device__ __forceinline__ void pixel_masks(float r, float g, float b, const float* __restrict__ colors, int c0, int c1,
+                                            float thr, uint8_t* __restrict__ masks, size_t P, size_t pix, bool inside) {
+    const float far = thr * 1.000001f;
+    for (int c = c0; c < c1; ++c) {
+        const float d0 = r - colors[3 * c], d1 = g - colors[3 * c + 1], d2 = b - colors[3 * c + 2];
+        const bool surely_out = fabsf(d0) > far || fabsf(d1) > far || fabsf(d2) > far;
+        uint8_t m = 0;
+        if (__ballot(!surely_out) != 0ull) {
+            const float dist = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+            m = dist <= thr ? 1 : 0;
+        }
+        if (inside) gstore(masks + (size_t)c * P + pix, m);
+    }
+}
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -104,7 +126,9 @@ __device__ unsigned long long g_comp_stats[32];
 // continues over object entries only (environment entries are dropped before their record is even gathered) up to
 // the tile's last object entry (ViewEntry::obj_last, a by-product of the tile sort).  Pixel arithmetic is the
 // sequence a separate objects-only pass executes: bit-identical (tests/test_gpu_parity.py).
-template <bool AUX, bool FUSED>
+// LAYERED (pgr_forward_layers_async): the work item's tile index runs over n_layers stacked copies of the tile grid;
+// pixels and lists are those of the layer rendered alone, and the only output is the layer's colour-distance mask.
+template <bool AUX, bool FUSED, bool LAYERED = false>
 __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t item, const SemanticDev& sem, int n_sem,
                                                   bool sem_background, float4* __restrict__ s_g, float4* __restrict__ s_c,
                                                   float4* __restrict__ s_s, uint32_t* __restrict__ s_i,
@@ -114,16 +138,22 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
     const float4* __restrict__ splats = ve.splats;
     const CompOut o = ve.out;
     const int W = cam.width, H = cam.height;
-    const int tile = (int)(item >> 2), quarter = (int)(item & 3);
+    const int list = (int)(item >> 2), quarter = (int)(item & 3);     // list = tile, or layer * layer_tiles + tile
+    const int layer = LAYERED ? list / sem.layer_tiles : 0;
+    const int tile = LAYERED ? list - layer * sem.layer_tiles : list;
     const int tile_x = tile % cam.grid_x, tile_y = tile / cam.grid_x;
     const int lane = threadIdx.x;
     const int qx0 = tile_x * TILE + (quarter & 1) * 8, qy0 = tile_y * TILE + (quarter >> 1) * 8;
     if (qx0 >= W || qy0 >= H) return;            // quarter entirely outside the image
     const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
     const bool inside = px < W && py < H;
+    // the pixel's index, formed ONCE (pinned: the epilogue's stores would otherwise each rebuild it from the lane's row and
+    // column, and keep those live through the walk -- 78 instead of 72 VGPRs in the fused kernel, 6 instead of 7 waves)
+    uint32_t pix32 = (uint32_t)py * (uint32_t)W + (uint32_t)px;
+    asm volatile("" : "+v"(pix32));
     const f32x2 pxf = {(float)px, (float)px}, pyf = {(float)py, (float)py};
 
-    const uint2 range = gload(ve.ranges + tile);
+    const uint2 range = gload(ve.ranges + list);
     const int n = (int)(range.y - range.x);
     const bool want_sem = FUSED;                  // (the kernel sends only quarters with object entries down this path)
 
@@ -392,28 +422,45 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
                      for (int m = 0; m < 3; ++m) { atomicAdd(&g_comp_stats[22 + m], st_mode_b[m]); atomicAdd(&g_comp_stats[25 + m], st_mode_e[m]); } }
     }
 #endif
+    const size_t P = (size_t)W * H;
+    const size_t pix = pix32;
+    // depth rule (PgrDepthMode): the un-normalised sum, or the sum over 1 - T_final (= the blended weights' total)
+    const bool norm_depth = cam.depth_mode == PGR_DEPTH_NORMALIZED;
+    auto depth_out = [&](float D, float Tf) {
+        if (!norm_depth) return D;
+        const float wsum = 1.0f - Tf;
+        return wsum > 0.0f ? D / wsum : 0.0f;
+    };
+    if (LAYERED) {
+        pixel_masks(fmaf(T, cam.bg[0], Crg.x), fmaf(T, cam.bg[1], Crg.y), fmaf(T, cam.bg[2], Cbd.x), sem.mask_colors, layer,
+                    layer + 1, sem.mask_thr, ve.sem_masks, P, pix, inside);
+        return;
+    }
     if (inside) {
-        const size_t P = (size_t)W * H;
-        const size_t pix = (size_t)py * W + px;
         gstore(o.color + 0 * P + pix, fmaf(T, cam.bg[0], Crg.x));
         gstore(o.color + 1 * P + pix, fmaf(T, cam.bg[1], Crg.y));
         gstore(o.color + 2 * P + pix, fmaf(T, cam.bg[2], Cbd.x));
-        if (o.depth) gstore(o.depth + pix, Cbd.y);
+        if (o.depth) gstore(o.depth + pix, depth_out(Cbd.y, T));
         if (AUX) {
             if (o.final_T) gstore(o.final_T + pix, T);
             if (o.n_contrib) gstore(o.n_contrib + pix, last);
         }
-        if (want_sem) {
-            gstore(ve.sem_color + 0 * P + pix, fmaf(Ts, cam.bg[0], Srg.x));
-            gstore(ve.sem_color + 1 * P + pix, fmaf(Ts, cam.bg[1], Srg.y));
-            gstore(ve.sem_color + 2 * P + pix, fmaf(Ts, cam.bg[2], Sbd.x));
-            if (ve.sem_depth) gstore(ve.sem_depth + pix, Sbd.y);
-        } else if (sem_background) {             // no object entry in this tile: the objects-only image is the background
-            gstore(ve.sem_color + 0 * P + pix, cam.bg[0]);       // (= fmaf(1, bg, 0) of the general form, bit for bit)
-            gstore(ve.sem_color + 1 * P + pix, cam.bg[1]);
-            gstore(ve.sem_color + 2 * P + pix, cam.bg[2]);
-            if (ve.sem_depth) gstore(ve.sem_depth + pix, 0.0f);
+    }
+    if (want_sem || sem_background) {
+        // the objects-only image's pixel; a tile without object entries holds the background (= fmaf(1, bg, 0) of the
+        // general form, bit for bit)
+        const float sr = want_sem ? fmaf(Ts, cam.bg[0], Srg.x) : cam.bg[0];
+        const float sg = want_sem ? fmaf(Ts, cam.bg[1], Srg.y) : cam.bg[1];
+        const float sb = want_sem ? fmaf(Ts, cam.bg[2], Sbd.x) : cam.bg[2];
+        if (inside) {
+            gstore(ve.sem_color + 0 * P + pix, sr);
+            gstore(ve.sem_color + 1 * P + pix, sg);
+            gstore(ve.sem_color + 2 * P + pix, sb);
+            if (ve.sem_depth) gstore(ve.sem_depth + pix, want_sem ? depth_out(Sbd.y, Ts) : 0.0f);
         }
+        // the K masks of that pixel, from the registers that hold it (round 3: a separate pass re-read 12 P bytes per view)
+        if (ve.sem_masks && sem.mask_colors)
+            pixel_masks(sr, sg, sb, sem.mask_colors, 0, sem.k, sem.mask_thr, ve.sem_masks, P, pix, inside);
     }
 }
 
@@ -423,7 +470,7 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
 // -- of the 27 us per view the semantic image cost on C3, 11 were this.  (Tried on top, slower: routing the environment
 // entries of fused quarters through a copy of the plain blend -- three inlined copies of the blend cost more than the
 // scalar tests they saved.)
-template <bool AUX, bool FUSED>
+template <bool AUX, bool FUSED, bool LAYERED = false>
 __global__ __launch_bounds__(WAVE) PGR_COMP_OCC void composite_quarter_kernel(const ViewEntry* __restrict__ views,
                                                                               uint32_t items_per_view,
                                                                               const uint32_t* __restrict__ work_order,
@@ -433,14 +480,16 @@ __global__ __launch_bounds__(WAVE) PGR_COMP_OCC void composite_quarter_kernel(co
     const uint32_t view = item / items_per_view;
     item -= view * items_per_view;
     const ViewEntry& ve = views[view];
-    if (ve.counters[1] || !ve.out.color) return;
+    if (ve.counters[1] || (LAYERED ? !ve.sem_masks : !ve.out.color)) return;
     constexpr int PAIRS = WAVE_BATCH / 2 + 1;     // +1: a null entry pads an odd batch
     __shared__ float4 s_g[3 * PAIRS];
     __shared__ float4 s_c[2 * PAIRS];
     __shared__ float4 s_s[FUSED ? 2 * PAIRS : 1];
     __shared__ uint32_t s_i[AUX ? 2 * PAIRS : 1];
     __shared__ float s_col[FUSED ? 3 * SEM_LDS_OBJECTS : 1];
-    if constexpr (FUSED) {
+    if constexpr (LAYERED) {
+        composite_quarter<false, false, true>(ve, item, sem, 0, false, s_g, s_c, s_s, s_i, nullptr);
+    } else if constexpr (FUSED) {
         const bool want_sem = ve.sem_color != nullptr;
         // object entries live in [0, n_sem).  readfirstlane: the value arrives through a vector load; everything derived
         // from it (the semantic masks, the loop exits) must stay on the scalar unit
@@ -460,10 +509,18 @@ __global__ __launch_bounds__(WAVE) PGR_COMP_OCC void composite_quarter_kernel(co
     }
 }
 
-template <bool AUX, bool FUSED>
+template <bool AUX, bool FUSED, bool LAYERED = false>
 inline void launch_composite(uint32_t slots, hipStream_t stream, const ViewEntry* views, uint32_t items_per_view,
                              const uint32_t* work_order, SemanticDev sem) {
-    composite_quarter_kernel<AUX, FUSED><<<slots, WAVE, 0, stream>>>(views, items_per_view, work_order, sem);
+    composite_quarter_kernel<AUX, FUSED, LAYERED><<<slots, WAVE, 0, stream>>>(views, items_per_view, work_order, sem);
+}
+
+// One launch prepares a batch's header: [zero, zero + n_zero) words cleared (tile counters | obj_last, work-order state),
+// [ff, ff + n_ff) words set to INVALID_ITEM (the work order).  Was three memsets.
+__global__ void batch_init_kernel(uint32_t* __restrict__ zero, size_t n_zero, uint32_t* __restrict__ ff, size_t n_ff) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += stride) gstore(zero + i, 0u);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ff; i += stride) gstore(ff + i, INVALID_ITEM);
 }
 
 // object ids of the object Gaussians as one byte each (see SemanticDev::object_u8)
@@ -487,13 +544,15 @@ constexpr int ORDER_BAND_ROWS = 1;
 constexpr int ORDER_CLASSES_USED = 3;            // > 4096, > 1024, rest
 constexpr int ORDER_BINS = NUM_XCD * ORDER_CLASSES_USED;
 
-// order_state layout (uint32): [ORDER_BINS] counters -> cursors, then [SORT_TIERS] lengths of the sort queues
+// order_state layout (uint32): [ORDER_BINS] counters -> cursors, then [SORT_TIERS] lengths of the sort queues, then the
+// ticket of tile_scan_kernel's workgroups (the last one turns the counters into cursors)
 // Sort queues: every non-empty list of a view that did not overflow is one uint4 (item, first instance, keys, 0) in the
 // queue of its tier -- 1..2048 keys, 2049..4096, 4097..8192, longer: one queue and one sort launch each.  A sort
 // workgroup learns its list from that one word (the view's table entry arrives beside it through the scalar cache)
 // instead of chasing item -> view table -> ranges -> keys; and a launch has no workgroups for empty tiles.
 constexpr int SORT_TIERS = 4;
-constexpr int ORDER_STATE_WORDS = ORDER_BINS + SORT_TIERS;
+constexpr int ORDER_DONE_WORD = ORDER_BINS + SORT_TIERS;
+constexpr int ORDER_STATE_WORDS = ORDER_BINS + SORT_TIERS + 1;
 
 __device__ __forceinline__ int sort_tier(uint32_t len) { return len > 8192u ? 3 : (len > 4096u ? 2 : (len > 2048u ? 1 : 0)); }
 
@@ -506,32 +565,7 @@ __host__ __device__ inline int max_band_rows(int grid_y) {
     return (bands + NUM_XCD - 1) / NUM_XCD * ORDER_BAND_ROWS;
 }
 
-// grid = (ceil(tiles/256), n_views), 256 threads
-__global__ __launch_bounds__(256) void order_count_kernel(const ViewEntry* __restrict__ views, int tiles, int grid_x,
-                                                          uint32_t* __restrict__ state) {
-    __shared__ uint32_t hist[ORDER_BINS];
-    if (threadIdx.x < ORDER_BINS) hist[threadIdx.x] = 0;
-    __syncthreads();
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < tiles) {
-        const uint2 r = views[blockIdx.y].ranges[t];
-        atomicAdd(&hist[xcd_of_tile(t, grid_x) * ORDER_CLASSES_USED + coarse_class(r.y - r.x)], ITEMS_PER_TILE);
-    }
-    __syncthreads();
-    if (threadIdx.x < ORDER_BINS && hist[threadIdx.x]) atomicAdd(&state[threadIdx.x], hist[threadIdx.x]);
-}
-
-// 1 thread per stream: exclusive prefix over the classes = write cursors
-__global__ void order_scan_kernel(uint32_t* __restrict__ state) {
-    const int x = threadIdx.x;
-    if (x >= NUM_XCD) return;
-    uint32_t acc = 0;
-    for (int c = 0; c < ORDER_CLASSES_USED; ++c) {
-        const uint32_t v = state[x * ORDER_CLASSES_USED + c];
-        state[x * ORDER_CLASSES_USED + c] = acc;
-        acc += v;
-    }
-}
+// (the counts per (stream, class) and their prefix sums: tile_scan_kernel, tilebin.hip.h)
 
 // grid = (ceil(tiles/256), n_views), 256 threads.  work_order is pre-filled with INVALID_ITEM.  Ranks inside a
 // workgroup follow the tile order (ballot prefix per bin), so row-major neighbours stay adjacent in their
@@ -670,6 +704,39 @@ __global__ void pack_frames_kernel(const float* __restrict__ color, const float*
             for (int m = 8 * j; m < min(k, 8 * j + 8); ++m)
                 bits |= (masks[(b * (size_t)k + m) * P + p] ? 1u : 0u) << (m & 7);
             mask_bits[(b * P + p) * bytes + j] = (uint8_t)bits;
+        }
+    }
+}
+
+// One record per frame (include/pegasus_raster.h PgrRecordLayout): the two casts of pack_frames_kernel and the mask bit
+// planes, written into the frame's contiguous record -- the unit the gather to the root rank and the disk writers move.
+__global__ void pack_records_kernel(const float* __restrict__ color, const float* __restrict__ depth,
+                                    const uint8_t* __restrict__ masks, size_t P, int k, uint8_t* __restrict__ records,
+                                    size_t record_stride, size_t off_depth, size_t off_masks) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const size_t b = blockIdx.y;
+    uint8_t* rec = records + b * record_stride;
+    if (color) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = color[(b * 3 + c) * P + p] * 255.0f;
+            v = fminf(fmaxf(v, -2147483520.0f), 2147483520.0f);
+            rec[p * 3 + c] = (uint8_t)((int)v & 0xFF);
+        }
+    }
+    if (depth) {
+        float v = depth[b * P + p] * 1000.0f;
+        v = fminf(fmaxf(v, -2147483520.0f), 2147483520.0f);
+        reinterpret_cast<uint16_t*>(rec + off_depth)[p] = (uint16_t)((int)v & 0xFFFF);
+    }
+    if (masks) {
+        const int bytes = (k + 7) / 8;
+        for (int j = 0; j < bytes; ++j) {
+            uint32_t bits = 0;
+            for (int m = 8 * j; m < min(k, 8 * j + 8); ++m)
+                bits |= (masks[(b * (size_t)k + m) * P + p] ? 1u : 0u) << (m & 7);
+            rec[off_masks + p * bytes + j] = (uint8_t)bits;
         }
     }
 }

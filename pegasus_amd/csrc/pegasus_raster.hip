@@ -51,10 +51,11 @@ static bool records_enabled() {      // PGR_BIN_RECORDS=0: the scatter walk re-e
     return !(e && e[0] == '0');
 }
 
-static Layout make_layout(int32_t n, int32_t width, int32_t height, int64_t max_instances) {
+// layers > 1 (pgr_forward_layers_async): the view is `layers` stacked copies of the tile grid -- per-(tile, layer) lists
+static Layout make_layout(int32_t n, int32_t width, int32_t height, int64_t max_instances, int32_t layers = 1) {
     Layout L{};
     const size_t N = (size_t)(n > 0 ? n : 0), I = (size_t)(max_instances > 0 ? max_instances : 0);
-    const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
+    const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE * (layers > 1 ? layers : 1);
     L.tiles = gx * gy;
     L.grid_x = gx;
     L.grid_y = gy;
@@ -165,10 +166,11 @@ static BatchLayout make_batch_layout(const Layout& L, int n_views, size_t n_scen
     return B;
 }
 
-static int check_camera(const PgrCamera* cam, const PgrOutputs* out) {
+static int check_camera(const PgrCamera* cam, const PgrOutputs* out, bool layered = false) {
     if (!cam || !out || cam->image_width <= 0 || cam->image_height <= 0 || !(cam->tanfovx > 0.f) ||
-        !(cam->tanfovy > 0.f) || !cam->viewmatrix || !cam->projmatrix || !cam->campos || !cam->bg || !out->color ||
-        !out->depth)
+        !(cam->tanfovy > 0.f) || !cam->viewmatrix || !cam->projmatrix || !cam->campos || !cam->bg ||
+        (layered ? !out->sem_masks : (!out->color || !out->depth)) ||
+        (cam->depth_mode != PGR_DEPTH_EXPECTED && cam->depth_mode != PGR_DEPTH_NORMALIZED))
         return PGR_ERR_INVALID_ARGUMENT;
     // tile coordinates are packed into 16 bits
     if ((cam->image_width + TILE - 1) / TILE > 0xffff || (cam->image_height + TILE - 1) / TILE > 0xffff)
@@ -176,9 +178,12 @@ static int check_camera(const PgrCamera* cam, const PgrOutputs* out) {
     return PGR_OK;
 }
 
-static int zero_outputs(const PgrOutputs* out, size_t P, hipStream_t stream) {
-    if (!hip_ok(hipMemsetAsync(out->color, 0, 3 * P * sizeof(float), stream), "memset color") ||
-        !hip_ok(hipMemsetAsync(out->depth, 0, P * sizeof(float), stream), "memset depth"))
+static int zero_outputs(const PgrOutputs* out, size_t P, hipStream_t stream, int n_masks) {
+    if (out->color && !hip_ok(hipMemsetAsync(out->color, 0, 3 * P * sizeof(float), stream), "memset color"))
+        return PGR_ERR_LAUNCH_FAILURE;
+    if (out->depth && !hip_ok(hipMemsetAsync(out->depth, 0, P * sizeof(float), stream), "memset depth"))
+        return PGR_ERR_LAUNCH_FAILURE;
+    if (out->sem_masks && n_masks > 0 && !hip_ok(hipMemsetAsync(out->sem_masks, 0, (size_t)n_masks * P, stream), "memset masks"))
         return PGR_ERR_LAUNCH_FAILURE;
     if (out->final_T && !hip_ok(hipMemsetAsync(out->final_T, 0, P * sizeof(float), stream), "memset T"))
         return PGR_ERR_LAUNCH_FAILURE;
@@ -200,7 +205,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
                                   void* workspace, size_t workspace_bytes, int64_t max_instances,
                                   int64_t* num_instances, hipStream_t stream, hipEvent_t* ev,
                                   void* host_scratch = nullptr, const PgrSemantic* semantic = nullptr,
-                                  const PgrPosedObjects* posed = nullptr) {
+                                  const PgrPosedObjects* posed = nullptr, const PgrLayers* layers = nullptr) {
     auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], stream); };
     // every argument check happens here, before the first enqueue: an early return below this block would leave work
     // on the stream that still reads the (pageable) table staging of the synchronous path
@@ -208,17 +213,23 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         return PGR_ERR_INVALID_ARGUMENT;
     if (semantic && (!semantic->object_id || !semantic->colors || semantic->n_env < 0 || semantic->k_objects <= 0))
         return PGR_ERR_INVALID_ARGUMENT;
+    if (layers && (semantic || !layers->layer_id || !layers->mask_colors || layers->n_layers <= 0 || layers->n_layers > 4096))
+        return PGR_ERR_INVALID_ARGUMENT;
     if (n_views <= 0 || !cams || !outs) return PGR_ERR_INVALID_ARGUMENT;
     if (num_instances) for (int v = 0; v < n_views; ++v) num_instances[v] = 0;
     if (int rc = check_scene(scene)) return rc;
     if (max_instances < 0 || max_instances > 0x7fffffffLL) return PGR_ERR_INVALID_ARGUMENT;
     const int W = cams[0].image_width, H = cams[0].image_height, N = scene->n;
     for (int v = 0; v < n_views; ++v) {
-        if (int rc = check_camera(&cams[v], &outs[v])) return rc;
+        if (int rc = check_camera(&cams[v], &outs[v], layers != nullptr)) return rc;
         if (cams[v].image_width != W || cams[v].image_height != H) return PGR_ERR_INVALID_ARGUMENT;
         // a semantic descriptor asks for the objects-only image of EVERY view of the batch
         if (semantic && !outs[v].sem_color) return PGR_ERR_INVALID_ARGUMENT;
+        // masks in the compositor's epilogue need the colours to threshold against
+        if (!layers && outs[v].sem_masks && !(semantic && semantic->mask_colors)) return PGR_ERR_INVALID_ARGUMENT;
     }
+    const int n_layers = layers ? layers->n_layers : 1;
+    if (layers && (size_t)n_layers * ((H + TILE - 1) / TILE) > 0xffffu) return PGR_ERR_INVALID_ARGUMENT;   // 16-bit tile rows
     const size_t P = (size_t)W * H;
     // failure after the first enqueue: the synchronous path drains the stream before its staging memory goes away
     auto fail = [&](int32_t rc) {
@@ -229,12 +240,14 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     // N == 0: outputs stay zero-filled, no background (SURVEY.md section 8a "Edge cases")
     if (N == 0) {
         for (int v = 0; v < n_views; ++v)
-            if (int rc = zero_outputs(&outs[v], P, stream)) return rc;
+            if (int rc = zero_outputs(&outs[v], P, stream, layers ? n_layers : (semantic ? semantic->k_objects : 0))) return rc;
         return PGR_OK;
     }
 
     if (!workspace) return PGR_ERR_INVALID_ARGUMENT;
-    const Layout L = make_layout(N, W, H, max_instances);
+    const Layout L = make_layout(N, W, H, max_instances, n_layers);
+    const int layer_tiles = L.tiles / n_layers, layer_rows = L.grid_y / n_layers;
+    if (layers && layer_tiles > BIN_LDS_TILES) return PGR_ERR_INVALID_ARGUMENT;     // one layer per LDS pass
     const BatchLayout B = make_batch_layout(L, n_views, (size_t)N);
     if (workspace_bytes < B.total) return PGR_ERR_WORKSPACE_TOO_SMALL;
     char* ws = static_cast<char*>(workspace);
@@ -260,7 +273,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     bool want_aux = false, want_sem = false;
     // the count walk's verdicts live where the sort's outputs will (alt, gauss_sorted: contiguous, dead until the sort)
     const size_t verdict_room = (L.total - L.alt) / (VERDICT_REGION_WORDS * 4);
-    const int verdict_groups = L.tiles <= BIN_LDS_TILES && records_enabled()
+    const int verdict_groups = layer_tiles <= BIN_LDS_TILES && records_enabled()
                                    ? (int)std::min<size_t>(verdict_room, (size_t)(N + WAVE - 1) / WAVE) : 0;
     for (int v = 0; v < n_views; ++v) {
         vw[v] = carve(ws + B.views + (size_t)v * B.per_view, L);
@@ -277,12 +290,13 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         e.sem_color = semantic ? outs[v].sem_color : nullptr;
         e.sem_depth = semantic ? outs[v].sem_depth : nullptr;
         e.obj_last = vw[v].obj_last;
+        e.sem_masks = (semantic || layers) ? outs[v].sem_masks : nullptr;
         want_sem = want_sem || e.sem_color;
         want_aux = want_aux || outs[v].final_T || outs[v].n_contrib;
         bins[v] = BinView{vw[v].crects, vw[v].splats, vw[v].tile_count, vw[v].rel, vw[v].ranges,
                           vw[v].counters, vw[v].bucket, vw[v].gauss_sorted, vw[v].alt, vw[v].obj_last,
                           semantic ? semantic->n_env : -1, scene->tie_index,
-                          scene->tie_index ? reinterpret_cast<const uint32_t*>(ws + B.tie_inv) : nullptr,
+                          scene->tie_index ? (scene->tie_inv ? scene->tie_inv : reinterpret_cast<const uint32_t*>(ws + B.tie_inv)) : nullptr,
                           reinterpret_cast<uint2*>(vw[v].alt)};
         // radii and the reference-style 3-sigma rectangles are per-view OUTPUTS: written only when the caller asks for
         // radii (12 N bytes per view the frame path never reads; pgr_workspace_view's `rects` is valid only then)
@@ -293,7 +307,11 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
 
     // ---- stage 0: camera pack + per-Gaussian preprocess
     mark(0);
-    if (scene->tie_index)
+    // the batch header in one launch: tile counters | obj_last and the work-order state cleared, the work order invalid
+    static_assert(ORDER_STATE_WORDS * 4 <= 256, "order state fits its slot");
+    batch_init_kernel<<<256, 256, 0, stream>>>(reinterpret_cast<uint32_t*>(ws + B.tile_counts), (B.work_order - B.tile_counts) / 4,
+                                              reinterpret_cast<uint32_t*>(ws + B.work_order), B.order_slots);
+    if (scene->tie_index && !scene->tie_inv)     // (a per-scene constant: pgr_scene_prepare computes it once)
         invert_tie_index_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, scene->tie_index,
                                                                       reinterpret_cast<uint32_t*>(ws + B.tie_inv));
     for (int v0 = 0; v0 < n_views; v0 += CAM_PACK_MAX) {
@@ -302,7 +320,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         for (int k = 0; k < cnt; ++k) {
             const PgrCamera& c = cams[v0 + k];
             cp.view[k] = c.viewmatrix; cp.proj[k] = c.projmatrix; cp.campos[k] = c.campos; cp.bg[k] = c.bg;
-            cp.tanfovx[k] = c.tanfovx; cp.tanfovy[k] = c.tanfovy;
+            cp.tanfovx[k] = c.tanfovx; cp.tanfovy[k] = c.tanfovy; cp.depth_mode[k] = c.depth_mode;
         }
         pack_camera_kernel<<<cnt, 64, 0, stream>>>(cp, W, H, cams_dev + v0);
     }
@@ -314,45 +332,43 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     // one pass over the Gaussians for the whole batch (scene data read once, per-view outputs written)
     const PosedDev pd{posed ? posed->object_id : nullptr, posed ? posed->poses : nullptr, posed ? posed->k_objects : 0};
     const int deg = scene->shs ? scene->sh_degree : 0;
-#define PGR_PRE(D, Pz) preprocess_batch_kernel<D, Pz><<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, cams_dev, pre_table, n_views, pd, vis, B.vis_words)
-    if (posed) {
-        switch (deg) { case 0: PGR_PRE(0, true); break; case 1: PGR_PRE(1, true); break; case 2: PGR_PRE(2, true); break;
-                       default: PGR_PRE(3, true); break; }
+    const LayerDev ld{layers ? layers->layer_id : nullptr, n_layers};
+#define PGR_PRE(D, Pz, Ly) preprocess_batch_kernel<D, Pz, Ly><<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, cams_dev, pre_table, n_views, pd, vis, B.vis_words, ld)
+#define PGR_PRE_DEG(Pz, Ly) switch (deg) { case 0: PGR_PRE(0, Pz, Ly); break; case 1: PGR_PRE(1, Pz, Ly); break; \
+                                           case 2: PGR_PRE(2, Pz, Ly); break; default: PGR_PRE(3, Pz, Ly); break; }
+    if (layers) {
+        if (posed) { PGR_PRE_DEG(true, true) } else { PGR_PRE_DEG(false, true) }
     } else {
-        switch (deg) { case 0: PGR_PRE(0, false); break; case 1: PGR_PRE(1, false); break; case 2: PGR_PRE(2, false); break;
-                       default: PGR_PRE(3, false); break; }
+        if (posed) { PGR_PRE_DEG(true, false) } else { PGR_PRE_DEG(false, false) }
     }
+#undef PGR_PRE_DEG
 #undef PGR_PRE
     mark(1);
     // ---- stage 1: per-chunk LDS tile histograms + slice reservation, then the tile scan (device only)
     const int grid_x = (W + TILE - 1) / TILE;
     const bool few_views = n_views <= SMALL_BATCH_VIEWS;
-    const size_t lds = bin_lds_bytes(L.tiles, few_views ? BIN_THREADS_SMALL : BIN_THREADS);
-    if (!hip_ok(hipMemsetAsync(ws + B.tile_counts, 0, (size_t)n_views * L.tiles * 8, stream), "memset tile counts"))
-        return fail(PGR_ERR_LAUNCH_FAILURE);
+    const size_t lds = bin_lds_bytes(layer_tiles, few_views ? BIN_THREADS_SMALL : BIN_THREADS);
+    const BinLayers bl{layers ? layers->layer_id : nullptr, layer_tiles, layer_rows, n_layers};
     if (few_views)
         bin_kernel<false, BIN_THREADS_SMALL><<<dim3(L.n_chunks, n_views), BIN_THREADS_SMALL, lds, stream>>>(
-            bin_table, N, grid_x, L.tiles, W, H, vis, B.vis_words, verdict_groups);
+            bin_table, N, grid_x, L.tiles, W, H, vis, B.vis_words, verdict_groups, bl);
     else
         bin_kernel<false, BIN_THREADS><<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(
-            bin_table, N, grid_x, L.tiles, W, H, vis, B.vis_words, verdict_groups);
-    tile_scan_kernel<<<n_views, 1024, 0, stream>>>(bin_table, L.tiles, (uint32_t)max_instances);
+            bin_table, N, grid_x, L.tiles, W, H, vis, B.vis_words, verdict_groups, bl);
+    // tile scan -> ranges; the same pass counts the compositor's work items per (XCD stream, length class) and its last
+    // workgroup turns the counts into the streams' write cursors
+    tile_scan_kernel<<<n_views, 1024, 0, stream>>>(bin_table, L.tiles, (uint32_t)max_instances, L.grid_x, order_state);
     mark(2);
     // ---- stage 2: scatter (depth bits, index) into the tiles' slices
     if (few_views)
         bin_kernel<true, BIN_THREADS_SMALL><<<dim3(L.n_chunks, n_views), BIN_THREADS_SMALL, lds, stream>>>(
-            bin_table, N, grid_x, L.tiles, W, H, vis, B.vis_words, verdict_groups);
+            bin_table, N, grid_x, L.tiles, W, H, vis, B.vis_words, verdict_groups, bl);
     else
         bin_kernel<true, BIN_THREADS><<<dim3(L.n_chunks, n_views), BIN_THREADS, lds, stream>>>(
-            bin_table, N, grid_x, L.tiles, W, H, vis, B.vis_words, verdict_groups);
+            bin_table, N, grid_x, L.tiles, W, H, vis, B.vis_words, verdict_groups, bl);
     mark(3);
     // ---- stage 3: work order (XCD streams, longest lists first) + per-tile (depth, index) sort
-    if (!hip_ok(hipMemsetAsync(order_state, 0, ORDER_STATE_WORDS * 4, stream), "memset order state") ||
-        !hip_ok(hipMemsetAsync(work_order, 0xff, B.order_slots * 4, stream), "memset work order"))
-        return fail(PGR_ERR_LAUNCH_FAILURE);
     const dim3 og((L.tiles + 255) / 256, n_views);
-    order_count_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, L.grid_x, order_state);
-    order_scan_kernel<<<1, 64, 0, stream>>>(order_state);
     const int items = n_views * L.tiles;
     const size_t qs = (size_t)items;              // queue stride
     const bool merge_long = n_views <= SMALL_BATCH_VIEWS;
@@ -373,18 +389,22 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     // walk also produces the objects-only semantic image
     const uint32_t items_per_view = ITEMS_PER_TILE * (uint32_t)L.tiles;
     const uint32_t slots = (uint32_t)B.order_slots;
-    SemanticDev sd{nullptr, nullptr, nullptr, 0, 0};
+    SemanticDev sd{nullptr, nullptr, nullptr, 0, 0, nullptr, 0.0f, layer_tiles};
     if (want_sem) {
-        const uint8_t* ids_u8 = nullptr;
-        if (semantic->k_objects <= 255 && semantic->n_env < N) {
+        const uint8_t* ids_u8 = semantic->object_id_u8;      // (a per-scene constant: pgr_scene_prepare packs it once)
+        if (!ids_u8 && semantic->k_objects <= 255 && semantic->n_env < N) {
             auto* dst = reinterpret_cast<uint8_t*>(ws + B.obj_u8);
             const int n_obj = N - semantic->n_env;
             pack_object_ids_kernel<<<(n_obj + 255) / 256, 256, 0, stream>>>(semantic->object_id, semantic->n_env, N, dst);
             ids_u8 = dst;
         }
-        sd = SemanticDev{semantic->object_id, ids_u8, semantic->colors, semantic->n_env, semantic->k_objects};
+        sd = SemanticDev{semantic->object_id, ids_u8, semantic->colors, semantic->n_env, semantic->k_objects,
+                         semantic->mask_colors, semantic->mask_threshold, layer_tiles};
     }
-    if (want_aux && want_sem)
+    if (layers) {
+        sd.mask_colors = layers->mask_colors; sd.mask_thr = layers->mask_threshold; sd.k = n_layers;
+        launch_composite<false, false, true>(slots, stream, view_table, items_per_view, work_order, sd);
+    } else if (want_aux && want_sem)
         launch_composite<true, true>(slots, stream, view_table, items_per_view, work_order, sd);
     else if (want_aux)
         launch_composite<true, false>(slots, stream, view_table, items_per_view, work_order, sd);
@@ -415,7 +435,7 @@ using namespace pgr;
 extern "C" {
 
 int32_t pgr_abi_version(void) { return PGR_ABI_VERSION; }
-const char* pgr_version(void) { return "pegasus_raster 0.6 (gfx950)"; }
+const char* pgr_version(void) { return "pegasus_raster 0.7 (gfx950)"; }
 
 const char* pgr_status_string(int32_t status) {
     switch (status) {
@@ -501,6 +521,53 @@ int32_t pgr_forward_posed_async(const PgrScene* scene, const PgrSemantic* semant
     if (scene && scene->n == 0) memset(static_cast<char*>(host_scratch), 0, host_scratch_bytes(n_views));
     return forward_batch_impl(scene, n_views, cameras, outs, workspace, workspace_bytes, max_instances_per_view, nullptr,
                               static_cast<hipStream_t>(stream_v), nullptr, host_scratch, semantic, posed);
+}
+
+size_t pgr_layers_workspace_bytes(int32_t n, int32_t width, int32_t height, int64_t max_instances, int32_t n_views,
+                                  int32_t n_layers) {
+    if (n < 0 || width <= 0 || height <= 0 || max_instances < 0 || max_instances > 0x7fffffffLL || n_views <= 0 ||
+        n_layers <= 0 || n_layers > 4096)
+        return 0;
+    return make_batch_layout(make_layout(n, width, height, max_instances, n_layers), n_views, (size_t)n).total;
+}
+
+int32_t pgr_forward_layers_async(const PgrScene* scene, const PgrLayers* layers, const PgrPosedObjects* posed,
+                                 int32_t n_views, const PgrCamera* cameras, const PgrOutputs* outs, void* workspace,
+                                 size_t workspace_bytes, int64_t max_instances_per_view, void* host_scratch,
+                                 size_t host_scratch_size, void* stream_v) {
+    if (!layers || !host_scratch || n_views <= 0 || host_scratch_size < host_scratch_bytes(n_views))
+        return PGR_ERR_INVALID_ARGUMENT;
+    if (scene && scene->n == 0) memset(static_cast<char*>(host_scratch), 0, host_scratch_bytes(n_views));
+    return forward_batch_impl(scene, n_views, cameras, outs, workspace, workspace_bytes, max_instances_per_view, nullptr,
+                              static_cast<hipStream_t>(stream_v), nullptr, host_scratch, nullptr, posed, layers);
+}
+
+size_t pgr_scene_cache_bytes(int32_t n) { return n < 0 ? 0 : align_up((size_t)n * 4) + align_up((size_t)n); }
+
+int32_t pgr_scene_prepare(const PgrScene* scene, const PgrSemantic* semantic, void* cache, size_t cache_bytes,
+                          const uint32_t** tie_inv, const uint8_t** object_id_u8, void* stream_v) {
+    if (!scene || scene->n < 0 || !tie_inv || !object_id_u8) return PGR_ERR_INVALID_ARGUMENT;
+    *tie_inv = nullptr;
+    *object_id_u8 = nullptr;
+    const int N = scene->n;
+    if (N == 0) return PGR_OK;
+    if (!cache) return PGR_ERR_INVALID_ARGUMENT;
+    if (cache_bytes < pgr_scene_cache_bytes(N)) return PGR_ERR_WORKSPACE_TOO_SMALL;
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    char* c = static_cast<char*>(cache);
+    if (scene->tie_index) {
+        auto* inv = reinterpret_cast<uint32_t*>(c);
+        invert_tie_index_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, scene->tie_index, inv);
+        *tie_inv = inv;
+    }
+    if (semantic && semantic->object_id && semantic->k_objects > 0 && semantic->k_objects <= 255 && semantic->n_env >= 0 &&
+        semantic->n_env < N) {
+        auto* ids = reinterpret_cast<uint8_t*>(c + align_up((size_t)N * 4));
+        const int n_obj = N - semantic->n_env;
+        pack_object_ids_kernel<<<(n_obj + 255) / 256, 256, 0, stream>>>(semantic->object_id, semantic->n_env, N, ids);
+        *object_id_u8 = ids;
+    }
+    return hip_ok(hipGetLastError(), "scene_prepare launch") ? PGR_OK : PGR_ERR_LAUNCH_FAILURE;
 }
 
 int32_t pgr_batch_status(const void* host_scratch, int32_t n_views, int64_t* num_instances) {
@@ -613,7 +680,7 @@ int32_t pgr_block_visibility(const PgrScene* scene, int32_t n_views, const PgrCa
         for (int k = 0; k < cnt; ++k) {
             const PgrCamera& c = cams[v0 + k];
             cp.view[k] = c.viewmatrix; cp.proj[k] = c.projmatrix; cp.campos[k] = c.campos; cp.bg[k] = c.bg;
-            cp.tanfovx[k] = c.tanfovx; cp.tanfovy[k] = c.tanfovy;
+            cp.tanfovx[k] = c.tanfovx; cp.tanfovy[k] = c.tanfovy; cp.depth_mode[k] = 0;
         }
         pack_camera_kernel<<<cnt, 64, 0, stream>>>(cp, W, H, cams_dev + v0);
     }
@@ -666,6 +733,30 @@ int32_t pgr_pack_frames(const float* color_b3hw, const float* depth_bhw, const u
     pack_frames_kernel<<<dim3((unsigned)((P + 255) / 256), n_images), 256, 0, static_cast<hipStream_t>(stream_v)>>>(
         color_b3hw, depth_bhw, masks_bkhw, P, k, rgb_bhwc, depth_mm_bhw, mask_bits_bhwj);
     return hip_ok(hipGetLastError(), "pack_frames launch") ? PGR_OK : PGR_ERR_LAUNCH_FAILURE;
+}
+
+int32_t pgr_frame_record_layout(int32_t width, int32_t height, int32_t k, PgrRecordLayout* layout) {
+    if (!layout || width <= 0 || height <= 0 || k < 0) return PGR_ERR_INVALID_ARGUMENT;
+    const size_t P = (size_t)width * height;
+    layout->off_rgb = 0;
+    layout->off_depth = (int64_t)align_up(3 * P, 16);
+    layout->off_masks = layout->off_depth + (int64_t)align_up(2 * P, 16);
+    layout->bytes = layout->off_masks + (int64_t)align_up((size_t)((k + 7) / 8) * P, 16);
+    return PGR_OK;
+}
+
+int32_t pgr_pack_records(const float* color_b3hw, const float* depth_bhw, const uint8_t* masks_bkhw, int32_t n_images,
+                         int32_t k, int32_t width, int32_t height, uint8_t* records, int64_t record_stride,
+                         void* stream_v) {
+    PgrRecordLayout L;
+    if (pgr_frame_record_layout(width, height, k, &L) != PGR_OK || n_images < 0 || n_images > 65535 || !records ||
+        record_stride < L.bytes || (record_stride & 15) || (masks_bkhw && k == 0))
+        return PGR_ERR_INVALID_ARGUMENT;
+    if (n_images == 0) return PGR_OK;
+    const size_t P = (size_t)width * height;
+    pack_records_kernel<<<dim3((unsigned)((P + 255) / 256), n_images), 256, 0, static_cast<hipStream_t>(stream_v)>>>(
+        color_b3hw, depth_bhw, masks_bkhw, P, k, records, (size_t)record_stride, (size_t)L.off_depth, (size_t)L.off_masks);
+    return hip_ok(hipGetLastError(), "pack_records launch") ? PGR_OK : PGR_ERR_LAUNCH_FAILURE;
 }
 
 }  // extern "C"

@@ -36,6 +36,7 @@ __device__ __forceinline__ float4 gload(const float4* p) { const f32x4_t v = *(c
 __device__ __forceinline__ f32x4_t gload_quad(const float4* p) { return *(const PGR_GLOBAL f32x4_t*)p; }   // as one register tuple
 __device__ __forceinline__ void gstore(uint32_t* p, uint32_t v) { *(PGR_GLOBAL uint32_t*)p = v; }
 __device__ __forceinline__ void gstore(float* p, float v) { *(PGR_GLOBAL float*)p = v; }
+__device__ __forceinline__ void gstore(uint8_t* p, uint8_t v) { *(PGR_GLOBAL uint8_t*)p = v; }
 __device__ __forceinline__ void gstore(uint64_t* p, uint64_t v) { *(PGR_GLOBAL uint64_t*)p = v; }
 __device__ __forceinline__ void gstore(uint2* p, uint2 v) { *(PGR_GLOBAL u32x2_t*)p = u32x2_t{v.x, v.y}; }
 __device__ __forceinline__ void gstore(float4* p, float4 v) { *(PGR_GLOBAL f32x4_t*)p = f32x4_t{v.x, v.y, v.z, v.w}; }
@@ -44,6 +45,9 @@ __device__ __forceinline__ uint32_t gatomic_add(uint32_t* p, uint32_t v) {
 }
 __device__ __forceinline__ uint32_t gatomic_max(uint32_t* p, uint32_t v) {
     return __hip_atomic_fetch_max((PGR_GLOBAL uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t gatomic_load(const uint32_t* p) {     // sees other workgroups' agent-scope atomics
+    return __hip_atomic_load((const PGR_GLOBAL uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Per-view constants, resident in HBM so that no host round trip is needed to read the
@@ -58,7 +62,8 @@ struct alignas(16) CameraDev {
     float focal_x, focal_y;
     int32_t width, height;
     int32_t grid_x, grid_y;
-    int32_t pad[2];
+    int32_t depth_mode;                      // PgrDepthMode
+    int32_t pad[1];
     float pad2[16];
 };
 static_assert(sizeof(CameraDev) == 256, "CameraDev must be 256 B");

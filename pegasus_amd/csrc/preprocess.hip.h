@@ -214,15 +214,24 @@ struct PosedDev {
     int32_t k;
 };
 
+// LAYERED (pgr_forward_layers_async: silhouettes): Gaussian i belongs to image layer_id[i] of the view (0: to none, it is
+// dropped).  Everything per Gaussian is computed as if its layer were rendered alone; only the tile ROWS of its rectangles
+// are moved down by (layer - 1) x grid_y, so that the binning sees one tall image of n_layers x grid_y tile rows and
+// builds per-(tile, layer) lists.
+struct LayerDev {
+    const int32_t* layer_id;         // [n]
+    int32_t n_layers;
+};
+
 // vis_out != NULL: hierarchical culling (blockcull.hip.h).  The wave first bounds its 64 Gaussians, then lane l decides
 // for view 64 c + l whether the whole block is certainly culled there (one ballot = 64 views): such views are skipped by
 // the whole wave (radii / rectangles, where the caller wants them, are zero; the candidate rectangle is not written:
 // the binning walk consults the same bits, stored as vis_out[group * vis_words + view / 32]).
-template <int DEG, bool POSED>
+template <int DEG, bool POSED, bool LAYERED = false>
 __global__ __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void preprocess_batch_kernel(PgrScene sc, const CameraDev* __restrict__ cams,
                                                                      const PreOut* __restrict__ outs, int n_views,
                                                                      PosedDev posed, uint32_t* __restrict__ vis_out,
-                                                                     int vis_words) {
+                                                                     int vis_words, LayerDev layers = LayerDev{nullptr, 0}) {
     const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & (WAVE - 1);
     if (i - lane >= sc.n) return;            // the whole wave is past the end
@@ -234,6 +243,11 @@ __global__ __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
     const float bx = real ? sc.means3d[3 * i + 0] : 0.f, by = real ? sc.means3d[3 * i + 1] : 0.f,
                 bz = real ? sc.means3d[3 * i + 2] : 0.f;
     const int oid = POSED && real ? posed.object_id[i] : 0;
+    int layer = 0;                           // LAYERED: 1-based image layer of this Gaussian, 0 = in none
+    if (LAYERED && real) {
+        layer = layers.layer_id[i];
+        if (layer < 0 || layer > layers.n_layers) layer = 0;
+    }
     float cov[6];
     bool have_cov = false, have_sh = false;
     ShRegs sh;
@@ -258,6 +272,12 @@ __global__ __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
             }
         }
         if (!real) continue;                 // (rejoins the wave at the next view's ballot)
+        if (LAYERED && layer == 0) {         // in no layer: as if culled
+            if (o.radii) o.radii[i] = 0;
+            if (o.rects) o.rects[i] = make_uint2(0u, 0u);
+            o.crects[i] = make_uint2(0u, 0u);
+            continue;
+        }
         int radius = 0;
         uint2 rect = make_uint2(0u, 0u), crect = make_uint2(0u, 0u);
         // The view matrix and the camera scalars are fetched ONCE per iteration, here: left to the compiler, every field
@@ -382,6 +402,11 @@ __global__ __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                                       (uint32_t)r.maxx | ((uint32_t)r.maxy << 16));
                     const float op = sc.opacities[i];
                     crect = candidate_rect(r, pix_x, pix_y, c_xx, c_yy, con_x, con_y, con_z, op, rad);
+                    if (LAYERED) {           // tile rows of layer k start at (k - 1) * grid_y
+                        const uint32_t off = (uint32_t)((layer - 1) * cam_gy) << 16;
+                        rect.x += off; rect.y += off;
+                        if (crect.x | crect.y) { crect.x += off; crect.y += off; }
+                    }
                     float4* rec = out_splats + (size_t)i * SPLAT_F4;
                     rec[0] = make_float4(pix_x, pix_y, con_x, con_y);
                     rec[1] = make_float4(con_z, op, con_y / con_z, con_y / con_x);     // + the cull record's B/C, B/A (cull.hip.h)
@@ -404,6 +429,7 @@ struct CamPack {
     const float* campos[CAM_PACK_MAX];
     const float* bg[CAM_PACK_MAX];
     float tanfovx[CAM_PACK_MAX], tanfovy[CAM_PACK_MAX];
+    int32_t depth_mode[CAM_PACK_MAX];
 };
 
 __global__ void pack_camera_kernel(CamPack p, int width, int height, CameraDev* __restrict__ outs) {
@@ -427,6 +453,7 @@ __global__ void pack_camera_kernel(CamPack p, int width, int height, CameraDev* 
         out->height = height;
         out->grid_x = (width + TILE - 1) / TILE;
         out->grid_y = (height + TILE - 1) / TILE;
+        out->depth_mode = p.depth_mode[v];
     }
 }
 

@@ -23,6 +23,7 @@
 #pragma once
 #include <type_traits>
 
+#include "composite.hip.h"       // work-order constants (tile_scan_kernel also counts the compositor's work-order bins)
 #include "cull.hip.h"
 #include "pgr_common.h"
 
@@ -129,9 +130,22 @@ constexpr int BIN_STAGE_WORDS = WAVE * 12 + WAVE;         // per wave: 64 x 3 fl
 // for a single view.  (Several workgroups per chunk, each with its own `rel` row: the scatter walk gains what the count
 // walk loses to the extra zero-fills and flushes of 2 500 tile counters -- 2 parts 43 / 45 us, 4 parts 55 / 38: dropped.)
 constexpr int BIN_THREADS_SMALL = 1024;
+// tiles: tiles histogrammed per LDS pass (all of them up to BIN_LDS_TILES; a LAYERED call: the tiles of ONE layer)
 __host__ __device__ inline size_t bin_lds_bytes(int tiles, int threads) {
     return ((size_t)(tiles < BIN_LDS_TILES ? tiles : BIN_LDS_TILES) + 3) / 4 * 16 + (size_t)(threads / WAVE) * BIN_STAGE_WORDS * 4 + 16;
 }
+
+// LAYERED binning (pgr_forward_layers_async): the view is one tall image of n_layers x layer_rows tile rows, `tiles` =
+// n_layers x layer_tiles.  Gaussians are ordered by layer, so a chunk of 4096 holds one layer (two at a boundary): the
+// chunk histograms ONE layer per LDS pass -- lo = (layer - 1) x layer_tiles, span = layer_tiles -- over the layers its
+// first and last Gaussian name; a 64-Gaussian group takes part in the passes of the layers it holds, and a group that
+// straddles a boundary keeps no verdict bits (its region would be written once per pass).
+struct BinLayers {
+    const int32_t* layer_id;     // [n] non-decreasing; NULL = not layered
+    int32_t layer_tiles;         // grid_x * grid_y of one layer
+    int32_t layer_rows;          // grid_y of one layer
+    int32_t n_layers;
+};
 constexpr uint32_t VERDICT_WINDOWS = 62;                               // ballots per group region
 constexpr uint32_t VERDICT_REGION_WORDS = 192;                         // 4-byte words: 64 depths + 2 x 62 (+ 4 unused)
 
@@ -147,7 +161,8 @@ constexpr uint32_t VERDICT_REGION_WORDS = 192;                         // 4-byte
 template <bool SCATTER, int THREADS>
 __global__ __launch_bounds__(THREADS) void bin_kernel(const BinView* __restrict__ views, int n, int grid_x,
                                                           int tiles, int W, int H, const uint32_t* __restrict__ vis,
-                                                          int vis_words, int verdict_groups) {
+                                                          int vis_words, int verdict_groups,
+                                                          BinLayers layers = BinLayers{nullptr, 0, 0, 0}) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr int BIN_WAVES = THREADS / WAVE;
     const BinView& bv = views[blockIdx.y];
@@ -155,7 +170,8 @@ __global__ __launch_bounds__(THREADS) void bin_kernel(const BinView* __restrict_
     const int chunk = blockIdx.x;
     const int begin = chunk * BIN_CHUNK, end = min(n, begin + BIN_CHUNK);
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-    const int hist_words = (min(tiles, BIN_LDS_TILES) + 3) / 4 * 4;
+    const bool layered = layers.layer_id != nullptr;
+    const int hist_words = (min(layered ? layers.layer_tiles : tiles, BIN_LDS_TILES) + 3) / 4 * 4;
     float4* const stage = reinterpret_cast<float4*>(lds + hist_words + wave * BIN_STAGE_WORDS);   // [64][3]
     // lanes talk to each other through this array inside one wave: DS operations of a wave execute in order, and a
     // compiler memory barrier keeps the load behind the stores.  (NOT volatile: a volatile generic pointer turns the
@@ -165,8 +181,17 @@ __global__ __launch_bounds__(THREADS) void bin_kernel(const BinView* __restrict_
     uint32_t* const ctrl = lds + hist_words + BIN_WAVES * BIN_STAGE_WORDS;
     constexpr int GROUPS = BIN_CHUNK / WAVE;
     static_assert(GROUPS == WAVE, "one visibility bit per lane of a wave");
-    for (int lo = 0; lo < tiles; lo += BIN_LDS_TILES) {
-        const int span = min(BIN_LDS_TILES, tiles - lo);
+    // LDS passes: windows of BIN_LDS_TILES tiles, or (layered) the layers this chunk's Gaussians belong to
+    int pass_first = 0, pass_last = (tiles - 1) / BIN_LDS_TILES;
+    if (layered) {
+        if (begin >= end) return;
+        pass_first = max(1, min(layers.n_layers + 1, (int)gload(layers.layer_id + begin)));
+        pass_last = min(layers.n_layers, (int)gload(layers.layer_id + end - 1));
+    }
+    for (int lp = pass_first; lp <= pass_last; ++lp) {
+        const int lo = layered ? (lp - 1) * layers.layer_tiles : lp * BIN_LDS_TILES;
+        const int span = layered ? layers.layer_tiles : min(BIN_LDS_TILES, tiles - lo);
+        const int row_off = layered ? (lp - 1) * layers.layer_rows : 0;     // tile row of the layer's first row
         for (int t = threadIdx.x; t < span; t += THREADS)
             lds[t] = SCATTER ? gload(bv.ranges + lo + t).x + gload(bv.rel + (size_t)chunk * tiles + lo + t) : 0u;
         if (wave == 0) {
@@ -189,7 +214,12 @@ __global__ __launch_bounds__(THREADS) void bin_kernel(const BinView* __restrict_
         };
         for (uint32_t ticket = take_ticket(); ticket < (uint32_t)GROUPS; ticket = take_ticket()) {
             const int base = begin + (int)ticket * WAVE;
-            const bool has_region = base / WAVE < verdict_groups;
+            bool has_region = base / WAVE < verdict_groups;
+            if (layered) {                   // (scalar: the group's first and last layer)
+                const int l0 = gload(layers.layer_id + base), l1 = gload(layers.layer_id + min(base + WAVE, end) - 1);
+                if (lp < l0 || lp > l1) continue;
+                has_region = has_region && l0 == l1;
+            }
             uint32_t* const region = reinterpret_cast<uint32_t*>(bv.records) + (size_t)(base / WAVE) * VERDICT_REGION_WORDS;
             uint64_t* const ballots = reinterpret_cast<uint64_t*>(region + WAVE);
             const int i = base + lane;
@@ -276,7 +306,7 @@ __global__ __launch_bounds__(THREADS) void bin_kernel(const BinView* __restrict_
                         CullSplat cs;
                         cs.mx = o0.x; cs.my = o0.y; cs.A = o0.z; cs.B = o0.w;
                         cs.C = o1.x; cs.rBC = o1.y; cs.rBA = o1.z; cs.tau = o1.w; cs.flags = fw & 3u;
-                        pass = tile_may_contribute(cs, x, y, W, H);
+                        pass = tile_may_contribute(cs, x, y - row_off, W, H);
                     }
                     if (WRITE_BITS) {
                         const uint64_t m = __ballot(pass);
@@ -317,13 +347,21 @@ __global__ void invert_tie_index_kernel(int n, const int32_t* __restrict__ tie_i
 // screen-filling splats x thousands of tiles), and a wrapped 32-bit sum could land below max_instances and let the
 // scatter pass write through wrapped ranges.  Ranges are clamped to max_instances (no cursor can pass the buffers
 // even if a later stage ignored the flag); counters[0] saturates at 0xffffffff.
+//
+// The same pass knows every list's length, so it also does what two small launches did until round 3 (order_count,
+// order_scan): it counts the compositor's work items per (XCD stream, length class) into order_state, and the LAST
+// workgroup to finish (agent-scope ticket behind a fence) turns the counts into the streams' write cursors.
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const BinView* __restrict__ views, int tiles,
-                                                         uint32_t max_instances) {
+                                                         uint32_t max_instances, int grid_x,
+                                                         uint32_t* __restrict__ order_state) {
     __shared__ unsigned long long wave_tot[1024 / WAVE];
     __shared__ unsigned long long carry_s;
+    __shared__ uint32_t hist[ORDER_BINS];
+    __shared__ uint32_t last_s;
     const BinView& bv = views[blockIdx.x];
     const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
     if (threadIdx.x == 0) carry_s = 0;
+    if (threadIdx.x < ORDER_BINS) hist[threadIdx.x] = 0;
     __syncthreads();
     for (int base = 0; base < tiles; base += 1024) {
         const int idx = base + threadIdx.x;
@@ -341,7 +379,11 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const BinView* __restri
         const unsigned long long carry = carry_s;
         const unsigned long long excl = carry + wave_prefix + s - v;
         const unsigned long long cap = max_instances;
-        if (idx < tiles) bv.ranges[idx] = make_uint2((uint32_t)min(excl, cap), (uint32_t)min(excl + v, cap));
+        if (idx < tiles) {
+            const uint2 r = make_uint2((uint32_t)min(excl, cap), (uint32_t)min(excl + v, cap));
+            bv.ranges[idx] = r;
+            if (order_state) atomicAdd(&hist[xcd_of_tile(idx, grid_x) * ORDER_CLASSES_USED + coarse_class(r.y - r.x)], ITEMS_PER_TILE);
+        }
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = carry + wave_prefix + s;
         __syncthreads();
@@ -349,6 +391,22 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const BinView* __restri
     if (threadIdx.x == 0) {
         bv.counters[0] = (uint32_t)min(carry_s, 0xffffffffull);
         bv.counters[1] = carry_s > (unsigned long long)max_instances ? 1u : 0u;
+    }
+    if (!order_state) return;
+    if (threadIdx.x < ORDER_BINS && hist[threadIdx.x]) gatomic_add(order_state + threadIdx.x, hist[threadIdx.x]);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last_s = gatomic_add(order_state + ORDER_DONE_WORD, 1u) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!last_s) return;
+    __threadfence();
+    if (threadIdx.x < NUM_XCD) {             // one thread per stream: exclusive prefix over the classes = write cursors
+        uint32_t acc = 0;
+        for (int c = 0; c < ORDER_CLASSES_USED; ++c) {
+            const uint32_t v = gatomic_load(order_state + threadIdx.x * ORDER_CLASSES_USED + c);
+            gstore(order_state + threadIdx.x * ORDER_CLASSES_USED + c, acc);
+            acc += v;
+        }
     }
 }
 

@@ -7,8 +7,10 @@
                     /root/reference/src/gs/render.py:68-97)
 
 The reference does this one camera at a time with a deepcopy + 6 vstack per frame and host-side numpy
-masks; here a batch of cameras is two pgr_forward_batch calls over resident device tensors plus the mask
-kernel, and nothing leaves the GPU until the caller asks for it.
+masks; here a batch of cameras is ONE pipeline pass over resident device tensors (scene image, objects-only semantic image
+from the same per-tile lists, the K masks from the compositor's epilogue), and nothing leaves the GPU until the caller
+asks for it.  'seg_sil' (every object's silhouette, /root/reference/src/gs/render.py:36-65) is one more pass for all K
+objects at once (render_silhouettes: a layered call).
 """
 from __future__ import annotations
 
@@ -70,7 +72,9 @@ class FrameRenderer:
             dc_k = RGB2SH(self.colors_np).astype(np.float32)
             carried = np.maximum(np.float32(0.28209479177387814) * dc_k + np.float32(0.5), np.float32(0.0))
             self.semantic = dict(object_id=torch.from_numpy(oid.astype(np.int32)).to(self.device),
-                                 colors=t(carried.astype(np.float32)), n_env=self.n_env, k=self.K)
+                                 colors=t(carried.astype(np.float32)), n_env=self.n_env, k=self.K,
+                                 # the masks come out of the compositor's epilogue (bit for bit masks.color_masks of seg)
+                                 mask_colors=self.colors, mask_threshold=M.MASK_THRESHOLD)
             dc = RGB2SH(self.colors_np[oid[self.n_env:] - 1]).astype(np.float32)       # [n_obj,3]
             self.sem_shs = t(dc.reshape(-1, 1, 3))
             s = slice(self.n_env, self.n)
@@ -78,11 +82,17 @@ class FrameRenderer:
                             rotations=self.rotations[s])
             # tie order of the objects-only cloud: the caller's order of the object Gaussians among themselves
             self.obj_tie_index = None if self.tie_index is None else (self.tie_index[s] - self.n_env).contiguous()
+        # per-scene constants of the batch calls, once (pgr_scene_prepare): the inverse tie permutation, the object ids as bytes
+        self._prep = R.scene_prepare(self.n, self.tie_index, self.semantic if self.K else None)
+        self.tie_inv = self._prep["tie_inv"]
+        if self.K:
+            self.semantic["object_id_u8"] = self._prep["object_id_u8"]
 
-    def view_spec(self, view) -> R.ViewSpec:
+    def view_spec(self, view, depth_mode: int = 0) -> R.ViewSpec:
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
         return R.ViewSpec(view.height, view.width, view.tanfovx, view.tanfovy, self.bg,
-                          t(view.world_view_transform), t(view.full_proj_transform), t(view.camera_center))
+                          t(view.world_view_transform), t(view.full_proj_transform), t(view.camera_center),
+                          depth_mode=int(depth_mode))
 
     def alloc_frames(self, batch: int, height: int, width: int, masks: bool = True):
         dev = self.device
@@ -109,7 +119,7 @@ class FrameRenderer:
     def render_frames_async(self, specs: Sequence[R.ViewSpec], frames: dict, masks: bool = True, slot: int = 0,
                             poses=None):
         """The fast path: ONE batch call renders the scene (color, depth) and -- from the same per-tile lists --
-        the objects-only semantic image (seg), then one mask launch; enqueued on side stream ``slot`` (2 slots =
+        the objects-only semantic image (seg) and its K masks (compositor epilogue); enqueued on side stream ``slot`` (2 slots =
         two batches in flight on two streams; the streams are independent of each other and of the caller's stream
         after their start, so the batches overlap on the GPU).  Returns a ``wait()``-able handle; nothing
         synchronises the host.  Keep at most one batch in flight per slot.
@@ -131,6 +141,7 @@ class FrameRenderer:
         if fused:
             for i in range(B):
                 outs[i]["sem_color"], outs[i]["sem_depth"] = frames["seg"][i], frames["seg_depth"][i]
+                outs[i]["sem_masks"] = frames["masks"][i]
         st.wait_stream(cur)
         posed = self._posed(poses, B)
         if posed is not None:
@@ -140,11 +151,9 @@ class FrameRenderer:
             posed["poses"].record_stream(st)
         with torch.cuda.stream(st):
             h = R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales, tie_index=self.tie_index,
-                                rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False, outputs=outs,
-                                async_slot=("frames", slot), semantic=self.semantic if fused else None,
+                                tie_inv=self.tie_inv, rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False,
+                                outputs=outs, async_slot=("frames", slot), semantic=self.semantic if fused else None,
                                 posed=posed)
-            if fused:
-                M.color_masks(frames["seg"][:B], self.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])
             ev = torch.cuda.Event()
             ev.record(st)
         # The caller's stream does NOT wait here: the two slots' streams then really overlap on the GPU (batch i+1's
@@ -159,11 +168,8 @@ class FrameRenderer:
             _args = (specs, posed)       # keeps the caller's device tensors alive while the batch runs
 
             def wait(self_inner):
-                h.wait()
+                h.wait()           # (a batch re-rendered after an instance overflow rewrites its masks as well)
                 ev.synchronize()
-                if fused and getattr(h, "_was_redone", False):
-                    M.color_masks(frames["seg"][:B], renderer.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])
-                    torch.cuda.current_stream(dev).synchronize()
                 return frames
         return _Pending()
 
@@ -224,22 +230,63 @@ class FrameRenderer:
         if fused:
             for i in range(B):
                 outs[i]["sem_color"], outs[i]["sem_depth"] = frames["seg"][i], frames["seg_depth"][i]
+                outs[i]["sem_masks"] = frames["masks"][i]
         R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales, tie_index=self.tie_index,
-                        rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False, outputs=outs,
-                        stage_ms=stage_ms, semantic=self.semantic if fused else None, posed=self._posed(poses, B))
-        if fused:
-            M.color_masks(frames["seg"][:B], self.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])
+                        tie_inv=self.tie_inv, rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False,
+                        outputs=outs, stage_ms=stage_ms, semantic=self.semantic if fused else None,
+                        posed=self._posed(poses, B))
         return frames
 
-    def render_silhouettes(self, specs: Sequence[R.ViewSpec], out: torch.Tensor = None, poses=None) -> torch.Tensor:
+    def render_silhouettes(self, specs: Sequence[R.ViewSpec], out: torch.Tensor = None, poses=None, slot: int = 0,
+                           wait: bool = True):
         """Silhouette masks [B, K, H, W] uint8: object k rendered ALONE in its semantic colour and thresholded, i.e. its
         full outline whatever occludes it in the scene (/root/reference/src/gs/render.py:36-65 does this with one
-        deepcopy + merge + render per object and camera).  Here: one batch call per object over its slice of the
-        resident scene and one mask launch each, two passes in flight.  Measured on C3 (8 objects of 80 k Gaussians, 32
-        views of 800x800): 0.22 ms per view -- as much as the whole RGB + depth + visible-mask frame, because every pass
-        pays the fixed per-batch costs (tile launches over mostly empty tiles, full-image writes and mask reads); it is
-        an optional data point of the reference ('seg_sil'), not part of the measured frame.  ``poses`` as in
-        render_frames."""
+        deepcopy + merge + render per object and camera).  ONE layered batch call for all K objects (round 4;
+        pgr_forward_layers_async): the objects-only cloud is binned into per-(tile, object) lists -- the view is K stacked
+        copies of the tile grid -- and the compositor's epilogue thresholds layer k against colour k, so no image is
+        written or read back.  Bit-identical to K single-object passes (render_silhouettes_per_object, kept as the
+        checker).  ``poses`` as in render_frames; ``wait=False`` returns (out, pending) with the batch still in flight
+        on side stream ``slot``."""
+        B = len(specs)
+        H, W = int(specs[0].image_height), int(specs[0].image_width)
+        if out is None:
+            out = torch.empty((B, max(self.K, 1), H, W), dtype=torch.uint8, device=self.device)
+        if self.K == 0:
+            return out[:, :0] if wait else (out[:, :0], None)
+        if not hasattr(self, "_sil_prep"):
+            # the objects-only cloud: the caller's tie order among the object Gaussians, layer = object id
+            self._sil_layer_id = self.semantic["object_id"][self.n_env:].contiguous()
+            self._sil_prep = R.scene_prepare(self.n - self.n_env, self.obj_tie_index)
+        posed = None
+        if poses is not None:
+            posed = dict(object_id=self._sil_layer_id, poses=self._posed(poses, B)["poses"])
+        layers = dict(layer_id=self._sil_layer_id, n_layers=self.K, mask_colors=self.colors,
+                      mask_threshold=M.MASK_THRESHOLD)
+        outs = [dict(radii=None, sem_masks=out[i]) for i in range(B)]
+        dev = self.device
+        cur = torch.cuda.current_stream(dev)
+        if not hasattr(self, "_sil_streams"):
+            self._sil_streams = {}
+        st = self._sil_streams.get(slot)
+        if st is None:
+            st = self._sil_streams[slot] = torch.cuda.Stream(dev)
+        st.wait_stream(cur)
+        if posed is not None:
+            posed["poses"].record_stream(st)
+        with torch.cuda.stream(st):
+            h = R.forward_views(self.obj["means3d"], self.obj["opacities"], specs, shs=self.sem_shs, scales=self.obj["scales"],
+                                rotations=self.obj["rotations"], sh_degree=0, want_radii=False, posed=posed,
+                                tie_index=self.obj_tie_index, tie_inv=self._sil_prep["tie_inv"], outputs=outs,
+                                async_slot=("silhouette", slot), layers=layers)
+        h._args = (specs, posed, layers)
+        if not wait:
+            return out[:, :self.K], h
+        h.wait()
+        return out[:, :self.K]
+
+    def render_silhouettes_per_object(self, specs: Sequence[R.ViewSpec], out: torch.Tensor = None, poses=None) -> torch.Tensor:
+        """Round 2's form of render_silhouettes, kept as its checker: one batch call per object over its slice of the
+        resident scene and one mask launch each (0.22 ms per view for 8 objects at full size)."""
         B = len(specs)
         H, W = int(specs[0].image_height), int(specs[0].image_width)
         if out is None:
@@ -251,8 +298,6 @@ class FrameRenderer:
             self._obj_slices = [(int(np.searchsorted(oid, k, "left")), int(np.searchsorted(oid, k, "right")))
                                 for k in range(1, self.K + 1)]
         posed_all = self._posed(poses, B)
-        # two object passes in flight (two workspaces, two image buffers): the host prepares pass k + 1 while the GPU runs
-        # pass k; a slot is reused only after its previous pass has been waited for (its pinned tables are then free)
         if getattr(self, "_sil_img", None) is None or self._sil_img[0].shape != (B, 3, H, W):
             self._sil_img = [torch.empty((B, 3, H, W), device=self.device) for _ in range(2)]
         pending = [None, None]
@@ -274,7 +319,7 @@ class FrameRenderer:
             pending[slot] = R.forward_views(self.means3d[s], self.opacities[s], specs,
                                             shs=self.sem_shs[a - self.n_env:b - self.n_env], scales=self.scales[s],
                                             rotations=self.rotations[s], sh_degree=0, want_radii=False, posed=posed,
-                                            tie_index=tie, outputs=outs, async_slot=("silhouette", slot))
+                                            tie_index=tie, outputs=outs, async_slot=("silhouette1", slot))
             out[:, k:k + 1] = M.color_masks(img, self.colors[k:k + 1], M.MASK_THRESHOLD)      # (kernel output is contiguous)
         redo = False
         for p in pending:
@@ -282,7 +327,7 @@ class FrameRenderer:
                 p.wait()
                 redo = redo or getattr(p, "_was_redone", False)
         if redo:            # an instance overflow re-rendered a pass after its masks were taken: start over (sized now)
-            return self.render_silhouettes(specs, out, poses)
+            return self.render_silhouettes_per_object(specs, out, poses)
         return out[:, :self.K]
 
     def _sil_depth(self, B, H, W):

@@ -108,6 +108,63 @@ def pack_frames(color: torch.Tensor = None, depth: torch.Tensor = None, masks: t
     return out
 
 
+def record_layout(height: int, width: int, k: int) -> dict:
+    """Byte offsets of the three sections of a frame record and its size (pgr_frame_record_layout; host only)."""
+    lay = _lib.PgrRecordLayout()
+    _lib.check(_lib.lib().pgr_frame_record_layout(int(width), int(height), int(k), C.byref(lay)), "pgr_frame_record_layout")
+    return dict(off_rgb=int(lay.off_rgb), off_depth=int(lay.off_depth), off_masks=int(lay.off_masks), bytes=int(lay.bytes))
+
+
+def pack_records(color: torch.Tensor = None, depth: torch.Tensor = None, masks: torch.Tensor = None,
+                 out: torch.Tensor = None) -> torch.Tensor:
+    """One launch, ONE uint8 record per frame (pgr_pack_records): [B, record_layout(H, W, K)["bytes"]] holding the frame's
+    uint8 RGB (HWC), uint16 depth millimetres and the K masks as bit planes back to back -- the unit the gather to the root
+    rank and the disk writers move.  ``out``: a preallocated [>= B, bytes] uint8 tensor (e.g. a FrameGather send buffer)
+    is filled in place; record_views() slices a record tensor back into the three images without copying."""
+    L = _lib.lib()
+    ref = next(t for t in (color, depth, masks) if t is not None)
+    if ref.device.type != "cuda":
+        raise RuntimeError("pack_records needs HIP device tensors; there is no CPU path")
+    dev = ref.device
+    B, (H, W) = int(ref.shape[0]), ref.shape[-2:]
+    K = 0
+    if color is not None:
+        color = color.contiguous().float()
+    if depth is not None:
+        depth = depth.contiguous().float()
+    if masks is not None:
+        masks = masks.contiguous()
+        if masks.dtype != torch.uint8:
+            raise ValueError("masks must be uint8 [B,K,H,W]")
+        K = int(masks.shape[1])
+    nbytes = record_layout(H, W, K)["bytes"]
+    if out is None:
+        out = torch.empty((B, nbytes), dtype=torch.uint8, device=dev)
+    if out.dtype != torch.uint8 or out.dim() != 2 or out.shape[0] < B or out.shape[1] < nbytes or out.stride(1) != 1 \
+            or out.stride(0) % 16 or out.device != dev:
+        raise ValueError(f"out must be a uint8 [>= {B}, >= {nbytes}] device tensor with a 16-byte-aligned row stride")
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    with torch.cuda.device(dev):
+        _lib.check(L.pgr_pack_records(ptr(color), ptr(depth), ptr(masks), B, K, W, H, ptr(out), int(out.stride(0)),
+                                      _stream(dev)), "pgr_pack_records")
+    return out
+
+
+def record_views(records: torch.Tensor, height: int, width: int, k: int) -> dict:
+    """Zero-copy views of a [..., bytes] uint8 record tensor (any device, any leading shape, last dimension contiguous):
+    "rgb" uint8 [..., H, W, 3], "depth_mm" int16 storage of uint16 millimetres [..., H, W], "mask_bits" uint8
+    [..., H, W, ceil(k/8)]."""
+    lay = record_layout(height, width, k)
+    P, J = height * width, (k + 7) // 8
+    lead = tuple(records.shape[:-1])
+    out = {"rgb": records[..., :3 * P].unflatten(-1, (height, width, 3)),
+           "depth_mm": records[..., lay["off_depth"]:lay["off_depth"] + 2 * P].view(torch.int16).unflatten(-1, (height, width))}
+    if J:
+        out["mask_bits"] = records[..., lay["off_masks"]:lay["off_masks"] + J * P].unflatten(-1, (height, width, J))
+    assert out["rgb"].shape[:-3] == lead
+    return out
+
+
 def unpack_mask_bits(mask_bits: torch.Tensor, k: int) -> torch.Tensor:
     """Inverse of pack_frames' mask packing: uint8 [B,H,W,ceil(k/8)] -> uint8 [B,k,H,W] (any device; host writers)."""
     planes = [(mask_bits[..., m // 8] >> (m % 8)) & 1 for m in range(k)]

@@ -27,6 +27,7 @@ class ViewSpec:
     viewmatrix: torch.Tensor
     projmatrix: torch.Tensor
     campos: torch.Tensor
+    depth_mode: int = 0          # PgrDepthMode: 0 = sum T alpha z (default), 1 = normalised by 1 - T_final
 
 
 class _Workspace:
@@ -122,7 +123,8 @@ class PendingBatch:
 def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, colors_precomp=None, scales=None,
                   rotations=None, cov3D_precomp=None, sh_degree=0, scale_modifier=1.0, want_radii=True,
                   want_aux=False, stage_ms: Optional[list] = None, outputs: Optional[list] = None,
-                  async_slot=None, semantic: Optional[dict] = None, posed: Optional[dict] = None, tie_index=None):
+                  async_slot=None, semantic: Optional[dict] = None, posed: Optional[dict] = None, tie_index=None,
+                  tie_inv=None, layers: Optional[dict] = None):
     """Renders ``len(views)`` views of one scene.  Returns a list of dicts with keys
     color[3,H,W], depth[1,H,W], radii[N] (or None), and final_T / n_contrib when ``want_aux``.
 
@@ -133,7 +135,14 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
     PendingBatch; the slot names the workspace / pinned scratch to use (one batch in flight per slot).
     ``semantic``: dict(object_id int32[N], colors float32[K,3], n_env, k) -> the fused objects-only semantic
     render is written to r["sem_color"] (and r["sem_depth"]) of every view (pgr_forward_frames_async).
-    ``tie_index``: int32[N] permutation -- exact depth ties are broken by it instead of the position (PgrScene.tie_index).
+    ``semantic`` may also carry ``mask_colors`` float32[K,3] (+ ``mask_threshold``): every output dict with a ``sem_masks``
+    uint8[K,H,W] tensor then receives the K colour-distance masks of the semantic image from the compositor's epilogue
+    (bit for bit what color_masks() computes from ``sem_color``), and ``object_id_u8`` (scene_prepare()).
+    ``tie_index``: int32[N] permutation -- exact depth ties are broken by it instead of the position (PgrScene.tie_index);
+    ``tie_inv``: its inverse from scene_prepare() (otherwise rebuilt per call).
+    ``layers``: dict(layer_id int32[N], n_layers, mask_colors float32[n_layers,3], mask_threshold) -> LAYERED call
+    (pgr_forward_layers_async, asynchronous only): Gaussian i is composited into image layer_id[i] alone and every
+    output dict's ``sem_masks`` uint8[n_layers,H,W] receives the layers' masks (silhouettes); no colour image.
     ``posed``: dict(object_id int32[N], poses float32[len(views), K, 20]) -> dynamic scene: view i places object k by
     poses[i, k-1] inside the preprocess (pgr_forward_posed_async; pegasus_amd.compose.pose_table builds the rows).
     """
@@ -158,7 +167,7 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
         n=n, means3d=_ptr(means3D), opacities=_ptr(opacities), scales=_ptr(scales), rotations=_ptr(rotations),
         cov3d_precomp=_ptr(cov3D_precomp), shs=_ptr(shs), colors_precomp=_ptr(colors_precomp),
         sh_degree=int(sh_degree), sh_stride=int(shs.shape[1]) if shs is not None else 0,
-        scale_modifier=float(scale_modifier), tie_index=_ptr(tie_index))
+        scale_modifier=float(scale_modifier), tie_index=_ptr(tie_index), tie_inv=_ptr(tie_inv) if tie_index is not None else None)
 
     cams = (_lib.PgrCamera * nv)()
     outs = (_lib.PgrOutputs * nv)()
@@ -170,7 +179,8 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
         bg, vm, pm, cp = (dev_f32(t, device) for t in (v.bg, v.viewmatrix, v.projmatrix, v.campos))
         keep.append((bg, vm, pm, cp))
         cams[i] = _lib.PgrCamera(image_width=W, image_height=H, tanfovx=float(v.tanfovx), tanfovy=float(v.tanfovy),
-                                 viewmatrix=_ptr(vm), projmatrix=_ptr(pm), campos=_ptr(cp), bg=_ptr(bg))
+                                 viewmatrix=_ptr(vm), projmatrix=_ptr(pm), campos=_ptr(cp), bg=_ptr(bg),
+                                 depth_mode=int(getattr(v, "depth_mode", 0)))
         if outputs is not None:
             r = outputs[i]
         else:
@@ -183,10 +193,11 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
             if semantic is not None:
                 r["sem_color"] = torch.empty((3, H, W), dtype=torch.float32, device=device)
                 r["sem_depth"] = torch.empty((1, H, W), dtype=torch.float32, device=device)
-        outs[i] = _lib.PgrOutputs(color=_ptr(r["color"]), depth=_ptr(r["depth"]), radii=_ptr(r.get("radii")),
+        outs[i] = _lib.PgrOutputs(color=_ptr(r.get("color")), depth=_ptr(r.get("depth")), radii=_ptr(r.get("radii")),
                                   final_T=_ptr(r.get("final_T")), n_contrib=_ptr(r.get("n_contrib")),
                                   sem_color=_ptr(r.get("sem_color")) if semantic is not None else None,
-                                  sem_depth=_ptr(r.get("sem_depth")) if semantic is not None else None)
+                                  sem_depth=_ptr(r.get("sem_depth")) if semantic is not None else None,
+                                  sem_masks=_ptr(r.get("sem_masks")) if (semantic is not None or layers is not None) else None)
         results.append(r)
 
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
@@ -204,13 +215,25 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
                                             k_objects=int(poses.shape[1]))
     if semantic is not None:
         sem_struct = _lib.PgrSemantic(object_id=_ptr(semantic["object_id"]), colors=_ptr(semantic["colors"]),
-                                      n_env=int(semantic["n_env"]), k_objects=int(semantic["k"]))
+                                      n_env=int(semantic["n_env"]), k_objects=int(semantic["k"]),
+                                      object_id_u8=_ptr(semantic.get("object_id_u8")),
+                                      mask_colors=_ptr(semantic.get("mask_colors")),
+                                      mask_threshold=float(semantic.get("mask_threshold", 0.1)))
+    layers_struct = None
+    if layers is not None:
+        if async_slot is None or semantic is not None or stage_ms is not None:
+            raise ValueError("a layered call is asynchronous (async_slot) and takes no semantic descriptor")
+        layers_struct = _lib.PgrLayers(layer_id=_ptr(layers["layer_id"]), n_layers=int(layers["n_layers"]),
+                                       mask_colors=_ptr(layers["mask_colors"]),
+                                       mask_threshold=float(layers.get("mask_threshold", 0.1)))
+        key = (device, n, W, H, "layers", int(layers["n_layers"]))
+        max_inst = _WS.capacity_hint.get(key, max(1 << 20, 6 * n))
     if semantic is not None or posed is not None:
         if async_slot is None and stage_ms is None:      # synchronous fused call: enqueue asynchronously, wait, retry on overflow
             kw = dict(shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
                       cov3D_precomp=cov3D_precomp, sh_degree=sh_degree, scale_modifier=scale_modifier,
                       want_radii=want_radii, want_aux=want_aux, outputs=results, semantic=semantic, posed=posed,
-                      tie_index=tie_index)
+                      tie_index=tie_index, tie_inv=tie_inv)
             for _attempt in range(3):
                 pb = forward_views(means3D, opacities, views, async_slot="sync-fused", **kw)
                 pb._redo = None
@@ -228,22 +251,37 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
             raise RuntimeError("instance capacity did not converge")
     if async_slot is not None:
         with torch.cuda.device(device):
-            nbytes = L.pgr_batch_workspace_bytes(n, W, H, max_inst, nv)
+            if layers_struct is not None:
+                nbytes = L.pgr_layers_workspace_bytes(n, W, H, max_inst, nv, layers_struct.n_layers)
+            else:
+                nbytes = L.pgr_batch_workspace_bytes(n, W, H, max_inst, nv)
             ws = _WS.get(device, nbytes, slot=("async", async_slot))
             sb = L.pgr_host_scratch_bytes(nv)
             scratch = _WS.pinned(async_slot, sb)
-            _lib.check(L.pgr_forward_posed_async(C.byref(scene), C.byref(sem_struct) if sem_struct else None,
-                                                 C.byref(posed_struct) if posed_struct else None, nv,
-                                                 cams, outs, C.c_void_p(ws.data_ptr()), ws.numel(), max_inst,
-                                                 C.c_void_p(scratch.data_ptr()), scratch.numel(), stream),
-                       "pgr_forward_posed_async")
+            if layers_struct is not None:
+                _lib.check(L.pgr_forward_layers_async(C.byref(scene), C.byref(layers_struct),
+                                                      C.byref(posed_struct) if posed_struct else None, nv,
+                                                      cams, outs, C.c_void_p(ws.data_ptr()), ws.numel(), max_inst,
+                                                      C.c_void_p(scratch.data_ptr()), scratch.numel(), stream),
+                           "pgr_forward_layers_async")
+            else:
+                _lib.check(L.pgr_forward_posed_async(C.byref(scene), C.byref(sem_struct) if sem_struct else None,
+                                                     C.byref(posed_struct) if posed_struct else None, nv,
+                                                     cams, outs, C.c_void_p(ws.data_ptr()), ws.numel(), max_inst,
+                                                     C.c_void_p(scratch.data_ptr()), scratch.numel(), stream),
+                           "pgr_forward_posed_async")
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(device))
         kw = dict(shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
                   cov3D_precomp=cov3D_precomp, sh_degree=sh_degree, scale_modifier=scale_modifier,
                   want_radii=want_radii, want_aux=want_aux, outputs=results, semantic=semantic, posed=posed,
-                      tie_index=tie_index)
-        redo = lambda: forward_views(means3D, opacities, views, **kw)
+                  tie_index=tie_index, tie_inv=tie_inv)
+        if layers is not None:          # a layered call is asynchronous only: the retry after an overflow is one too
+            def redo():
+                pb2 = forward_views(means3D, opacities, views, async_slot=async_slot, layers=layers, **kw)
+                return pb2.wait()
+        else:
+            redo = lambda: forward_views(means3D, opacities, views, **kw)
         pb = PendingBatch(results, ev, scratch, nv, key, max_inst, redo)
         pb._keep = (keep, ws, cams, outs, scene)
         return pb
@@ -324,3 +362,35 @@ def block_visibility(means3D, views: Sequence[ViewSpec], *, scales=None, rotatio
         torch.cuda.current_stream(device).synchronize()
     bits = (out.unsqueeze(2) >> torch.arange(32, device=device, dtype=torch.int32)) & 1
     return bits.reshape(groups, words * 32)[:, :nv].bool()
+
+
+def scene_prepare(n: int, tie_index: Optional[torch.Tensor] = None, semantic: Optional[dict] = None) -> dict:
+    """Per-SCENE constants of the batch calls, computed once (pgr_scene_prepare): ``tie_inv`` (inverse permutation of
+    ``tie_index``) and ``object_id_u8`` (the object Gaussians' ids as bytes).  Returns a dict with those two device
+    tensors (None where the input is absent) and the cache tensor that owns their memory ("cache": keep it alive)."""
+    L = _lib.lib()
+    ref = tie_index if tie_index is not None else (semantic["object_id"] if semantic is not None else None)
+    if ref is None or n == 0:
+        return dict(tie_inv=None, object_id_u8=None, cache=None)
+    device = ref.device
+    if device.type != "cuda":
+        raise RuntimeError("scene_prepare needs tensors on a HIP device")
+    scene = _lib.PgrScene(n=int(n), tie_index=_ptr(tie_index))
+    sem = None
+    if semantic is not None:
+        sem = _lib.PgrSemantic(object_id=_ptr(semantic["object_id"]), colors=_ptr(semantic["colors"]),
+                               n_env=int(semantic["n_env"]), k_objects=int(semantic["k"]))
+    with torch.cuda.device(device):
+        cache = torch.empty(int(L.pgr_scene_cache_bytes(int(n))) + 256, dtype=torch.uint8, device=device)
+        p_inv, p_u8 = C.c_void_p(), C.c_void_p()
+        _lib.check(L.pgr_scene_prepare(C.byref(scene), C.byref(sem) if sem is not None else None,
+                                       C.c_void_p(cache.data_ptr()), cache.numel(), C.byref(p_inv), C.byref(p_u8),
+                                       C.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "pgr_scene_prepare")
+
+    def view(ptr, nbytes, dtype):
+        if not ptr.value:
+            return None
+        off = ptr.value - cache.data_ptr()
+        return cache[off:off + nbytes].view(dtype)
+    n_obj = int(n) - int(semantic["n_env"]) if semantic is not None else 0
+    return dict(tie_inv=view(p_inv, 4 * int(n), torch.int32), object_id_u8=view(p_u8, n_obj, torch.uint8), cache=cache)

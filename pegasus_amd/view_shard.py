@@ -2,9 +2,16 @@
 finished frames gathered to one rank.
 
 Views are independent given the merged scene, so there is NO collective on the data path of a frame; the
-only communication is the final gather of finished frames, done with ``torch.distributed.gather`` (on the
-"nccl" backend = RCCL: grouped send/recv, so the 7 peers of an 8-GPU node stream to the root over their
-own xGMI links concurrently).  Backend-agnostic: the same code runs on gloo in the CPU tests.
+only communication is the gather of finished frames, done with ``torch.distributed.gather`` (on the
+"nccl" backend = RCCL: grouped send/recv straight into the root's receive tensors, so the 7 peers of an
+8-GPU node stream to the root over their own xGMI links concurrently).  Backend-agnostic: the same code runs
+on gloo in the CPU tests.
+
+Shape of the exchange (round 4): ONE collective per batch, carrying ONE uint8 record per frame (what
+``pgr_pack_records`` writes: uint8 RGB, uint16 depth millimetres, the K masks as bit planes), into buffers that exist
+before the first batch.  With view v -> rank v mod world and equal-sized chunks the root's rank-major receive buffer
+``recv[r, i]`` IS the global order under a transposed view -- frame g = i * world + r -- so nothing is reordered, copied
+or allocated on the root per batch (``FrameGather``).
 """
 from __future__ import annotations
 
@@ -23,54 +30,129 @@ def max_local(n_items: int, world: int) -> int:
     return (n_items + world - 1) // world
 
 
+def global_id(rank: int, i: int, world: int) -> int:
+    """The (rank, i) -> global frame rule of a gathered batch: local frame i of rank r is global frame i * world + r."""
+    return i * world + rank
+
+
+class FrameGather:
+    """Per-batch gather of fixed-size frame records to ``dst`` with everything preallocated.
+
+    ``send_buffer(slot)`` is this rank's uint8 [cap, record_bytes] staging tensor (the pack kernel writes straight into
+    it); ``start(slot)`` issues the one collective of the batch; ``finish(slot)`` completes it and returns, on ``dst``, the
+    rank-major receive tensor [world, cap, record_bytes] (elsewhere None).  ``depth`` slots: one gather in flight beside
+    the batch being packed.  ``global_view(slot)`` is the same memory as [cap, world, record_bytes]: row-major order of
+    its first two axes is the global frame order; ranks that owned fewer than ``cap`` frames of a batch leave their tail
+    rows undefined.
+    """
+
+    def __init__(self, cap: int, record_bytes: int, device, dst: int = 0, group=None, depth: int = 2,
+                 pin_memory: bool = False):
+        self.group, self.dst = group, dst
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.cap, self.record_bytes, self.depth = int(cap), int(record_bytes), int(depth)
+        kw = dict(dtype=torch.uint8, device=device)
+        if pin_memory and torch.device(device).type == "cpu":
+            kw["pin_memory"] = True
+        self.send = [torch.empty((self.cap, self.record_bytes), **kw) for _ in range(self.depth)]
+        self.recv = ([torch.empty((self.world, self.cap, self.record_bytes), **kw) for _ in range(self.depth)]
+                     if self.rank == dst else None)
+        # the per-rank receive views handed to the collective: made once (unbind returns views of recv)
+        self._recv_lists = [list(r.unbind(0)) for r in self.recv] if self.recv is not None else None
+        self._work = [None] * self.depth
+        self.batches = 0
+
+    @property
+    def bytes_per_rank_and_batch(self) -> int:
+        return self.cap * self.record_bytes
+
+    def send_buffer(self, slot: int) -> torch.Tensor:
+        return self.send[slot % self.depth]
+
+    def start(self, slot: int):
+        s = slot % self.depth
+        if self._work[s] is not None:
+            raise RuntimeError("FrameGather: slot still in flight (finish() it first)")
+        self._work[s] = dist.gather(self.send[s], self._recv_lists[s] if self._recv_lists is not None else None,
+                                    dst=self.dst, group=self.group, async_op=True)
+        self.batches += 1
+
+    def finish(self, slot: int) -> Optional[torch.Tensor]:
+        s = slot % self.depth
+        w = self._work[s]
+        if w is not None:
+            w.wait()
+            self._work[s] = None
+        return self.recv[s] if self.recv is not None else None
+
+    def finish_all(self):
+        for s in range(self.depth):
+            self.finish(s)
+
+    def global_view(self, slot: int) -> Optional[torch.Tensor]:
+        """[cap, world, record_bytes] view of the receive buffer: [i, r] = global frame i * world + r (no copy)."""
+        return None if self.recv is None else self.recv[slot % self.depth].transpose(0, 1)
+
+
+def _as_bytes(t: torch.Tensor) -> torch.Tensor:
+    """[n, ...] tensor -> uint8 [n, bytes per item] view (neither RCCL nor gloo carries 16-bit integers; everything
+    travels as bytes and is viewed back on arrival)."""
+    t = t.contiguous()
+    return t.view(torch.uint8).reshape(t.shape[0], -1) if t.shape[0] else t.new_zeros((0, _item_bytes(t)), dtype=torch.uint8)
+
+
+def _item_bytes(t: torch.Tensor) -> int:
+    n = 1
+    for d in t.shape[1:]:
+        n *= int(d)
+    return n * t.element_size()
+
+
 def gather_frames(local: Dict[str, torch.Tensor], n_items: int, dst: int = 0, group=None,
                   async_op: bool = False):
-    """``local[k]`` holds this rank's frames [n_local, ...] in the order of shard_indices().  On ``dst``
-    returns {k: tensor [n_items, ...]} in GLOBAL order, elsewhere None.  With async_op returns
-    (finish, works): call finish() after waiting to assemble."""
+    """Generic form for callers without preallocated records: ``local[k]`` holds this rank's frames [n_local, ...] in the
+    order of shard_indices().  All tensors of the dict travel as ONE uint8 record per frame in ONE gather.  On ``dst``
+    returns {k: tensor [n_items, ...]} in GLOBAL order (one strided copy per tensor kind out of the rank-major receive
+    buffer), elsewhere None.  With async_op returns (finish, works): call finish() after waiting."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     cap = max_local(n_items, world)
-    works, staging, wire_dtype = [], {}, {}
-    for k, t in local.items():
-        # neither RCCL/NCCL nor gloo carry 16-bit integers (the uint16-millimetre depth images travel as int16 storage):
-        # such tensors go over the wire as bytes and are viewed back on arrival
-        wire_dtype[k] = t.dtype
-        if t.dtype in (torch.int16, getattr(torch, "uint16", torch.int16)):
-            t = t.contiguous().view(torch.uint8)
-        pad = t
-        if t.shape[0] < cap:   # ranks with one view fewer pad so every rank contributes equal-sized chunks
-            pad = torch.cat([t, t.new_zeros((cap - t.shape[0],) + tuple(t.shape[1:]))], 0)
-        pad = pad.contiguous()
-        bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-        w = dist.gather(pad, bufs, dst=dst, group=group, async_op=async_op)
-        staging[k] = bufs
-        if async_op:
-            works.append(w)
+    keys = list(local.keys())
+    meta = {k: (tuple(local[k].shape[1:]), local[k].dtype, _item_bytes(local[k])) for k in keys}
+    rec_bytes = sum(m[2] for m in meta.values())
+    first = local[keys[0]]
+    record = torch.zeros((cap, rec_bytes), dtype=torch.uint8, device=first.device)
+    off = 0
+    for k in keys:
+        b = _as_bytes(local[k])
+        record[: b.shape[0], off:off + meta[k][2]] = b
+        off += meta[k][2]
+    recv = torch.empty((world, cap, rec_bytes), dtype=torch.uint8, device=first.device) if rank == dst else None
+    w = dist.gather(record, list(recv.unbind(0)) if recv is not None else None, dst=dst, group=group, async_op=async_op)
 
     def finish():
         if rank != dst:
             return None
-        out = {}
-        for k, bufs in staging.items():
-            full = torch.empty((n_items,) + tuple(bufs[0].shape[1:]), dtype=bufs[0].dtype, device=bufs[0].device)
-            for r in range(world):
-                idx = shard_indices(n_items, r, world)
-                if idx:
-                    full[idx] = bufs[r][: len(idx)]
-            out[k] = full if full.dtype == wire_dtype[k] else full.view(wire_dtype[k])
+        # [cap, world, bytes]: row-major order of the first two axes is the global order; one strided copy per kind
+        glob = recv.transpose(0, 1)
+        out, off = {}, 0
+        for k in keys:
+            shp, dt, nb = meta[k]
+            flat = glob[:, :, off:off + nb].reshape(cap * world, nb)[:n_items].contiguous()
+            out[k] = flat.view(dt).reshape((n_items,) + shp)
+            off += nb
         return out
 
     if async_op:
-        return finish, works
+        return finish, [w]
     return finish()
 
 
 def render_sharded(n_views: int, render_batch: Callable[[List[int]], Dict[str, torch.Tensor]], batch: int,
                    gather: bool = True, dst: int = 0, group=None) -> Optional[Dict[str, torch.Tensor]]:
     """Every rank renders its shard of ``n_views`` in batches of ``batch`` global view indices handed to
-    ``render_batch`` (which returns a dict of [len(indices), ...] tensors); the gather of batch b is issued
-    asynchronously and overlaps the rendering of batch b+1.  Returns the assembled frames on ``dst``."""
+    ``render_batch`` (which returns a dict of [len(indices), ...] tensors); returns the assembled frames on ``dst``."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     mine = shard_indices(n_views, rank, world)

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_status_strings():
     from pegasus_amd import _lib
     lib = _lib.lib()
-    assert lib.pgr_abi_version() == 1
+    assert lib.pgr_abi_version() == 2
     assert b"gfx950" in lib.pgr_version()
     assert lib.pgr_status_string(0) == b"ok"
     assert lib.pgr_status_string(-3) == b"instance buffer overflow"
@@ -45,6 +45,19 @@ def test_workspace_sizes_are_host_only():
     assert lib.pgr_batch_workspace_bytes(100_000, 800, 800, 1 << 20, 8) > 7 * one
     assert lib.pgr_workspace_bytes(-1, 800, 800, 10) == 0
     assert lib.pgr_workspace_bytes(10, 0, 800, 10) == 0
+
+
+def test_frame_record_layout_is_host_only_and_aligned():
+    from pegasus_amd import _lib, masks as M
+    lay = M.record_layout(800, 800, 8)
+    assert lay == dict(off_rgb=0, off_depth=1_920_000, off_masks=3_200_000, bytes=3_840_000)      # 3.84 MB
+    odd = M.record_layout(5, 7, 11)
+    assert all(v % 16 == 0 for v in odd.values()) and odd["off_depth"] >= 105 and odd["off_masks"] >= odd["off_depth"] + 70
+    assert odd["bytes"] >= odd["off_masks"] + 2 * 35
+    assert _lib.lib().pgr_frame_record_layout(0, 5, 1, None) == _lib.PGR_ERR_INVALID_ARGUMENT
+    assert _lib.lib().pgr_scene_cache_bytes(1000) >= 5000 and _lib.lib().pgr_scene_cache_bytes(-1) == 0
+    assert _lib.lib().pgr_layers_workspace_bytes(1000, 64, 64, 1 << 16, 2, 8) > _lib.lib().pgr_batch_workspace_bytes(1000, 64, 64, 1 << 16, 2)
+    assert _lib.lib().pgr_layers_workspace_bytes(1000, 64, 64, 1 << 16, 2, 0) == 0
 
 
 def test_invalid_arguments_are_rejected_before_any_launch():

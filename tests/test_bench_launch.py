@@ -39,10 +39,33 @@ def test_gpus_2_launches_two_ranks_by_itself_and_gathers():
     assert d["world_size"] == 2 and d["launcher"].startswith("self")
     assert [x["rank"] for x in d["devices"]] == [0, 1]
     g = line["config"]["gather"]
-    assert g["check"] == "ok" and g["bytes_per_rank_and_batch"] == 4 * 4 * 5 * (3 + 2 + 1)
+    from pegasus_amd import masks as M
+    assert g["check"] == "ok" and g["bytes_per_rank_and_batch"] == 4 * M.record_layout(4, 5, 8)["bytes"]
     assert g["views_per_s_with_gather"] == line["value"] and g["views_per_s_render_only"] > 0
     assert line["value"] > 0 and abs(line["ms_per_step"] * 3 * line["value"] / 1e3 - 3 * 4 * 2) < 0.05
     assert line.get("stub") is True and "INVALID" in line["metric"]
+    # measurement protocol: R repeats of the K steps, the median one is the value; every rank's own time is in the line
+    assert line["repeats"] == 5 and len(line["ms_per_step_all"]) == 5
+    assert line["value_min"] <= line["value"] <= line["value_max"]
+    assert sorted(line["ms_per_step_all"])[2] == line["ms_per_step"]
+    pr = line["per_rank_s"]
+    assert len(pr["all"]) == 2 and pr["min"] <= pr["rank0"] <= pr["max"] + 1e-9 and pr["max"] * 1e3 <= line["ms_per_step"] * 3 + 1e-3
+    assert g["rank0_gather_host_ms_per_step"] >= 0
+
+
+import pytest as _pytest
+
+
+@_pytest.mark.parametrize("world", [4, 8])
+def test_stub_gather_at_world_4_and_8(world):
+    """The N-rank protocol at the node's real sizes (gloo, stub frame source): one gather per batch into the rank-major
+    buffer, content checked through the (rank, i) -> global id rule."""
+    p, line = _run([sys.executable, "bench.py", "--gpus", str(world), "--stub-renderer", "--steps", "2", "--warmup", "1",
+                    "--batch", "3", "--repeats", "2"], timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line["n_gpus"] == world and line["config"]["gather"]["check"] == "ok"
+    assert len(line["per_rank_s"]["all"]) == world and line["repeats"] == 2
+    assert abs(line["ms_per_step"] * 2 * line["value"] / 1e3 - 2 * 3 * world) < 0.05
 
 
 def test_outer_torchrun_and_no_gather():

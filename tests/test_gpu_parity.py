@@ -622,3 +622,154 @@ def test_hip_agrees_with_independent_dense_float64_renderer(gpu_device):
         dc, dd = np.abs(g["color"] - c64), np.abs(g["out_depth"][0] - d64)
         assert np.quantile(dc, 0.999) < 5e-5 and np.quantile(dd, 0.999) < 5e-5, (seed, dc.max(), dd.max())
         assert (dc > 1e-3).mean() < 1e-3 and (g["radii"] > 0).sum() > 500
+
+
+def test_layered_silhouettes_equal_per_object_passes(gpu_device):
+    """render_silhouettes (ONE layered pass: per-(tile, object) lists, masks from the compositor's epilogue) is bit-equal to
+    K single-object passes + mask launches (round 2's form) -- static and posed, image sizes that are and are not a
+    multiple of the tile size, a background close to one of the semantic colours, objects that straddle binning chunks."""
+    import torch
+    from pegasus_amd import compose, frames as F
+    for (w, h, bg, scale) in ((320, 240, (0.0, 0.0, 0.0), 0.03), (333, 250, (0.0, 0.0, 0.0), 0.05)):
+        cloud, views = scenes.scene_c3(scale=scale, n_views=4, width=w, height=h)
+        act = cloud.activated()
+        fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"], cloud.object_id,
+                             sh_degree=3, device=gpu_device, bg=bg)
+        specs = [fr.view_spec(v) for v in views]
+        a = fr.render_silhouettes(specs).clone()
+        b = fr.render_silhouettes_per_object(specs).clone()
+        torch.cuda.synchronize()
+        assert a.shape == b.shape == (4, fr.K, h, w) and torch.equal(a, b)
+        assert int(a.sum()) > 0 and all(int(a[:, k].sum()) > 0 for k in range(fr.K))
+        # posed: every object moved per view
+        rng = np.random.default_rng(5)
+        oid = cloud.object_id
+        centers = [act["means3d"][oid == k].astype(np.float64).mean(0) for k in range(1, fr.K + 1)]
+        from scipy.spatial.transform import Rotation as Rot
+
+        def rigid():
+            T = np.eye(4)
+            T[:3, :3] = Rot.from_rotvec(rng.normal(0, 0.3, 3)).as_matrix()
+            T[:3, 3] = rng.normal(0, 0.03, 3)
+            return T
+        poses = np.stack([compose.pose_table([(rigid(), centers[k]) for k in range(fr.K)]) for _ in views])
+        ap = fr.render_silhouettes(specs, poses=poses).clone()
+        bp = fr.render_silhouettes_per_object(specs, poses=poses).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(ap, bp) and not torch.equal(ap, a)
+    # a background that IS object 3's colour: empty pixels of layer 3 are inside its mask, in both forms
+    cloud, views = scenes.scene_c3(scale=0.03, n_views=2, width=160, height=128)
+    act = cloud.activated()
+    from pegasus_amd import masks as M
+    c3 = tuple(float(x) for x in M.generate_colors(8)[2])
+    fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"], cloud.object_id,
+                         sh_degree=3, device=gpu_device, bg=c3)
+    specs = [fr.view_spec(v) for v in views]
+    a, b = fr.render_silhouettes(specs).clone(), fr.render_silhouettes_per_object(specs).clone()
+    assert torch.equal(a, b) and float(a[:, 2].float().mean()) > 0.5 and float(a[:, 0].float().mean()) < 0.5
+
+
+def test_layered_silhouettes_after_an_instance_overflow(gpu_device):
+    import torch
+    from pegasus_amd import frames as F, rasterizer
+    cloud, views = scenes.scene_c3(scale=0.03, n_views=3, width=320, height=240)
+    act = cloud.activated()
+    fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"], cloud.object_id,
+                         sh_degree=3, device=gpu_device)
+    specs = [fr.view_spec(v) for v in views]
+    ref = fr.render_silhouettes(specs).clone()
+    for key in list(rasterizer._WS.capacity_hint):
+        rasterizer._WS.capacity_hint[key] = 1500
+    for kk in [k for k in rasterizer._WS.buf if isinstance(k, tuple) and len(k) == 2 and isinstance(k[1], tuple)]:
+        rasterizer._WS.buf.pop(kk)
+    again = fr.render_silhouettes(specs).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(ref, again)
+
+
+def test_depth_mode_switch_matches_oracle(oracle, gpu_device):
+    """PgrDepthMode (SURVEY.md 8a "keep it a one-line switch"): 0 = sum T alpha z (default), 1 = that sum over 1 - T_final.
+    Both against the oracle's same switch; colour, final_T and n_contrib do not depend on it; the semantic depth follows."""
+    import torch
+    from pegasus_amd import frames as F, rasterizer as R
+    cloud, views = scenes.scene_c3(scale=0.03, n_views=2, width=200, height=150)
+    act = cloud.activated()
+    fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"], cloud.object_id,
+                         sh_degree=3, device=gpu_device, bg=(0.2, 0.1, 0.0), spatial_order=False)
+    res = {}
+    for mode in (0, 1):
+        specs = [fr.view_spec(v, depth_mode=mode) for v in views]
+        res[mode] = R.forward_views(fr.means3d, fr.opacities, specs, shs=fr.shs, scales=fr.scales, rotations=fr.rotations,
+                                    sh_degree=3, want_aux=True, semantic=fr.semantic)
+        torch.cuda.synchronize()
+        for i, v in enumerate(views):
+            o = oracle.forward(**act, sh_degree=3, **v.raster_kwargs((0.2, 0.1, 0.0)), num_threads=8, cull_mode=1, depth_mode=mode)
+            ok = ~o["ambig"].astype(bool)
+            g = res[mode][i]
+            assert np.abs(g["depth"].cpu().numpy()[0] - o["out_depth"][0])[ok].max() <= 1e-4
+            assert np.abs(g["color"].cpu().numpy() - o["color"])[:, ok].max() <= 1e-4
+            np.testing.assert_array_equal(g["n_contrib"].cpu().numpy().astype(np.uint32)[ok], o["n_contrib"][ok])
+    for i in range(len(views)):
+        a, b = res[0][i], res[1][i]
+        assert torch.equal(a["color"], b["color"]) and torch.equal(a["final_T"], b["final_T"]) and torch.equal(a["sem_color"], b["sem_color"])
+        T = a["final_T"]
+        want = torch.where(1.0 - T > 0, a["depth"][0] / (1.0 - T), torch.zeros_like(T))
+        assert torch.equal(b["depth"][0], want)                       # the normalised image IS the default one over 1 - T
+        assert float((b["depth"][0] - a["depth"][0]).abs().max()) > 1e-3
+        assert not torch.equal(a["sem_depth"], b["sem_depth"])
+
+
+def test_pack_records_is_pack_frames_in_one_buffer(gpu_device):
+    """pgr_pack_records: the three images of pgr_pack_frames back to back in ONE record per frame (what one gather / one
+    writer task moves), into a caller-provided buffer with a larger row stride; record_views() slices it back, zero-copy."""
+    import torch
+    from pegasus_amd import masks as M
+    rng = np.random.default_rng(12)
+    for (B, K, H, W) in ((3, 8, 37, 53), (2, 11, 16, 16), (1, 1, 5, 7), (2, 0, 9, 9)):
+        t = lambda a: torch.from_numpy(a).to(gpu_device)
+        color = t(rng.uniform(-0.2, 1.4, size=(B, 3, H, W)).astype(np.float32))
+        depth = t(rng.uniform(0, 70, size=(B, 1, H, W)).astype(np.float32))
+        masks = t((rng.uniform(size=(B, K, H, W)) < 0.3).astype(np.uint8)) if K else None
+        want = M.pack_frames(color, depth, masks)
+        lay = M.record_layout(H, W, K)
+        rec = M.pack_records(color, depth, masks)
+        assert rec.shape == (B, lay["bytes"]) and rec.dtype == torch.uint8
+        big = torch.full((B + 1, lay["bytes"] + 32), 7, dtype=torch.uint8, device=gpu_device)
+        assert M.pack_records(color, depth, masks, out=big) is big
+        torch.cuda.synchronize()
+        for r in (rec, big[:B]):
+            v = M.record_views(r, H, W, K)
+            assert torch.equal(v["rgb"], want["rgb"]) and torch.equal(v["depth_mm"], want["depth_mm"])
+            if K:
+                assert torch.equal(v["mask_bits"], want["mask_bits"])
+            assert v["rgb"].data_ptr() == r.data_ptr()                    # views, not copies
+        assert int((big[B] != 7).sum()) == 0 and int((big[:, lay["bytes"]:] != 7).sum()) == 0   # nothing written outside
+        # a rank-major gathered buffer [world, B, bytes] slices the same way
+        stacked = torch.stack([rec, rec])
+        assert torch.equal(M.record_views(stacked, H, W, K)["depth_mm"][1], want["depth_mm"])
+
+
+def test_scene_prepare_constants_match_the_per_call_path(gpu_device):
+    """pgr_scene_prepare: the inverse tie permutation and the object-id byte table, computed once, give the frames the
+    per-call path gives (which rebuilds them in the workspace every batch)."""
+    import torch
+    from pegasus_amd import frames as F, rasterizer as R
+    cloud, views = scenes.scene_c3(scale=0.03, n_views=3, width=256, height=192)
+    act = cloud.activated()
+    fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"], cloud.object_id,
+                         sh_degree=3, device=gpu_device)
+    assert fr.tie_inv is not None and fr.semantic["object_id_u8"] is not None
+    inv = fr.tie_inv.long()
+    assert torch.equal(inv[fr.tie_index.long()], torch.arange(fr.n, device=gpu_device))
+    assert torch.equal(fr.semantic["object_id_u8"].int(), fr.semantic["object_id"][fr.n_env:])
+    specs = [fr.view_spec(v) for v in views]
+    a = {k: v.clone() for k, v in fr.render_frames(specs).items()}
+    sem = {k: v for k, v in fr.semantic.items() if k != "object_id_u8"}
+    f = fr.alloc_frames(3, 192, 256)
+    outs = [dict(color=f["color"][i], depth=f["depth"][i], radii=None, sem_color=f["seg"][i], sem_depth=f["seg_depth"][i],
+                 sem_masks=f["masks"][i]) for i in range(3)]
+    R.forward_views(fr.means3d, fr.opacities, specs, shs=fr.shs, scales=fr.scales, rotations=fr.rotations, sh_degree=3,
+                    want_radii=False, outputs=outs, semantic=sem, tie_index=fr.tie_index)       # no tie_inv, no byte table
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], f[k]), k

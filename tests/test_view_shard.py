@@ -50,19 +50,69 @@ def _worker(rank, world, port, n_views, batch, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_views,batch", [(7, 2), (8, 4), (1, 3)])
-def test_two_rank_shard_and_gather(n_views, batch):
+def _spawn(target, world, *args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_views, batch, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port, *args, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in procs]
+    results = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(results) == [("ok", 0), ("ok", 1)]
+    assert sorted(results) == [("ok", r) for r in range(world)]
+
+
+@pytest.mark.parametrize("world,n_views,batch", [(2, 7, 2), (2, 8, 4), (2, 1, 3), (4, 10, 2), (4, 3, 2), (8, 21, 3), (8, 64, 4)])
+def test_shard_and_gather(world, n_views, batch):
+    """world 2 / 4 / 8, n_views divisible by the world size and not, fewer views than ranks."""
+    _spawn(_worker, world, n_views, batch)
+
+
+def _frame_gather_worker(rank, world, port, q):
+    """FrameGather: preallocated send / receive buffers, one gather per batch, two slots in flight, and the
+    (rank, i) -> global id rule g = i * world + r of the rank-major receive buffer."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pegasus_amd import view_shard as vs
+        cap, rec = 3, 48
+        fg = vs.FrameGather(cap, rec, "cpu", dst=0, depth=2)
+        ptrs = [t.data_ptr() for t in fg.send] + ([t.data_ptr() for t in fg.recv] if rank == 0 else [])
+        ok = True
+
+        def record(g):                                   # a frame's record is a function of its global id
+            return ((torch.arange(rec, dtype=torch.int64) * 7 + g * 13) % 251).to(torch.uint8)
+        expect = {}
+        for step in range(5):
+            slot = step & 1
+            got = fg.finish(slot)                        # the batch that used this slot two steps ago
+            if step >= 2 and rank == 0:
+                glob = fg.global_view(slot)              # [cap, world, rec]: [i, r] = global frame i * world + r
+                want = expect.pop(step - 2)
+                ok = ok and got is fg.recv[slot] and torch.equal(glob.reshape(cap * world, rec), want)
+            buf = fg.send_buffer(slot)
+            for i in range(cap):
+                buf[i] = record(step * 1000 + vs.global_id(rank, i, world))
+            expect[step] = torch.stack([record(step * 1000 + g) for g in range(cap * world)])
+            fg.start(slot)
+        fg.finish_all()
+        if rank == 0:
+            for step in (3, 4):
+                ok = ok and torch.equal(fg.global_view(step & 1).reshape(cap * world, rec), expect[step])
+        # nothing was allocated per batch: the buffers are the ones made in the constructor
+        ok = ok and ptrs == [t.data_ptr() for t in fg.send] + ([t.data_ptr() for t in fg.recv] if rank == 0 else [])
+        ok = ok and fg.batches == 5 and (fg.recv is None) == (rank != 0)
+        q.put(("ok" if ok else "mismatch", rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_frame_gather_preallocated_rank_major(world):
+    _spawn(_frame_gather_worker, world)
 
 
 def test_shard_indices_partition():
@@ -110,15 +160,5 @@ def _async_worker(rank, world, port, q):
 
 
 def test_async_gather_of_quantised_batches():
-    """What bench.py --gather does per batch: uint8 / int16 frames, one asynchronous gather in flight."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_async_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=120) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert sorted(results) == [("ok", 0), ("ok", 1)]
+    """The generic dict form: uint8 / int16 frames as ONE record per frame in ONE gather, asynchronous."""
+    _spawn(_async_worker, 2)
