@@ -699,6 +699,12 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
                                                                "write_size_kib_per_launch") if kk in k}
             roofline["traffic_detail"]["kernel"] = kern
             roofline["traffic_source"] = pmc["source"]
+            # the whole path's HBM-side traffic (counters) beside the formula's bytes: every kernel one frames batch launches
+            per_batch = sum(kk["traffic_bytes_per_launch"]        # (each of them is launched once per batch)
+                            for name, kk in pmc["kernels"].items()
+                            if "traffic_bytes_per_launch" in kk and (not name.startswith("composite_quarter_kernel") or name == kern))
+            roofline["whole_path"]["traffic_bytes_per_view"] = int(per_batch / B)
+            roofline["whole_path"]["traffic_frac"] = round(per_batch / B * value / world / 1e9 / HBM_PEAK_GBS, 5)
             if "valu_busy" in k:
                 roofline["valu_issue"] = {"busy_frac": k["valu_busy"], "lds_busy_frac": k.get("lds_busy"), "kernel": kern,
                                           "definition": pmc.get("busy_definition")}
@@ -757,30 +763,39 @@ def _cpu_baseline(args, eng):
         oracle.forward(**act, sh_degree=3, **eng.views[0].raster_kwargs(), num_threads=c, want_binning=False)
         trial[c] = time.perf_counter() - t1
     cores = min(trial, key=trial.get)
+
+    def frame_on(threads, v, step):
+        """one FRAME of the metric on the CPU: scene pass + objects-only semantic pass + K masks (or the scene pass alone)"""
+        posed = {} if eng.pose_seq is None else dict(object_id=oid, poses=eng.pose_seq[step % SEQUENCE_STEPS])
+        t1 = time.perf_counter()
+        oracle.forward(**act, sh_degree=3, **v.raster_kwargs(), num_threads=threads, want_binning=False, **posed)
+        if with_masks:
+            posed_o = {} if eng.pose_seq is None else dict(object_id=oid[n_env:], poses=eng.pose_seq[step % SEQUENCE_STEPS])
+            seg = oracle.forward(act["means3d"][n_env:], act["opacities"][n_env:], scales=act["scales"][n_env:],
+                                 rotations=act["rotations"][n_env:], shs=sem_shs, sh_degree=0,
+                                 **v.raster_kwargs(), num_threads=threads, want_binning=False, **posed_o)
+            oracle.color_masks(seg["color"], fr.colors_np, 0.1)
+        return time.perf_counter() - t1
     n_done, t_cpu = 0, 0.0
     n_env = fr.n_env
     with_masks = eng.with_masks
     sem_shs = fr.sem_shs.cpu().numpy() if with_masks else None
     oid = eng.cloud.object_id
     while n_done < len(eng.views) and (n_done == 0 or t_cpu + t_cpu / n_done < args.cpu_budget_s):
-        v = eng.views[n_done]
-        posed = {} if eng.pose_seq is None else dict(object_id=oid, poses=eng.pose_seq[n_done % SEQUENCE_STEPS])
-        t1 = time.perf_counter()
-        oracle.forward(**act, sh_degree=3, **v.raster_kwargs(), num_threads=cores, want_binning=False, **posed)
-        if with_masks:
-            posed_o = {} if eng.pose_seq is None else dict(object_id=oid[n_env:], poses=eng.pose_seq[n_done % SEQUENCE_STEPS])
-            seg = oracle.forward(act["means3d"][n_env:], act["opacities"][n_env:], scales=act["scales"][n_env:],
-                                 rotations=act["rotations"][n_env:], shs=sem_shs, sh_degree=0,
-                                 **v.raster_kwargs(), num_threads=cores, want_binning=False, **posed_o)
-            oracle.color_masks(seg["color"], fr.colors_np, 0.1)
-        t_cpu += time.perf_counter() - t1
+        t_cpu += frame_on(cores, eng.views[n_done], n_done)
         n_done += 1
+    # SURVEY.md section 8d asks for (i) 1 thread and (ii) all host cores beside it: one frame each (a 1-thread frame of
+    # the 2 M-Gaussian scene takes seconds, the bound on this leg's run time)
+    t_one = frame_on(1, eng.views[0], 0)
+    t_all = frame_on(n_cpu, eng.views[0], 0)
     try:
         cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
     except (OSError, StopIteration):
         cpu_model = "unknown"
     return {"value": round(n_done / t_cpu, 4), "unit": "frames/s" if with_masks else "views/s", "cores": cores,
             "kind": "port", "cpu_model": cpu_model,
+            "one_thread": {"value": round(1.0 / t_one, 4), "cores": 1, "sample": "1 frame"},
+            "all_cores": {"value": round(1.0 / t_all, 4), "cores": n_cpu, "sample": "1 frame"},
             "sample": f"first {n_done} frame(s) of the same scene and cameras, oracle/pgr_oracle.c with OpenMP, "
                       f"reference-style lists; {cores} threads = the fastest of a one-view trial at "
                       f"{{{', '.join(f'{c}: {t:.2f} s' for c, t in trial.items())}}} on this host's {n_cpu} hardware threads; "

@@ -2,8 +2,12 @@
 
 Reference (the surviving copy of the writer): /root/reference/src/tools/pegasus_working.py:441-455,457-576.
 For every frame and object:  T_m2c = T_w2c @ T_m2w  with  T_w2c[:3,:3] = cam.R.T, T_w2c[:3,3] = cam.T
-(pegasus_working.py:464-466);  scene_gt entry = {"cam_R_m2c": 9 floats row-major, "cam_t_m2c": 3 floats,
-"obj_id"};  scene_camera entry = {"cam_K": 9 floats, "depth_scale"} with K from the FoV
+(pegasus_working.py:464-466);  scene_gt entry (pegasus_working.py:565-576) = {"cam_R_m2c": 9 floats row-major,
+"cam_t_m2c": 3 floats, "T_w2c": 16, "T_m2w": 16, "obj_id", "bullet_obj_id"} and -- when the caller supplies the object's
+model-space bounding box (the reference takes the 8 corners of the mesh's minimal oriented box from open3d, which is out of
+scope here, in the NDDS corner order of pegasus_working.py:470-495) -- "3d_bounding_box_model_coord" [8,3],
+"3d_bounding_center" [3], "projected_points" [8,2] and "projected_center" [1,2] with P = K @ T_m2c[:3] applied to the
+homogeneous points (pegasus_working.py:547-563);  scene_camera entry = {"cam_K": 9 floats, "depth_scale"} with K from the FoV
 (fov2focal, pegasus_working.py:349-356).  Format: submodules/bop_toolkit/docs/bop_datasets_format.md:75-109.
 
 Quirk kept from the reference and flagged: translations stay in METRES while depth images are written in
@@ -28,14 +32,42 @@ def camera_K(fovx, fovy, width, height) -> np.ndarray:
     return np.array([[fx, 0, width / 2.0], [0, fy, height / 2.0], [0, 0, 1.0]])
 
 
-def scene_gt_entry(R_c2w, t_w2c, object_poses_m2w: dict, translation_scale: float = 1.0) -> list:
-    """object_poses_m2w: {obj_id: 4x4 model-to-world}.  Returns the BOP scene_gt list for one image."""
+def project_points(K, T_m2c, points) -> np.ndarray:
+    """[n,2] pixel coordinates of model-space points: P = K @ T_m2c[:3] on homogeneous points, then the division
+    cv2.convertPointsFromHomogeneous does (a zero last coordinate divides by 1)   (pegasus_working.py:547-563)."""
+    pts = np.asarray(points, dtype=np.float64).reshape(-1, 3)
+    hom = np.concatenate([pts, np.ones((pts.shape[0], 1))], axis=1)
+    proj = (np.asarray(K, dtype=np.float64).reshape(3, 3) @ np.asarray(T_m2c, dtype=np.float64)[:3]) @ hom.T      # [3,n]
+    w = np.where(proj[2] != 0.0, proj[2], 1.0)
+    return (proj[:2] / w).T
+
+
+def scene_gt_entry(R_c2w, t_w2c, object_poses_m2w: dict, translation_scale: float = 1.0, K=None, boxes: dict = None,
+                   dataset_ids: dict = None) -> list:
+    """object_poses_m2w: {bullet_obj_id: 4x4 model-to-world}.  Returns the scene_gt list for one image with the fields of
+    the reference's writer (pegasus_working.py:565-576).  ``dataset_ids``: {bullet_obj_id: the object's dataset ID (the
+    reference's meta_info.ID)}, default: the same number.  ``boxes``: {bullet_obj_id: (corners [8,3], center [3])} in
+    model coordinates + ``K`` [3,3] add the box and its projection."""
     T_w2c = world_to_camera(R_c2w, t_w2c)
     out = []
     for obj_id, T_m2w in object_poses_m2w.items():
-        T = T_w2c @ np.asarray(T_m2w, dtype=np.float64)
-        out.append({"cam_R_m2c": T[:3, :3].reshape(-1).tolist(),
-                    "cam_t_m2c": (T[:3, 3] * translation_scale).tolist(), "obj_id": int(obj_id)})
+        T_m2w = np.asarray(T_m2w, dtype=np.float64).reshape(4, 4)
+        T = T_w2c @ T_m2w
+        e = {"cam_R_m2c": T[:3, :3].reshape(-1).tolist(),
+             "cam_t_m2c": (T[:3, 3] * translation_scale).tolist(),
+             "T_w2c": T_w2c.reshape(-1).tolist(), "T_m2w": T_m2w.reshape(-1).tolist(),
+             "obj_id": int((dataset_ids or {}).get(obj_id, obj_id)), "bullet_obj_id": int(obj_id)}
+        if boxes is not None and obj_id in boxes:
+            if K is None:
+                raise ValueError("boxes need the camera matrix K for their projection")
+            corners, center = boxes[obj_id]
+            corners = np.asarray(corners, dtype=np.float64).reshape(8, 3)
+            center = np.asarray(center, dtype=np.float64).reshape(3)
+            e["3d_bounding_box_model_coord"] = corners.tolist()
+            e["3d_bounding_center"] = center.tolist()
+            e["projected_center"] = project_points(K, T, center[None]).tolist()
+            e["projected_points"] = project_points(K, T, corners).tolist()
+        out.append(e)
     return out
 
 
@@ -48,9 +80,11 @@ def scene_camera_entry(fovx, fovy, width, height, R_c2w=None, t_w2c=None, depth_
     return e
 
 
-def batch_pose_records(views, object_poses_per_frame, translation_scale: float = 1.0):
+def batch_pose_records(views, object_poses_per_frame, translation_scale: float = 1.0, boxes: dict = None,
+                       dataset_ids: dict = None):
     """views: sequence with R_c2w, t_w2c, fovx, fovy, width, height (pegasus_amd.scenes.View or Camera-like);
-    object_poses_per_frame: one {obj_id: 4x4} dict per view (or a single dict for a static scene)."""
+    object_poses_per_frame: one {obj_id: 4x4} dict per view (or a single dict for a static scene); ``boxes`` /
+    ``dataset_ids`` as in scene_gt_entry."""
     gt, cam = {}, {}
     for i, v in enumerate(views):
         poses = object_poses_per_frame if isinstance(object_poses_per_frame, dict) else object_poses_per_frame[i]
@@ -58,6 +92,7 @@ def batch_pose_records(views, object_poses_per_frame, translation_scale: float =
         t = getattr(v, "t_w2c", getattr(v, "T", None))
         fx, fy = getattr(v, "fovx", getattr(v, "FoVx", None)), getattr(v, "fovy", getattr(v, "FoVy", None))
         w, h = getattr(v, "width", getattr(v, "image_width", None)), getattr(v, "height", getattr(v, "image_height", None))
-        gt[str(i)] = scene_gt_entry(R, t, poses, translation_scale)
+        gt[str(i)] = scene_gt_entry(R, t, poses, translation_scale, K=camera_K(fx, fy, w, h) if boxes is not None else None,
+                                    boxes=boxes, dataset_ids=dataset_ids)
         cam[str(i)] = scene_camera_entry(fx, fy, w, h, R, t)
     return gt, cam

@@ -5,8 +5,13 @@ Layout and naming follow the reference's writer (/root/reference/src/visualizati
 
     <out>/train/<scene:06d>/rgb/<frame:06d>.png              8-bit RGB,  (img * 255).astype(uint8)
     <out>/train/<scene:06d>/depth/<frame:06d>.png            16-bit grey, (depth * 1000).astype(uint16)  (millimetres)
-    <out>/train/<scene:06d>/mask_visib/<frame:06d>_<obj:06d>.png   8-bit 0/255
+    <out>/train/<scene:06d>/mask_visib/<frame:06d>_<obj:06d>.png   8-bit 0/255      visible masks ('seg_vis')
+    <out>/train/<scene:06d>/mask/<frame:06d>_<obj:06d>.png         8-bit 0/255      silhouettes   ('seg_sil')
+    <out>/train/<scene:06d>/sem_mask/<frame:06d>.png               8-bit RGB, uint8 of the semantic image ('sem_seg')
     <out>/train/<scene:06d>/scene_gt.json, scene_camera.json      pegasus_amd.bop_pose records
+
+(the five image kinds of the reference's write_training_data, /root/reference/src/tools/pegasus_working.py:412-439, for the
+data points ['rgb','depth','seg_vis','seg_sil','sem_seg'] of /root/reference/pegasus.py:491)
 
 The reference encodes PNGs with imageio (absent here); PNG is deflate + CRC, so zlib is all it takes.  Quantisation
 runs on the GPU (pgr_quantize_frame); only the 8/16-bit images cross PCIe.
@@ -76,7 +81,7 @@ class BopSceneWriter:
         import os
         from concurrent.futures import ThreadPoolExecutor
         self.scene = Path(out_dir) / "train" / f"{scene_id:06d}"
-        for d in ("rgb", "depth", "mask_visib"):
+        for d in ("rgb", "depth", "mask_visib", "mask", "sem_mask"):
             (self.scene / d).mkdir(parents=True, exist_ok=True)
         self.scene_gt, self.scene_camera = {}, {}
         self.n_frames, self.level = 0, png_level
@@ -93,7 +98,9 @@ class BopSceneWriter:
         else:
             batch_futures.append(self._pool.submit(self._write, path, image))
 
-    def add_batch(self, frames: dict, scene_gt: dict, scene_camera: dict, n: int = None):
+    def add_batch(self, frames: dict, scene_gt: dict, scene_camera: dict, n: int = None, silhouettes=None):
+        """``frames``: FrameRenderer output (color, depth, and with masks: seg, masks); ``silhouettes``: uint8 [B,K,H,W]
+        of FrameRenderer.render_silhouettes (or frames["sil"]) -> the mask/ directory."""
         from . import masks as M
         n = frames["color"].shape[0] if n is None else n
         # GPU: uint8 HWC / uint16 millimetres for the whole batch in one launch (pgr_pack_frames), then ONE device->host copy
@@ -102,6 +109,10 @@ class BopSceneWriter:
         rgb8 = packed["rgb"].cpu().numpy()
         mm = packed["depth_mm"].cpu().numpy().view(np.uint16)
         mk = (frames["masks"][:n] * 255).cpu().numpy() if "masks" in frames else None
+        sem8 = M.pack_frames(color=frames["seg"][:n])["rgb"].cpu().numpy() if "seg" in frames else None
+        if silhouettes is None:
+            silhouettes = frames.get("sil")
+        sil = (silhouettes[:n] * 255).cpu().numpy() if silhouettes is not None else None
         futures = []
         for i in range(n):
             fid = self.n_frames
@@ -110,6 +121,11 @@ class BopSceneWriter:
             if mk is not None:
                 for k in range(mk.shape[1]):
                     self._submit(self.scene / "mask_visib" / f"{fid:06d}_{k:06d}.png", mk[i, k], futures)
+            if sem8 is not None:
+                self._submit(self.scene / "sem_mask" / f"{fid:06d}.png", sem8[i], futures)
+            if sil is not None:
+                for k in range(sil.shape[1]):
+                    self._submit(self.scene / "mask" / f"{fid:06d}_{k:06d}.png", sil[i, k], futures)
             self.scene_gt[str(fid)] = scene_gt[str(i)]
             self.scene_camera[str(fid)] = scene_camera[str(i)]
             self.n_frames += 1

@@ -39,6 +39,13 @@ def main():
     fr = FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"], cloud.object_id,
                        device="cuda:0")
     centers = [act["means3d"][cloud.object_id == k].mean(0) for k in range(1, fr.K + 1)]
+    # model-space bounding boxes for the scene_gt records (the reference takes the mesh's minimal oriented box from open3d;
+    # here: the axis-aligned box of the object's Gaussians in its rest frame, corners in binary order z-fastest)
+    boxes = {}
+    for k in range(1, fr.K + 1):
+        p = act["means3d"][cloud.object_id == k].astype(np.float64)
+        lo, hi = p.min(0), p.max(0)
+        boxes[k] = (np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])]), p.mean(0))
     w = BopSceneWriter(args.out, workers=args.writers)
     t0 = time.perf_counter()
     t_gpu = 0.0
@@ -53,11 +60,13 @@ def main():
             idx = [(b0 + j) % 200 for j in range(len(vs))]
             poses, m2w = seq_tables[idx], [seq_motion[i] for i in idx]
         t1 = time.perf_counter()
-        frames = fr.render_frames([fr.view_spec(v) for v in vs], poses=poses)
+        specs = [fr.view_spec(v) for v in vs]
+        frames = fr.render_frames(specs, poses=poses)
+        sil = fr.render_silhouettes(specs, poses=poses) if fr.K else None          # 'seg_sil': one layered pass for all objects
         torch.cuda.synchronize()
         t_gpu += time.perf_counter() - t1
-        gt, cam = bop_pose.batch_pose_records(vs, m2w)
-        w.add_batch(frames, gt, cam, n=len(vs))
+        gt, cam = bop_pose.batch_pose_records(vs, m2w, boxes=boxes)
+        w.add_batch(frames, gt, cam, n=len(vs), silhouettes=sil)
     scene = w.close()
     dt = time.perf_counter() - t0
     print(f"{w.n_frames} frames ({cloud.n} Gaussians, {fr.K} objects) -> {scene}: rendering {t_gpu * 1e3:.1f} ms, "

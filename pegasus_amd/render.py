@@ -80,9 +80,13 @@ def _semantic_scene(gs_environment, gs_object_list):
     objects = list(gs_object_list.values())
     for current in objects:
         _restore_semantics(current)
-    key = _fingerprint([getattr(o, k) for o in objects for k in _GEOMETRY] +
-                       [t for o in objects for t in (o._features_dc_semantics, o._features_rest_semantics)
-                        if isinstance(t, torch.Tensor)])
+    # the tensors the key is made of.  The slot KEEPS them (below): a key built from id() / data_ptr() is only meaningful
+    # while those objects are alive -- apply_transformation replaces _xyz / _rotation with fresh tensors on every pose
+    # update, and freed ids and allocator blocks are handed out again, so that after two pose updates the old key could
+    # match tensors that merely reuse the addresses (round-3 advisor finding: stale poses in the masks)
+    keyed = [getattr(o, k) for o in objects for k in _GEOMETRY] + \
+            [t for o in objects for t in (o._features_dc_semantics, o._features_rest_semantics) if isinstance(t, torch.Tensor)]
+    key = _fingerprint(keyed)
     key = None if key is None else (key, tuple(id(o) for o in objects), id(gs_environment),
                                     getattr(gs_environment, "active_sh_degree", None))
     if key is not None and _kept_scene.get("key") == key:
@@ -92,7 +96,7 @@ def _semantic_scene(gs_environment, gs_object_list):
         parts = [getattr(o, k) for o in objects]
         setattr(scene, k, torch.cat(parts, 0) if parts else getattr(gs_environment, k)[:0])
     _kept_scene.clear()
-    _kept_scene.update(key=key, scene=scene, renders={}, keep=objects)
+    _kept_scene.update(key=key, scene=scene, renders={}, keep=(objects, keyed))
     return scene, key
 
 

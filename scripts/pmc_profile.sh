@@ -6,6 +6,14 @@
 cd "$(dirname "$0")/.."
 REPO=$PWD
 name=${1:-pmc}; shift
+# the counter passes describe the SINGLE-PROCESS path: a flag that turns the profiled bench.py into a launcher of a process
+# tree (--gpus N), or into another measurement (--facade, --stub-renderer), would make pmc.json describe something else
+for a in "$@"; do
+  case "$a" in
+    --gpus*|--facade|--stub-renderer|--share-devices|--force-dist|--backend*)
+      echo "pmc_profile.sh: flag $a is not allowed here (single-process counter passes only)" >&2; exit 2;;
+  esac
+done
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 BENCH_FLAGS="--steps 3 --warmup 1 --no-cpu-baseline --no-drop-in --profile-steps 1 --sync-steps $*"

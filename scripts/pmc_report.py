@@ -16,7 +16,7 @@ import sqlite3
 import sys
 from collections import defaultdict
 
-STAGE_KERNEL = [("preprocess", r"preprocess_batch_kernel"), ("bin_count", r"bin_kernel<false>"), ("bin_scatter", r"bin_kernel<true>"),
+STAGE_KERNEL = [("preprocess", r"preprocess_batch_kernel"), ("bin_count", r"bin_kernel<false"), ("bin_scatter", r"bin_kernel<true"),
                 ("tile_sort", r"tile_sort_kernel$"), ("composite", r"composite_quarter_kernel")]
 
 

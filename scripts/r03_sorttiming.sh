@@ -1,6 +1,6 @@
-cd $GRAFT_REPO_ROOT
-cp pegasus_amd/csrc/libpegasus_raster.so /tmp/lib_orig.so
-cp build_variants/lib_sorttiming.so pegasus_amd/csrc/libpegasus_raster.so
-python scripts/sort_timing.py c5 2>&1 | grep -v amdgpu.ids
-python scripts/sort_timing.py c3 2>&1 | grep -v amdgpu.ids
-cp /tmp/lib_orig.so pegasus_amd/csrc/libpegasus_raster.so
+#!/bin/bash
+# per-phase sort timing from a -DPGR_SORT_TIMING build in build_variants/lib_sorttiming.so (loaded through PGR_LIB)
+set -e
+cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set}"
+PGR_LIB=$PWD/build_variants/lib_sorttiming.so python scripts/sort_timing.py c5 2>&1 | grep -v amdgpu.ids
+PGR_LIB=$PWD/build_variants/lib_sorttiming.so python scripts/sort_timing.py c3 2>&1 | grep -v amdgpu.ids

@@ -17,11 +17,9 @@ if [ "$mode" = build ]; then
   wait
   ls -la build_variants
 else
-  cp pegasus_amd/csrc/libpegasus_raster.so /tmp/lib_orig.so
-  for f in build_variants/*.so; do
-    cp "$f" pegasus_amd/csrc/libpegasus_raster.so
+  for f in build_variants/*.so; do      # (loaded through PGR_LIB: the product .so is never overwritten)
     echo -n "$f  "
-    timeout 200 python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c "
+    PGR_LIB=$PWD/$f timeout 200 python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
@@ -29,5 +27,4 @@ for l in sys.stdin:
         print(round(d['value'], 1), d['unit'], {k: round(v, 4) for k, v in st.items()})
 "
   done
-  cp /tmp/lib_orig.so pegasus_amd/csrc/libpegasus_raster.so
 fi

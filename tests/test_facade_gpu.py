@@ -166,6 +166,19 @@ def test_generate_writes_bop_layout(gpu_device, tmp_path):
     assert rgb.shape == (160, 160, 3) and rgb.dtype == np.uint8 and rgb.max() > 0
     assert depth.shape == (160, 160) and depth.dtype == np.uint16 and 200 < depth[depth > 0].mean() < 3000   # millimetres
     assert all(set(np.unique(m)) <= {0, 255} for m in masks) and sum(int(m.sum()) for m in masks) > 0
+    # the reference writer's other two image kinds (pegasus_working.py:423-434): the uint8 semantic image and the silhouettes
+    sem = decode_png((scene / "sem_mask" / "000003.png").read_bytes())
+    sil = [decode_png((scene / "mask" / f"000003_{k:06d}.png").read_bytes()) for k in range(8)]
+    assert sem.shape == (160, 160, 3) and sem.dtype == np.uint8 and sem.max() > 0
+    assert all(set(np.unique(m)) <= {0, 255} for m in sil)
+    # a silhouette holds its object's visible mask (up to threshold pixels at blended edges), and occluded parts beside it
+    assert sum(int((s_ >= v_).sum()) for s_, v_ in zip(sil, masks)) > 0.999 * 8 * 160 * 160
+    assert sum(int(m.sum()) for m in sil) >= sum(int(m.sum()) for m in masks)
+    # where exactly one object is visible the semantic image shows that object's colour
+    e0 = gt["3"][0]
+    assert set(e0) >= {"cam_R_m2c", "cam_t_m2c", "T_w2c", "T_m2w", "obj_id", "bullet_obj_id", "3d_bounding_box_model_coord",
+                       "3d_bounding_center", "projected_center", "projected_points"}
+    assert np.array(e0["projected_points"]).shape == (8, 2) and len(e0["T_w2c"]) == 16
 
 
 @pytest.mark.gpu
@@ -281,3 +294,16 @@ def test_semantic_wrappers_follow_objects_cameras_and_backgrounds(gpu_device):
         assert same(recol, both(cams[0], bg, cold=True)) and not torch.equal(recol[1], faint[1])
         # the objects keep the paint, as the reference's callers expect (render.py:51-52)
         assert torch.equal(objs[2]._features_dc, objs[2]._features_dc_semantics.expand_as(objs[2]._features_dc))
+        # Two pose updates between semantic renders (masks asked for every 2nd step).  apply_transformation /
+        # apply_translation replace _xyz with a fresh tensor per update, so ids and allocator blocks are recycled: a key of
+        # (id, version, data_ptr) could match tensors that merely reuse the addresses of two updates ago.  The slot keeps
+        # its keyed tensors alive, so it cannot (round-3 advisor finding).  The cold reference leaves the warm slot as it was.
+        for step in range(8):
+            for _ in range(2):
+                objs[1].apply_translation_on_xyz(torch.tensor([0.004, 0.0, 0.001], device=dev))
+            warm = both(cams[0], bg, cold=False)
+            saved = dict(prender._kept_scene)
+            cold = both(cams[0], bg, cold=True)
+            prender._kept_scene.clear()
+            prender._kept_scene.update(saved)
+            assert same(warm, cold), step

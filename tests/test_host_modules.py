@@ -64,6 +64,32 @@ def test_bop_pose_record():
     K = np.array(bop_pose.scene_camera_entry(0.8, 0.6, 640, 480)["cam_K"]).reshape(3, 3)
     assert K[0, 2] == 320 and K[1, 2] == 240 and abs(K[0, 0] - 320 / np.tan(0.4)) < 1e-9
     assert bop_pose.scene_gt_entry(R_c2w, t, {7: T_m2w}, translation_scale=1000.0)[0]["cam_t_m2c"][2] == e["cam_t_m2c"][2] * 1000
+    # the other fields of the reference's record (/root/reference/src/tools/pegasus_working.py:565-576), against a numpy
+    # restatement of its lines 463-466, 547-563
+    assert e["bullet_obj_id"] == 7 and "projected_points" not in e
+    T_w2c = np.eye(4); T_w2c[:3, :3] = R_c2w.T; T_w2c[:3, 3] = t
+    np.testing.assert_allclose(np.array(e["T_w2c"]).reshape(4, 4), T_w2c, atol=1e-15)
+    np.testing.assert_allclose(np.array(e["T_m2w"]).reshape(4, 4), T_m2w, atol=1e-15)
+    corners = np.array([[x, y, z] for x in (-0.05, 0.05) for y in (-0.03, 0.03) for z in (-0.1, 0.1)])
+    center = np.array([0.001, -0.002, 0.003])
+    b = bop_pose.scene_gt_entry(R_c2w, t, {7: T_m2w}, K=K, boxes={7: (corners, center)}, dataset_ids={7: 21})[0]
+    assert b["obj_id"] == 21 and b["bullet_obj_id"] == 7
+    np.testing.assert_array_equal(np.array(b["3d_bounding_box_model_coord"]), corners)
+    np.testing.assert_array_equal(np.array(b["3d_bounding_center"]), center)
+    T = T_w2c @ T_m2w
+    P = K @ T[:3]
+    hom = (P @ np.concatenate([corners, np.ones((8, 1))], 1).T).T
+    np.testing.assert_allclose(np.array(b["projected_points"]), hom[:, :2] / hom[:, 2:], atol=1e-12)
+    hc = P @ np.append(center, 1.0)
+    np.testing.assert_allclose(np.array(b["projected_center"]), [hc[:2] / hc[2]], atol=1e-12)
+    assert np.array(b["projected_points"]).shape == (8, 2) and np.array(b["projected_center"]).shape == (1, 2)
+    with pytest.raises(ValueError):
+        bop_pose.scene_gt_entry(R_c2w, t, {7: T_m2w}, boxes={7: (corners, center)})
+    # batch form: boxes reach every frame's records, K comes from the view's FoV
+    from types import SimpleNamespace
+    V = SimpleNamespace(R_c2w=R_c2w, t_w2c=t, fovx=0.8, fovy=0.6, width=640, height=480)
+    gt, cam = bop_pose.batch_pose_records([V, V], {7: T_m2w}, boxes={7: (corners, center)})
+    assert gt["1"][0]["projected_points"] == b["projected_points"] and len(cam["0"]["cam_K"]) == 9
 
 
 def test_pose_interpolation_matches_reference_golden():
