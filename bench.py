@@ -741,8 +741,11 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
                              "static scene, camera batches"),
                 "scene_layout": ("input order" if fr.order is None else
                                  "Morton order per object (one-time, at scene load, outside the timed region)"),
-                "outputs": ("color[3,H,W] f32 + depth[1,H,W] f32 + semantic image[3,H,W] f32 + masks[K,H,W] u8"
+                "outputs": (("color[3,H,W] f32 + depth[1,H,W] f32 + semantic image[3,H,W] f32 + masks[K,H,W] u8"
+                             + (" + silhouette masks[K,H,W] u8" if eng.with_sil else ""))
                             if with_masks else "color[3,H,W] f32 + depth[1,H,W] f32"),
+                "data_points": (["rgb", "depth", "seg_vis", "sem_seg"] + (["seg_sil"] if eng.with_sil else [])) if with_masks
+                               else ["rgb", "depth"],
                 "parallelism": f"view-shard x{world}", "distributed": dist_info, "gather": gather_info},
         roofline=roofline, cpu_baseline=cpu, drop_in=drop_in)
     if rehearsal:

@@ -357,7 +357,8 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
             bin_table, N, grid_x, L.tiles, W, H, vis, B.vis_words, verdict_groups, bl);
     // tile scan -> ranges; the same pass counts the compositor's work items per (XCD stream, length class) and its last
     // workgroup turns the counts into the streams' write cursors
-    tile_scan_kernel<<<n_views, 1024, 0, stream>>>(bin_table, L.tiles, (uint32_t)max_instances, L.grid_x, order_state);
+    tile_scan_kernel<<<n_views, 1024, 0, stream>>>(bin_table, L.tiles, (uint32_t)max_instances, L.grid_x, order_state,
+                                                   layers ? 1 : 0);
     mark(2);
     // ---- stage 2: scatter (depth bits, index) into the tiles' slices
     if (few_views)
@@ -373,7 +374,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     const size_t qs = (size_t)items;              // queue stride
     const bool merge_long = n_views <= SMALL_BATCH_VIEWS;
     order_scatter_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, L.grid_x, order_state, work_order, sort_queue,
-                                                 (uint32_t)items, merge_long ? 1 : 0);
+                                                 (uint32_t)items, merge_long ? 1 : 0, layers ? 1 : 0);
     const uint32_t* n_queue = order_state + ORDER_BINS;
     tile_sort_long_kernel<1024, 16, true><<<std::min(items, 512), 1024, 0, stream>>>(
         bin_table, L.tiles, sort_queue + 3 * qs, n_queue + 3);
@@ -403,6 +404,9 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     }
     if (layers) {
         sd.mask_colors = layers->mask_colors; sd.mask_thr = layers->mask_threshold; sd.k = n_layers;
+        // empty (layer, tile) lists have no work item: their pixels hold the background's verdict
+        layer_mask_fill_kernel<<<dim3((unsigned)((P + 1023) / 1024), n_layers, n_views), 256, 0, stream>>>(
+            view_table, layers->mask_colors, layers->mask_threshold, P);
         launch_composite<false, false, true>(slots, stream, view_table, items_per_view, work_order, sd);
     } else if (want_aux && want_sem)
         launch_composite<true, true>(slots, stream, view_table, items_per_view, work_order, sd);

@@ -353,7 +353,7 @@ __global__ void invert_tie_index_kernel(int n, const int32_t* __restrict__ tie_i
 // workgroup to finish (agent-scope ticket behind a fence) turns the counts into the streams' write cursors.
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const BinView* __restrict__ views, int tiles,
                                                          uint32_t max_instances, int grid_x,
-                                                         uint32_t* __restrict__ order_state) {
+                                                         uint32_t* __restrict__ order_state, int skip_empty) {
     __shared__ unsigned long long wave_tot[1024 / WAVE];
     __shared__ unsigned long long carry_s;
     __shared__ uint32_t hist[ORDER_BINS];
@@ -382,7 +382,9 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const BinView* __restri
         if (idx < tiles) {
             const uint2 r = make_uint2((uint32_t)min(excl, cap), (uint32_t)min(excl + v, cap));
             bv.ranges[idx] = r;
-            if (order_state) atomicAdd(&hist[xcd_of_tile(idx, grid_x) * ORDER_CLASSES_USED + coarse_class(r.y - r.x)], ITEMS_PER_TILE);
+            // (a layered call gives empty lists no work item: their pixels are pre-filled, layer_mask_fill_kernel)
+            if (order_state && !(skip_empty && r.y == r.x))
+                atomicAdd(&hist[xcd_of_tile(idx, grid_x) * ORDER_CLASSES_USED + coarse_class(r.y - r.x)], ITEMS_PER_TILE);
         }
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = carry + wave_prefix + s;
