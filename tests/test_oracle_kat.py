@@ -293,3 +293,30 @@ def test_sh_colour_model_against_first_principles_basis(oracle):
         d = means[i].astype(np.float64) - v.camera_center.astype(np.float64)
         want = np.maximum(real_sh_basis(3, d / np.linalg.norm(d)) @ shs[i].astype(np.float64) + 0.5, 0.0)
         np.testing.assert_allclose(o["rgb"][i], want, atol=2e-6)
+
+
+def test_depth_mode_switch_known_answers(oracle):
+    """The depth rule is a switch (SURVEY.md section 8a "Depth variant": unverified, "keep it a one-line switch").
+    mode 0: sum T alpha z.  mode 1: that sum over 1 - T_final (= the blended weights' total): one splat -> exactly its z;
+    two coincident splats at z1 < z2 -> (a1 z1 + a2 (1 - a1) z2) / (a1 + a2 (1 - a1)); untouched pixels -> 0 in both."""
+    x, y = world_of(20, 30, 2.0)
+    one = [splat(x, y, 2.0, 3.0, 0.6, (0.9, 0.5, 0.1))]
+    r0, r1 = run(oracle, one, depth_mode=0), run(oracle, one, depth_mode=1)
+    assert r0["out_depth"][0, 30, 20] == pytest.approx(2.0 * 0.6, abs=1e-6)
+    assert r1["out_depth"][0, 30, 20] == pytest.approx(2.0, abs=1e-5)
+    assert r1["out_depth"][0, 0, 63] == 0.0 and r0["out_depth"][0, 0, 63] == 0.0          # nothing blended there
+    np.testing.assert_array_equal(r0["color"], r1["color"])                               # only the depth image differs
+    np.testing.assert_array_equal(r0["final_T"], r1["final_T"])
+    np.testing.assert_array_equal(r0["n_contrib"], r1["n_contrib"])
+    xa, ya = world_of(20, 30, 1.5)
+    xb, yb = world_of(20, 30, 3.0)
+    two = [splat(xb, yb, 3.0, 3.0, 0.8, (0.1, 0.9, 0.1)), splat(xa, ya, 1.5, 3.0, 0.5, (0.9, 0.1, 0.1))]
+    a1, a2 = 0.5, 0.8
+    r0, r1 = run(oracle, two, depth_mode=0), run(oracle, two, depth_mode=1)
+    d = a1 * 1.5 + a2 * (1 - a1) * 3.0
+    assert r0["out_depth"][0, 30, 20] == pytest.approx(d, abs=2e-6)
+    assert r1["out_depth"][0, 30, 20] == pytest.approx(d / (a1 + a2 * (1 - a1)), abs=1e-5)
+    # everywhere: normalised = un-normalised / (1 - T), exactly as the expression says
+    T = r0["final_T"]
+    want = np.where(1.0 - T > 0, r0["out_depth"][0] / (np.float32(1.0) - T), np.float32(0.0)).astype(np.float32)
+    np.testing.assert_array_equal(r1["out_depth"][0], want)
