@@ -147,3 +147,18 @@ def test_one_rank_process_group_on_rccl(gpu_device):
     g = line["config"]["gather"]
     assert g["check"] == "ok" and g["bytes_per_rank_and_batch"] == 4 * 800 * 800 * (3 + 2 + 1)
     assert g["views_per_s_with_gather"] > 0 and g["views_per_s_render_only"] > 0
+
+
+@pytest.mark.gpu
+def test_dynamic_sequence_two_ranks_rehearsal(gpu_device):
+    """configs[4]'s multi-GPU form, rehearsed: time step s -> rank s mod 2, every rank poses its own steps from the trajectory
+    fixture, packs records and gathers them (two ranks on the one device, gloo).  Launcher, sharding of TIME STEPS, gather
+    and check -- not a result."""
+    p, line = _run([sys.executable, "bench.py", "--gpus", "2", "--share-devices", "--backend", "gloo", "--workload", "c5",
+                    "--dynamic", "--scale", "0.02", "--steps", "2", "--warmup", "1", "--batch", "4", "--views", "200",
+                    "--slots", "2", "--repeats", "2", "--no-drop-in"], timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert line["n_gpus"] == 2 and "rehearsal" in line and "simulation_steps.json" in line["config"]["sequence"]
+    g = line["config"]["gather"]
+    assert g["check"] == "ok" and g["views_per_s_with_gather"] > 0 and len(line["per_rank_s"]["all"]) == 2
+    assert line["config"]["objects"] == 20

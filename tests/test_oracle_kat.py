@@ -318,5 +318,6 @@ def test_depth_mode_switch_known_answers(oracle):
     assert r1["out_depth"][0, 30, 20] == pytest.approx(d / (a1 + a2 * (1 - a1)), abs=1e-5)
     # everywhere: normalised = un-normalised / (1 - T), exactly as the expression says
     T = r0["final_T"]
-    want = np.where(1.0 - T > 0, r0["out_depth"][0] / (np.float32(1.0) - T), np.float32(0.0)).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want = np.where(1.0 - T > 0, r0["out_depth"][0] / (np.float32(1.0) - T), np.float32(0.0)).astype(np.float32)
     np.testing.assert_array_equal(r1["out_depth"][0], want)
