@@ -377,9 +377,34 @@ def _checksums(local):
     return {k: int(t.contiguous().view(torch.uint8).to(torch.int64).sum().item()) for k, t in local.items()}
 
 
+_REAL_STDOUT = None
+
+
+def protect_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries under us write there too -- RCCL prints a version banner at
+    communicator creation, gloo its "Rank 0 is connected to ..." lines (both seen in this round's rehearsals, straight to
+    file descriptor 1, unordered against Python's buffered stream) -- so for the rest of the process descriptor 1 IS stderr,
+    and the line goes to a private duplicate of the original stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line: dict):
+    data = (json.dumps(line) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def run_worker(args):
     import torch
     import torch.distributed as dist
+    protect_stdout()
 
     env_world = os.environ.get("WORLD_SIZE")
     world = int(env_world) if env_world else 1
@@ -430,11 +455,12 @@ def run_worker(args):
         if world != 1 or eng.stub:
             raise SystemExit("--facade measures the single-process drop-in path: run it with --gpus 1")
         d = drop_in_numbers(eng, n_frames=16, n_render_calls=128)
-        print(json.dumps({"metric": "drop-in frames/sec through PEGASUS's per-camera loop (RGB+depth+visible masks+semantic "
-                                    f"mask, one render() per data point) on {eng.cloud.n / 1e6:.2g}M-Gaussian scene @{eng.W}x{eng.H}",
-                          "value": d["frames_per_s"], "unit": "frames/s", "n_gpus": 1, "higher_is_better": True,
-                          "dtype": "f32", "data": "synthetic", "config": {"workload": eng.label, "objects": eng.fr.K},
-                          "drop_in": d}))
+        emit({"metric": "drop-in frames/sec through PEGASUS's per-camera loop (RGB+depth+visible masks+semantic "
+                        f"mask, one render() per data point; static scene: the objects-only semantic scene and its render are "
+                        f"shared by the two semantic wrappers and kept while no object moves) on {eng.cloud.n / 1e6:.2g}M-Gaussian scene @{eng.W}x{eng.H}",
+              "value": d["frames_per_s"], "unit": "frames/s", "n_gpus": 1, "higher_is_better": True,
+              "dtype": "f32", "data": "synthetic", "config": {"workload": eng.label, "objects": eng.fr.K},
+              "drop_in": d})
         return 0
     B, n_slots = eng.B, eng.n_slots
     # ---- the one exchange of the path (N > 1): per batch ONE gather of ONE uint8 record per frame, between buffers that
@@ -442,7 +468,7 @@ def run_worker(args):
     # i * world + r, so the root's rank-major receive buffer is the global order under a transposed view: nothing is
     # reordered, copied or allocated per batch.
     fg = stage = None
-    gstat = {"host_s": 0.0, "batches": 0}
+    gstat = {"host_s": 0.0, "wire_s": 0.0, "batches": 0}
     if gather_on:
         from pegasus_amd import view_shard as VS
         host_wire = backend == "gloo"              # gloo moves host memory: rehearsals and CPU tests only
@@ -459,21 +485,26 @@ def run_worker(args):
         t0 = time.perf_counter()
         slot = gstat["batches"] & 1
         fg.finish(slot)                            # the gather that last used this slot's buffers (two batches ago)
+        t1 = time.perf_counter()
+        wire = t1 - t0                             # host time spent waiting for bytes to move (RCCL: none, the wait is a stream dependency)
         if stage is not None:
             eng.pack(token, stage[slot])
+            t2 = time.perf_counter()
             fg.send_buffer(slot).copy_(stage[slot], non_blocking=True)
             torch.cuda.current_stream().synchronize()
+            wire += time.perf_counter() - t2       # the rehearsal's device -> pinned host leg belongs to its wire
         else:
             eng.pack(token, fg.send_buffer(slot))
         fg.start(slot)
         gstat["batches"] += 1
-        gstat["host_s"] += time.perf_counter() - t0
+        gstat["wire_s"] += wire
+        gstat["host_s"] += time.perf_counter() - t0 - wire
 
     def finish_inflight():
         if fg is not None:
             t0 = time.perf_counter()
             fg.finish_all()
-            gstat["host_s"] += time.perf_counter() - t0
+            gstat["wire_s"] += time.perf_counter() - t0
 
     def run_steps(first, count, gather):
         """`count` steps as an `n_slots`-deep software pipeline: batch i is enqueued (no host sync) while batch i-1
@@ -524,9 +555,9 @@ def run_worker(args):
     eng.settle(run_steps)
     run_steps(0, args.warmup, gather_on)
     repeats = max(1, args.repeats)
-    gstat.update(host_s=0.0, batches=0)
+    gstat.update(host_s=0.0, wire_s=0.0, batches=0)
     runs = [timed(args.warmup, args.steps, gather_on) for _ in range(repeats)]
-    gather_host_s = gstat["host_s"] / repeats
+    gather_host_s, gather_wire_s = gstat["host_s"] / repeats, gstat["wire_s"] / repeats
     order = sorted(range(repeats), key=lambda r: runs[r][0])
     med = order[(repeats - 1) // 2]                # the median repeat (lower middle for an even count)
     elapsed, per_rank = runs[med]
@@ -593,24 +624,27 @@ def run_worker(args):
             "views_per_s_with_gather": round(value, 3),
             "views_per_s_render_only": round(total_views / elapsed_render_only, 3),
             "inbound_to_root_gb_per_s": round(fg.bytes_per_rank_and_batch * (world - 1) * args.steps / elapsed / 1e9, 2),
-            # rank 0's host time inside pack + gather calls per step (enqueue of the pack kernel, completion of the gather
-            # two batches back, start of this one), mean over the repeats
+            # rank 0's own per-batch overhead: host time to enqueue the pack kernel and start the collective (there is no
+            # assembly step: nothing is reordered or copied on arrival), mean over the repeats; and, apart from it, the host
+            # time spent WAITING for bytes to move -- zero on RCCL (completion is a stream dependency), the whole transfer on
+            # the gloo rehearsal (device -> pinned host -> loopback TCP)
             "rank0_gather_host_ms_per_step": round(gather_host_s / args.steps * 1e3, 4),
             "rank0_gather_host_frac_of_step": round(gather_host_s / elapsed, 4),
+            "rank0_wait_for_wire_ms_per_step": round(gather_wire_s / args.steps * 1e3, 4),
             "check": gather_check,
         }
     if eng.stub:
         line.update(metric="STUB launch-path test (no rasterizer) -- INVALID as a measurement", stub=True,
                     config={"workload": eng.label, "views_per_step": B, "parallelism": f"view-shard x{world}",
                             "distributed": dist_info, "gather": gather_info})
-        print(json.dumps(line))
+        emit(line)
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return 0
 
     _finish_real_line(args, eng, line, value, world, dist_info, gather_info, rehearsal)
-    print(json.dumps(line))
+    emit(line)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -889,7 +923,9 @@ def drop_in_numbers(eng, n_frames=4, n_render_calls=48):
             "ms_per_part": {k: round(v / n_frames * 1e3, 3) for k, v in parts.items()},
             "frame": "deepcopy + merge of the scene, render_rgb_and_depth, render_visib_mask (K masks to the host as float64, "
                      "as the reference returns them) and render_semanticsegmentation_mask -- the ['rgb','seg_vis','sem_seg'] "
-                     "data points of /root/reference/pegasus.py:254-358, one camera per frame",
+                     "data points of /root/reference/pegasus.py:254-358, one camera per frame.  STATIC scene: the two semantic "
+                     "wrappers share one objects-only scene and one render per camera, kept while no object moves; a dynamic "
+                     "run rebuilds that scene every frame and is slower than this figure",
             "sample": f"{n_frames} frames, {min(n_render_calls, len(cams))} render() calls; same scene and cameras as the batch path"}
 
 

@@ -85,8 +85,13 @@ class FrameRenderer:
         # per-scene constants of the batch calls, once (pgr_scene_prepare): the inverse tie permutation, the object ids as bytes
         self._prep = R.scene_prepare(self.n, self.tie_index, self.semantic if self.K else None)
         self.tie_inv = self._prep["tie_inv"]
+        self.obj_tie_inv = None
         if self.K:
             self.semantic["object_id_u8"] = self._prep["object_id_u8"]
+            # the objects-only cloud (separate semantic pass, silhouettes): its own inverse tie permutation; layer = object id
+            self._sil_layer_id = self.semantic["object_id"][self.n_env:].contiguous()
+            self._sil_prep = R.scene_prepare(self.n - self.n_env, self.obj_tie_index)
+            self.obj_tie_inv = self._sil_prep["tie_inv"]
 
     def view_spec(self, view, depth_mode: int = 0) -> R.ViewSpec:
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
@@ -188,15 +193,15 @@ class FrameRenderer:
         s_scene.wait_stream(cur)
         with torch.cuda.stream(s_scene):
             h1 = R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales, tie_index=self.tie_index,
-                                 rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False, outputs=outs,
-                                 async_slot=("scene", slot))
+                                 tie_inv=self.tie_inv, rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False,
+                                 outputs=outs, async_slot=("scene", slot))
         h2 = None
         if masks and self.K:
             souts = [dict(color=frames["seg"][i], depth=frames["seg_depth"][i], radii=None) for i in range(B)]
             s_sem.wait_stream(cur)
             with torch.cuda.stream(s_sem):
                 h2 = R.forward_views(self.obj["means3d"], self.obj["opacities"], specs, shs=self.sem_shs, tie_index=self.obj_tie_index,
-                                     scales=self.obj["scales"], rotations=self.obj["rotations"], sh_degree=0,
+                                     tie_inv=self.obj_tie_inv, scales=self.obj["scales"], rotations=self.obj["rotations"], sh_degree=0,
                                      want_radii=False, outputs=souts, async_slot=("sem", slot))
                 M.color_masks(frames["seg"][:B], self.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])
                 ev_masks = torch.cuda.Event()
@@ -253,10 +258,6 @@ class FrameRenderer:
             out = torch.empty((B, max(self.K, 1), H, W), dtype=torch.uint8, device=self.device)
         if self.K == 0:
             return out[:, :0] if wait else (out[:, :0], None)
-        if not hasattr(self, "_sil_prep"):
-            # the objects-only cloud: the caller's tie order among the object Gaussians, layer = object id
-            self._sil_layer_id = self.semantic["object_id"][self.n_env:].contiguous()
-            self._sil_prep = R.scene_prepare(self.n - self.n_env, self.obj_tie_index)
         posed = None
         if poses is not None:
             posed = dict(object_id=self._sil_layer_id, poses=self._posed(poses, B)["poses"])
@@ -276,7 +277,7 @@ class FrameRenderer:
         with torch.cuda.stream(st):
             h = R.forward_views(self.obj["means3d"], self.obj["opacities"], specs, shs=self.sem_shs, scales=self.obj["scales"],
                                 rotations=self.obj["rotations"], sh_degree=0, want_radii=False, posed=posed,
-                                tie_index=self.obj_tie_index, tie_inv=self._sil_prep["tie_inv"], outputs=outs,
+                                tie_index=self.obj_tie_index, tie_inv=self.obj_tie_inv, outputs=outs,
                                 async_slot=("silhouette", slot), layers=layers)
         h._args = (specs, posed, layers)
         if not wait:
@@ -353,12 +354,12 @@ class FrameRenderer:
             frames = self.alloc_frames(B, H, W, masks)
         outs = [dict(color=frames["color"][i], depth=frames["depth"][i], radii=None) for i in range(B)]
         R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales, tie_index=self.tie_index,
-                        rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False, outputs=outs,
-                        stage_ms=stage_ms)
+                        tie_inv=self.tie_inv, rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False,
+                        outputs=outs, stage_ms=stage_ms)
         if masks and self.K:
             souts = [dict(color=frames["seg"][i], depth=frames["seg_depth"][i], radii=None) for i in range(B)]
             R.forward_views(self.obj["means3d"], self.obj["opacities"], specs, shs=self.sem_shs, tie_index=self.obj_tie_index,
-                            scales=self.obj["scales"], rotations=self.obj["rotations"], sh_degree=0,
+                            tie_inv=self.obj_tie_inv, scales=self.obj["scales"], rotations=self.obj["rotations"], sh_degree=0,
                             want_radii=False, outputs=souts, stage_ms=sem_stage_ms)
             M.color_masks(frames["seg"][:B], self.colors, M.MASK_THRESHOLD, out=frames["masks"][:B])
         return frames

@@ -34,6 +34,8 @@ def test_gpus_2_launches_two_ranks_by_itself_and_gathers():
     p, line = _run([sys.executable, "bench.py", "--gpus", "2", "--stub-renderer", "--steps", "3", "--warmup", "1", "--batch", "4"])
     assert p.returncode == 0, p.stderr[-2000:]
     assert len([l for l in p.stdout.splitlines() if l.startswith("{")]) == 1          # ONE line, from rank 0
+    assert [l for l in p.stdout.splitlines() if l.strip()] == [l for l in p.stdout.splitlines() if l.startswith("{")], \
+        "stdout carries the JSON line and nothing else (gloo / RCCL banners go to stderr)"
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
     d = line["config"]["distributed"]
     assert d["world_size"] == 2 and d["launcher"].startswith("self")
