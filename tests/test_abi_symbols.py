@@ -88,3 +88,55 @@ def test_rasterizer_refuses_cpu_tensors():
         r(torch.zeros(4, 3), None, torch.zeros(4, 1), scales=torch.ones(4, 3), rotations=torch.zeros(4, 4))
     with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
         r(torch.zeros(4, 3), None, torch.zeros(4, 1), shs=torch.zeros(4, 16, 3), scales=torch.ones(4, 3))
+
+
+def test_new_entry_points_validate_before_any_launch():
+    """pgr_forward_layers_async / sem_masks / depth_mode / pgr_pack_records / pgr_scene_prepare: argument misuse is an
+    integer status from host-side checks (fake non-NULL device pointers are never dereferenced; no device is touched)."""
+    from pegasus_amd import _lib
+    lib = _lib.lib()
+    fake = C.c_void_p(0x1000)
+    scene = _lib.PgrScene(n=10, means3d=fake, opacities=fake, scales=fake, rotations=fake, shs=fake, sh_degree=0, sh_stride=1,
+                          scale_modifier=1.0)
+    cam = _lib.PgrCamera(image_width=64, image_height=64, tanfovx=0.5, tanfovy=0.5, viewmatrix=fake, projmatrix=fake,
+                         campos=fake, bg=fake, depth_mode=0)
+    scratch = (C.c_char * int(lib.pgr_host_scratch_bytes(1)))()
+    good_layers = _lib.PgrLayers(layer_id=fake, n_layers=3, mask_colors=fake, mask_threshold=0.1)
+
+    def layers_rc(layers, out, camera=cam):
+        return lib.pgr_forward_layers_async(C.byref(scene), C.byref(layers) if layers is not None else None, None, 1,
+                                            C.byref(camera), C.byref(out), None, 0, 100, scratch, len(scratch), None)
+    no_masks = _lib.PgrOutputs(color=fake, depth=fake)
+    with_masks = _lib.PgrOutputs(sem_masks=fake)
+    assert layers_rc(None, with_masks) == _lib.PGR_ERR_INVALID_ARGUMENT                       # no descriptor
+    assert layers_rc(good_layers, no_masks) == _lib.PGR_ERR_INVALID_ARGUMENT                  # a layered call's one output
+    for bad in (_lib.PgrLayers(layer_id=None, n_layers=3, mask_colors=fake), _lib.PgrLayers(layer_id=fake, n_layers=0, mask_colors=fake),
+                _lib.PgrLayers(layer_id=fake, n_layers=3, mask_colors=None), _lib.PgrLayers(layer_id=fake, n_layers=5000, mask_colors=fake)):
+        assert layers_rc(bad, with_masks) == _lib.PGR_ERR_INVALID_ARGUMENT
+    # everything valid but the workspace: the checks got that far without touching a device
+    assert layers_rc(good_layers, with_masks) == _lib.PGR_ERR_INVALID_ARGUMENT                # workspace == NULL
+    # depth_mode outside the enum
+    bad_cam = _lib.PgrCamera(image_width=64, image_height=64, tanfovx=0.5, tanfovy=0.5, viewmatrix=fake, projmatrix=fake,
+                             campos=fake, bg=fake, depth_mode=7)
+    need = C.c_int64(0)
+    out = _lib.PgrOutputs(color=fake, depth=fake, radii=fake)
+    assert lib.pgr_forward(C.byref(scene), C.byref(bad_cam), C.byref(out), None, 0, 100, C.byref(need), None) == _lib.PGR_ERR_INVALID_ARGUMENT
+    # masks from the compositor's epilogue need the colours to threshold against
+    sem = _lib.PgrSemantic(object_id=fake, colors=fake, n_env=5, k_objects=2)                 # no mask_colors
+    out_m = _lib.PgrOutputs(color=fake, depth=fake, sem_color=fake, sem_masks=fake)
+    assert lib.pgr_forward_frames_async(C.byref(scene), C.byref(sem), 1, C.byref(cam), C.byref(out_m), None, 0, 100, scratch,
+                                        len(scratch), None) == _lib.PGR_ERR_INVALID_ARGUMENT
+    # records: stride below the layout's size, unaligned stride, NULL destination
+    lay = _lib.PgrRecordLayout()
+    assert lib.pgr_frame_record_layout(16, 16, 8, C.byref(lay)) == 0
+    assert lib.pgr_pack_records(fake, fake, fake, 1, 8, 16, 16, fake, lay.bytes - 16, None) == _lib.PGR_ERR_INVALID_ARGUMENT
+    assert lib.pgr_pack_records(fake, fake, fake, 1, 8, 16, 16, fake, lay.bytes + 8, None) == _lib.PGR_ERR_INVALID_ARGUMENT
+    assert lib.pgr_pack_records(fake, fake, fake, 1, 8, 16, 16, None, lay.bytes, None) == _lib.PGR_ERR_INVALID_ARGUMENT
+    assert lib.pgr_pack_records(fake, fake, fake, 0, 8, 16, 16, fake, lay.bytes, None) == 0     # nothing to do
+    # scene_prepare: cache too small / missing out-pointers
+    p1, p2 = C.c_void_p(), C.c_void_p()
+    sc = _lib.PgrScene(n=1000, tie_index=fake)
+    assert lib.pgr_scene_prepare(C.byref(sc), None, fake, 16, C.byref(p1), C.byref(p2), None) == _lib.PGR_ERR_WORKSPACE_TOO_SMALL
+    assert lib.pgr_scene_prepare(C.byref(sc), None, fake, 1 << 20, None, C.byref(p2), None) == _lib.PGR_ERR_INVALID_ARGUMENT
+    empty = _lib.PgrScene(n=0)
+    assert lib.pgr_scene_prepare(C.byref(empty), None, None, 0, C.byref(p1), C.byref(p2), None) == 0 and not p1.value and not p2.value
