@@ -773,3 +773,48 @@ def test_scene_prepare_constants_match_the_per_call_path(gpu_device):
     torch.cuda.synchronize()
     for k in a:
         assert torch.equal(a[k], f[k]), k
+
+
+@pytest.mark.parametrize("n_views,env_switch", [(1, None), (2, None), (5, None), (5, "PGR_BIN_RECORDS"), (5, "PGR_BLOCK_CULL")])
+def test_layered_call_many_small_layers_and_unlayered_gaussians(gpu_device, monkeypatch, n_views, env_switch):
+    """pgr_forward_layers_async through the C ABI on a scene the FrameRenderer never builds: Gaussians that belong to NO
+    layer in front (layer id 0: dropped), then 37 small layers, so that binning chunks and 64-Gaussian groups straddle
+    several layers; one- and two-view calls (their own launch shapes) and the A/B switches.  Reference: every layer rendered
+    alone through the plain batch call + pgr_color_masks."""
+    import torch
+    from pegasus_amd import masks as M, rasterizer as R
+    if env_switch:
+        monkeypatch.setenv(env_switch, "0")
+    rng = np.random.default_rng(21)
+    K, per, n0 = 37, 333, 1500
+    n = n0 + K * per
+    xyz = np.concatenate([rng.normal(0, 0.25, (n0, 3)), np.concatenate([rng.normal(rng.uniform(-0.3, 0.3, 3), 0.05, (per, 3)) for _ in range(K)])]).astype(np.float32)
+    layer = np.concatenate([np.zeros(n0, np.int32), np.repeat(np.arange(1, K + 1, dtype=np.int32), per)])
+    scales = np.exp(rng.normal(np.log(0.01), 0.4, (n, 3))).astype(np.float32)
+    rots = rng.normal(size=(n, 4)).astype(np.float32); rots /= np.linalg.norm(rots, axis=1, keepdims=True)
+    opac = (1 / (1 + np.exp(-rng.normal(1.0, 1.5, n)))).astype(np.float32)
+    colors_np = M.generate_colors(K)
+    from pegasus_amd.sh_utils import RGB2SH
+    shs = RGB2SH(colors_np[np.maximum(layer, 1) - 1]).astype(np.float32).reshape(n, 1, 3)
+    _, views = scenes.scene_c3(scale=0.001, n_views=n_views, width=200, height=136)
+    dev = gpu_device
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    T = dict(xyz=t(xyz), op=t(opac), sc=t(scales), rot=t(rots), shs=t(shs), layer=t(layer), colors=t(colors_np))
+    bg = t(np.array([0.05, 0.0, 0.1], np.float32))
+    specs = [R.ViewSpec(v.height, v.width, v.tanfovx, v.tanfovy, bg, t(v.world_view_transform.astype(np.float32)),
+                        t(v.full_proj_transform.astype(np.float32)), t(v.camera_center.astype(np.float32))) for v in views]
+    H, W = views[0].height, views[0].width
+    out = torch.full((n_views, K, H, W), 9, dtype=torch.uint8, device=dev)
+    h = R.forward_views(T["xyz"], T["op"], specs, shs=T["shs"], scales=T["sc"], rotations=T["rot"], sh_degree=0, want_radii=False,
+                        outputs=[dict(radii=None, sem_masks=out[i]) for i in range(n_views)], async_slot=("layered-test", n_views),
+                        layers=dict(layer_id=T["layer"], n_layers=K, mask_colors=T["colors"], mask_threshold=0.1))
+    h.wait()
+    torch.cuda.synchronize()
+    assert int((out > 1).sum()) == 0                                   # every pixel of every plane was written
+    for k in range(1, K + 1):
+        s = slice(n0 + (k - 1) * per, n0 + k * per)
+        res = R.forward_views(T["xyz"][s], T["op"][s], specs, shs=T["shs"][s], scales=T["sc"][s], rotations=T["rot"][s],
+                              sh_degree=0, want_radii=False)
+        want = torch.stack([M.color_masks(r["color"], T["colors"][k - 1:k], 0.1)[0] for r in res])
+        assert torch.equal(out[:, k - 1], want), f"layer {k}"
+    assert int(out.sum()) > 0
