@@ -876,7 +876,8 @@ def drop_in_numbers(eng, n_frames=4, n_render_calls=48):
     bg = torch.zeros(3, device=dev)
     H, W = eng.H, eng.W
 
-    parts = {"compose": 0.0, "render_rgb_and_depth": 0.0, "render_visib_mask": 0.0, "render_semanticsegmentation_mask": 0.0}
+    parts = {"compose": 0.0, "render_rgb_and_depth": 0.0, "render_visib_mask": 0.0, "render_semanticsegmentation_mask": 0.0,
+             "render_silhouette_mask": 0.0}
 
     def lap(name, t_prev):
         torch.cuda.synchronize()
@@ -884,7 +885,7 @@ def drop_in_numbers(eng, n_frames=4, n_render_calls=48):
         parts[name] += now - t_prev
         return now
 
-    def frame(cam, clock=False):
+    def frame(cam, clock=False, silhouettes=False):
         t = time.perf_counter()
         scene = copy.deepcopy(env)                                   # pegasus.py:255-264
         for obj in objects.values():
@@ -898,6 +899,9 @@ def drop_in_numbers(eng, n_frames=4, n_render_calls=48):
         t = lap("render_visib_mask", t) if clock else t
         sem = RW.render_semanticsegmentation_mask(cam, env, objects, color_set, H, W, pipe, bg, False)
         t = lap("render_semanticsegmentation_mask", t) if clock else t
+        if silhouettes or clock:                                     # 'seg_sil' (pegasus.py:491's fifth data point)
+            sil = RW.render_silhouette_mask(cam, objects, env, W, H, color_set, pipe, bg)
+            t = lap("render_silhouette_mask", t) if clock else t
         return scene
 
     with torch.no_grad():
@@ -908,6 +912,13 @@ def drop_in_numbers(eng, n_frames=4, n_render_calls=48):
             scene = frame(c)
         torch.cuda.synchronize()
         t_frame = (time.perf_counter() - t0) / n_frames
+        frame(cams[0], silhouettes=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for c in cams[1:n_frames + 1]:                               # all five default data points: + the K silhouettes
+            frame(c, silhouettes=True)
+        torch.cuda.synchronize()
+        t_frame_all = (time.perf_counter() - t0) / n_frames
         for c in cams[1:n_frames + 1]:                               # once more with a synchronisation after every part
             frame(c, clock=True)
         for c in cams[:4]:
@@ -919,11 +930,13 @@ def drop_in_numbers(eng, n_frames=4, n_render_calls=48):
         torch.cuda.synchronize()
         t_call = (time.perf_counter() - t0) / min(n_render_calls, len(cams))
     return {"frames_per_s": round(1.0 / t_frame, 2), "ms_per_frame": round(t_frame * 1e3, 3),
+            "frames_per_s_all_data_points": round(1.0 / t_frame_all, 2),
             "render_call_ms": round(t_call * 1e3, 4), "render_calls_per_s": round(1.0 / t_call, 1),
             "ms_per_part": {k: round(v / n_frames * 1e3, 3) for k, v in parts.items()},
             "frame": "deepcopy + merge of the scene, render_rgb_and_depth, render_visib_mask (K masks to the host as float64, "
                      "as the reference returns them) and render_semanticsegmentation_mask -- the ['rgb','seg_vis','sem_seg'] "
-                     "data points of /root/reference/pegasus.py:254-358, one camera per frame.  STATIC scene: the two semantic "
+                     "data points of /root/reference/pegasus.py:254-358, one camera per frame (frames_per_s_all_data_points: + "
+                     "render_silhouette_mask, 'seg_sil': all K objects in one layered call, K float64 masks to the host).  STATIC scene: the two semantic "
                      "wrappers share one objects-only scene and one render per camera, kept while no object moves; a dynamic "
                      "run rebuilds that scene every frame and is slower than this figure",
             "sample": f"{n_frames} frames, {min(n_render_calls, len(cams))} render() calls; same scene and cameras as the batch path"}

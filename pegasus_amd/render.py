@@ -44,7 +44,44 @@ def _without_environment(scene, n_env):
 
 
 def render_silhouette_mask(cam, gs_object_list, gs_env, width, height, color_set, pipe_settings, bg):
-    """One single-object render per object over an EMPTY environment (render.py:36-65)."""
+    """Every object rendered ALONE in its semantic colour over an empty environment and thresholded (render.py:36-65: one
+    deepcopy + merge + render per object).  Here: ONE layered rasterizer call for all objects (pgr_forward_layers_async:
+    per-(tile, object) lists, the compositor's epilogue thresholds layer k against colour k) over the objects-only scene
+    the other two semantic wrappers share -- bit-equal to the per-object form below, which stays as the path for the
+    settings the layered call does not take (python-side covariances / SH, autograd, object ids that do not ascend)."""
+    ids = list(gs_object_list.keys())
+    plain = (not torch.is_grad_enabled() and not getattr(pipe_settings, "compute_cov3D_python", False)
+             and not getattr(pipe_settings, "convert_SHs_python", False) and ids == sorted(ids) and len(ids) > 0
+             and min(ids) >= 1 and max(ids) <= int(color_set.shape[0]))
+    if not plain:
+        return _render_silhouette_mask_per_object(cam, gs_object_list, gs_env, width, height, color_set, pipe_settings, bg)
+    import math
+    from . import rasterizer as R
+    from .gaussian_renderer import _kept
+    scene, key = _semantic_scene(gs_env, gs_object_list)
+    dev = scene._xyz.device
+    K = int(color_set.shape[0])
+    layer_id = _kept_scene.get("layer_id") if key is not None else None
+    if layer_id is None:
+        layer_id = torch.cat([torch.full((int(gs_object_list[i]._xyz.shape[0]),), int(i), dtype=torch.int32, device=dev)
+                              for i in ids])
+        if key is not None:
+            _kept_scene["layer_id"] = layer_id
+    spec = R.ViewSpec(int(cam.image_height), int(cam.image_width), math.tan(0.5 * cam.FoVx), math.tan(0.5 * cam.FoVy), bg,
+                      cam.world_view_transform, cam.full_proj_transform, cam.camera_center)
+    out = torch.empty((K, int(cam.image_height), int(cam.image_width)), dtype=torch.uint8, device=dev)
+    colors = torch.as_tensor(color_set, device=dev).float().contiguous()
+    h = R.forward_views(scene.get_xyz, _kept(scene, "get_opacity"), [spec], shs=_kept(scene, "get_features"),
+                        scales=_kept(scene, "get_scaling"), rotations=_kept(scene, "get_rotation"),
+                        sh_degree=int(scene.active_sh_degree), want_radii=False, outputs=[dict(radii=None, sem_masks=out)],
+                        async_slot=("drop-in-silhouette", 0),
+                        layers=dict(layer_id=layer_id, n_layers=K, mask_colors=colors, mask_threshold=M.MASK_THRESHOLD))
+    h.wait()
+    return _to_host(out.permute(1, 2, 0).to(torch.float64)).numpy()
+
+
+def _render_silhouette_mask_per_object(cam, gs_object_list, gs_env, width, height, color_set, pipe_settings, bg):
+    """One single-object render per object over an EMPTY environment (render.py:36-65), as the reference does it."""
     black = _without_environment(copy.deepcopy(gs_env), gs_env._xyz.shape[0])
     mask_silhouette = np.zeros((height, width, color_set.shape[0]))
     for gs_object_id, current in gs_object_list.items():

@@ -90,7 +90,12 @@ def test_render_facade_and_mask_wrappers(oracle, gpu_device):
         assert vis.sum() > 100
 
         sil = prender.render_silhouette_mask(cam, objs, env, W, H, colors, pipe, bg)
-        assert sil.shape == (H, W, 2)
+        assert sil.shape == (H, W, 2) and sil.dtype == np.float64
+        # the layered call (all objects in one pass) against the reference's form: one render per object, bit for bit
+        np.testing.assert_array_equal(sil, prender._render_silhouette_mask_per_object(cam, objs, env, W, H, colors, pipe, bg))
+        white = torch.ones(3, device=dev)
+        np.testing.assert_array_equal(prender.render_silhouette_mask(cam, objs, env, W, H, colors, pipe, white),
+                                      prender._render_silhouette_mask_per_object(cam, objs, env, W, H, colors, pipe, white))
         assert (sil.sum(axis=(0, 1)) >= vis.sum(axis=(0, 1)) * 0.98).all()   # a silhouette covers the visible part
         sem = prender.render_semanticsegmentation_mask(cam, env, objs, colors, H, W, pipe, bg, False)
         assert sem.dtype == np.uint8 and sem.shape == (H, W, 3)
