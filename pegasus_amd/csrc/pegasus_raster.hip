@@ -22,6 +22,9 @@
 #include "pgr_common.h"
 #include "preprocess.hip.h"
 #include "tilebin.hip.h"
+#ifdef PGR_REACH_BITS
+#include "composite_reach.hip.h"      // experiment build only (round 4: reach bits per quarter; measured negative)
+#endif
 
 namespace pgr {
 
@@ -385,6 +388,10 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
             bin_table, L.tiles, sort_queue + qs, n_queue + 1);
     }
     tile_sort_kernel<<<items, SORT_THREADS, 0, stream>>>(bin_table, L.tiles, sort_queue, n_queue);
+#ifdef PGR_REACH_BITS
+    const bool reach_path = !want_sem && !layers && getenv("PGR_REACH") && getenv("PGR_REACH")[0] == '1';
+    if (reach_path) reach_bits_kernel<<<dim3(L.tiles, n_views), 256, 0, stream>>>(view_table, L.tiles, bin_table);
+#endif
     mark(4);
     // ---- stage 4: compositing of every (view, tile, quarter) work item in ONE launch; with `semantic` the same
     // walk also produces the objects-only semantic image
@@ -402,6 +409,12 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         sd = SemanticDev{semantic->object_id, ids_u8, semantic->colors, semantic->n_env, semantic->k_objects,
                          semantic->mask_colors, semantic->mask_threshold, layer_tiles};
     }
+#ifdef PGR_REACH_BITS
+    if (reach_path) {
+        if (want_aux) composite_reach_kernel<true><<<slots, WAVE, 0, stream>>>(view_table, items_per_view, work_order, bin_table);
+        else composite_reach_kernel<false><<<slots, WAVE, 0, stream>>>(view_table, items_per_view, work_order, bin_table);
+    } else
+#endif
     if (layers) {
         sd.mask_colors = layers->mask_colors; sd.mask_thr = layers->mask_threshold; sd.k = n_layers;
         // empty (layer, tile) lists have no work item: their pixels hold the background's verdict
