@@ -98,9 +98,10 @@ class BopSceneWriter:
         else:
             batch_futures.append(self._pool.submit(self._write, path, image))
 
-    def add_batch(self, frames: dict, scene_gt: dict, scene_camera: dict, n: int = None, silhouettes=None):
+    def add_batch(self, frames: dict, scene_gt: dict, scene_camera: dict, n: int = None, silhouettes=None, frame_ids=None):
         """``frames``: FrameRenderer output (color, depth, and with masks: seg, masks); ``silhouettes``: uint8 [B,K,H,W]
-        of FrameRenderer.render_silhouettes (or frames["sil"]) -> the mask/ directory."""
+        of FrameRenderer.render_silhouettes (or frames["sil"]) -> the mask/ directory.  ``frame_ids``: the frames' numbers in
+        the dataset (default: consecutive) -- a view-sharded run gives every rank's writer the GLOBAL ids of its frames."""
         from . import masks as M
         n = frames["color"].shape[0] if n is None else n
         # GPU: uint8 HWC / uint16 millimetres for the whole batch in one launch (pgr_pack_frames), then ONE device->host copy
@@ -115,7 +116,7 @@ class BopSceneWriter:
         sil = (silhouettes[:n] * 255).cpu().numpy() if silhouettes is not None else None
         futures = []
         for i in range(n):
-            fid = self.n_frames
+            fid = self.n_frames if frame_ids is None else int(frame_ids[i])
             self._submit(self.scene / "rgb" / f"{fid:06d}.png", rgb8[i], futures)
             self._submit(self.scene / "depth" / f"{fid:06d}.png", mm[i], futures)
             if mk is not None:
@@ -135,13 +136,26 @@ class BopSceneWriter:
                 for f in self._pending.pop(0):
                     f.result()                       # re-raises a writer's exception here
 
-    def close(self):
+    def close(self, write_json: bool = True):
+        """Waits for the PNG tasks; writes scene_gt.json / scene_camera.json unless ``write_json`` is False (a view-sharded
+        run merges the ranks' records first: ``merge_records``)."""
         for batch in self._pending:
             for f in batch:
                 f.result()
         self._pending = []
         if self._pool is not None:
             self._pool.shutdown(wait=True)
-        (self.scene / "scene_gt.json").write_text(json.dumps(self.scene_gt))
-        (self.scene / "scene_camera.json").write_text(json.dumps(self.scene_camera))
+        if write_json:
+            self.write_records()
         return self.scene
+
+    def merge_records(self, others):
+        """Adds the (scene_gt, scene_camera) dict pairs of other ranks' writers (disjoint frame ids)."""
+        for gt, cam in others:
+            self.scene_gt.update(gt)
+            self.scene_camera.update(cam)
+
+    def write_records(self):
+        order = lambda d: {k: d[k] for k in sorted(d, key=int)}
+        (self.scene / "scene_gt.json").write_text(json.dumps(order(self.scene_gt)))
+        (self.scene / "scene_camera.json").write_text(json.dumps(order(self.scene_camera)))

@@ -312,3 +312,34 @@ def test_semantic_wrappers_follow_objects_cameras_and_backgrounds(gpu_device):
             prender._kept_scene.clear()
             prender._kept_scene.update(saved)
             assert same(warm, cold), step
+
+
+@pytest.mark.gpu
+def test_generate_view_sharded_over_two_ranks_writes_the_same_dataset(gpu_device, tmp_path):
+    """python -m pegasus_amd.generate under torchrun: frame f -> rank f mod 2, every rank renders and WRITES its own frames
+    under their global numbers, only the pose records travel (gloo, Python objects).  The dataset equals the one a single
+    process writes: every PNG byte for byte, both JSON files."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    flags = ["--frames", "7", "--batch", "3", "--scale", "0.01", "--size", "128", "--dynamic"]
+    env = {k: v for k, v in __import__("os").environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    one, two = tmp_path / "one", tmp_path / "two"
+    r = subprocess.run([sys.executable, "-m", "pegasus_amd.generate", "--out", str(one), *flags], cwd=str(root), env=env,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "-m", "pegasus_amd.generate", "--out", str(two), *flags], cwd=str(root), env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    files = sorted(p.relative_to(one) for p in one.rglob("*") if p.is_file())
+    assert files == sorted(p.relative_to(two) for p in two.rglob("*") if p.is_file()) and len(files) == 7 * (3 + 16) + 2
+    for f in files:
+        if f.suffix == ".png":
+            assert (one / f).read_bytes() == (two / f).read_bytes(), f
+        else:
+            assert json.loads((one / f).read_text()) == json.loads((two / f).read_text()), f

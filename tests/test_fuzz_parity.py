@@ -132,3 +132,29 @@ def test_fused_semantic_with_aux_outputs(gpu_device):
             assert torch.equal(both[i][k], plain[i][k]), (i, k)
         assert torch.equal(both[i]["sem_color"], frames["seg"][i]) and torch.equal(both[i]["sem_depth"], frames["seg_depth"][i])
     assert float(frames["seg"].std()) > 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_merged_scenes_layered_silhouettes_equal_per_object_passes(gpu_device, seed):
+    """The layered silhouette pass (per-(tile, object) lists, masks from the compositor's epilogue, empty lists pre-filled) on
+    the same random merged scenes: bit-equal to one single-object pass + mask launch per object -- any object count, object
+    splats fat enough to cover many tiles, translucent objects (edge quarters that never saturate), random backgrounds."""
+    import torch
+    from pegasus_amd import frames as F
+    rng = np.random.default_rng(900 + seed)
+    k_obj = int(rng.integers(1, 10))
+    n_env, n_obj = int(rng.choice([300, 3000])), int(rng.choice([50, 700, 5000]))
+    W, H = int(rng.choice([96, 200, 333])), int(rng.choice([64, 150, 240]))
+    cloud, views, _ = scenes.merged_scene(140 + seed, n_env, k_obj, n_obj, 4, W, H, plane_size=float(rng.choice([0.6, 2.0])))
+    act = cloud.activated()
+    if seed % 2:
+        act["opacities"][cloud.object_id > 0] *= np.float32(0.2)
+    if seed % 3 == 0:
+        act["scales"][cloud.object_id > 0] *= np.float32(5.0)
+    fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"], cloud.object_id,
+                         sh_degree=3, device=gpu_device, bg=tuple(rng.random(3).astype(np.float32)))
+    specs = [fr.view_spec(v) for v in views]
+    a = fr.render_silhouettes(specs).clone()
+    b = fr.render_silhouettes_per_object(specs).clone()
+    torch.cuda.synchronize()
+    assert a.shape == (4, k_obj, H, W) and torch.equal(a, b), seed
