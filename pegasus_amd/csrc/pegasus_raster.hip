@@ -212,11 +212,13 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], stream); };
     // every argument check happens here, before the first enqueue: an early return below this block would leave work
     // on the stream that still reads the (pageable) table staging of the synchronous path
-    if (posed && (!posed->object_id || !posed->poses || posed->k_objects <= 0 || (scene && scene->cov3d_precomp)))
+    // (per-Gaussian arrays of an EMPTY scene may be NULL: torch hands out a null pointer for an empty tensor)
+    const bool empty = scene && scene->n == 0;
+    if (posed && ((!posed->object_id && !empty) || !posed->poses || posed->k_objects <= 0 || (scene && scene->cov3d_precomp)))
         return PGR_ERR_INVALID_ARGUMENT;
-    if (semantic && (!semantic->object_id || !semantic->colors || semantic->n_env < 0 || semantic->k_objects <= 0))
+    if (semantic && ((!semantic->object_id && !empty) || !semantic->colors || semantic->n_env < 0 || semantic->k_objects <= 0))
         return PGR_ERR_INVALID_ARGUMENT;
-    if (layers && (semantic || !layers->layer_id || !layers->mask_colors || layers->n_layers <= 0 || layers->n_layers > 4096))
+    if (layers && (semantic || (!layers->layer_id && !empty) || !layers->mask_colors || layers->n_layers <= 0 || layers->n_layers > 4096))
         return PGR_ERR_INVALID_ARGUMENT;
     if (n_views <= 0 || !cams || !outs) return PGR_ERR_INVALID_ARGUMENT;
     if (num_instances) for (int v = 0; v < n_views; ++v) num_instances[v] = 0;

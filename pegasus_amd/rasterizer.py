@@ -155,6 +155,7 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
         return []
     H, W = int(views[0].image_height), int(views[0].image_width)
     n = int(means3D.shape[0])
+    means3D_in, opacities_in = means3D, opacities      # (an empty scene converts to None = NULL pointers: re-entrant calls get the originals)
     means3D = dev_f32(means3D, device)
     opacities = dev_f32(opacities, device)
     shs = dev_f32(shs, device)
@@ -235,7 +236,7 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
                       want_radii=want_radii, want_aux=want_aux, outputs=results, semantic=semantic, posed=posed,
                       tie_index=tie_index, tie_inv=tie_inv)
             for _attempt in range(3):
-                pb = forward_views(means3D, opacities, views, async_slot="sync-fused", **kw)
+                pb = forward_views(means3D_in, opacities_in, views, async_slot="sync-fused", **kw)
                 pb._redo = None
                 pb._event.synchronize()
                 need = (C.c_int64 * nv)()
@@ -278,10 +279,10 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
                   tie_index=tie_index, tie_inv=tie_inv)
         if layers is not None:          # a layered call is asynchronous only: the retry after an overflow is one too
             def redo():
-                pb2 = forward_views(means3D, opacities, views, async_slot=async_slot, layers=layers, **kw)
+                pb2 = forward_views(means3D_in, opacities_in, views, async_slot=async_slot, layers=layers, **kw)
                 return pb2.wait()
         else:
-            redo = lambda: forward_views(means3D, opacities, views, **kw)
+            redo = lambda: forward_views(means3D_in, opacities_in, views, **kw)
         pb = PendingBatch(results, ev, scratch, nv, key, max_inst, redo)
         pb._keep = (keep, ws, cams, outs, scene)
         return pb

@@ -818,3 +818,28 @@ def test_layered_call_many_small_layers_and_unlayered_gaussians(gpu_device, monk
         want = torch.stack([M.color_masks(r["color"], T["colors"][k - 1:k], 0.1)[0] for r in res])
         assert torch.equal(out[:, k - 1], want), f"layer {k}"
     assert int(out.sum()) > 0
+
+
+def test_empty_scene_layered_and_fused_masks_stay_zero(gpu_device):
+    """N = 0 (SURVEY.md 8a "Edge cases": outputs stay zero-filled, no background) for the two outputs round 4 added: the
+    layered call's mask planes and the fused call's sem_masks."""
+    import torch
+    from pegasus_amd import rasterizer as R
+    dev = gpu_device
+    z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=dev)
+    spec = R.ViewSpec(48, 64, 0.5, 0.5, torch.ones(3, device=dev), torch.eye(4, device=dev), torch.eye(4, device=dev), z(3))
+    colors = torch.tensor([[1.0, 1.0, 1.0], [0.2, 0.4, 0.6]], device=dev)        # colour 0 IS the background: still zeros
+    planes = torch.full((2, 48, 64), 7, dtype=torch.uint8, device=dev)
+    R.forward_views(z(0, 3), z(0, 1), [spec], shs=z(0, 1, 3), scales=z(0, 3), rotations=z(0, 4), sh_degree=0, want_radii=False,
+                    outputs=[dict(radii=None, sem_masks=planes)], async_slot=("empty-layered", 0),
+                    layers=dict(layer_id=z(0, dt=torch.int32), n_layers=2, mask_colors=colors, mask_threshold=0.1)).wait()
+    torch.cuda.synchronize()
+    assert int(planes.sum()) == 0
+    out = dict(color=torch.full((3, 48, 64), 5.0, device=dev), depth=torch.full((1, 48, 64), 5.0, device=dev), radii=None,
+               sem_color=torch.full((3, 48, 64), 5.0, device=dev), sem_depth=torch.full((1, 48, 64), 5.0, device=dev),
+               sem_masks=torch.full((2, 48, 64), 7, dtype=torch.uint8, device=dev))
+    sem = dict(object_id=z(0, dt=torch.int32), colors=colors, n_env=0, k=2, mask_colors=colors, mask_threshold=0.1)
+    R.forward_views(z(0, 3), z(0, 1), [spec], shs=z(0, 1, 3), scales=z(0, 3), rotations=z(0, 4), sh_degree=0, want_radii=False,
+                    outputs=[out], semantic=sem)
+    torch.cuda.synchronize()
+    assert all(float(out[k].float().abs().max()) == 0.0 for k in ("color", "depth", "sem_color", "sem_depth", "sem_masks"))
