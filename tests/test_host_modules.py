@@ -352,3 +352,31 @@ def test_network_gui_round_trip_over_loopback():
     assert client.recv(16) == struct.pack("<i", 1) + b"x"
     client.close()
     network_gui.conn = None                                # what the loop does after a dropped connection
+
+
+def test_record_views_slice_any_record_tensor_without_copying():
+    """masks.record_views on host memory (what rank 0 / a writer holds after the gather): [world, B, bytes] and [B, world, bytes]
+    (the transposed global view) slice into the three images as views of the same storage."""
+    import torch
+    from pegasus_amd import masks as M
+    H, W, K = 6, 10, 11
+    lay = M.record_layout(H, W, K)
+    P, J = H * W, (K + 7) // 8
+    world, B = 3, 2
+    buf = torch.zeros((world, B, lay["bytes"]), dtype=torch.uint8)
+    rng = np.random.default_rng(0)
+    rgb = torch.from_numpy(rng.integers(0, 256, (world, B, H, W, 3), dtype=np.uint8))
+    depth = torch.from_numpy(rng.integers(-2**15, 2**15, (world, B, H, W), dtype=np.int16))
+    bits = torch.from_numpy(rng.integers(0, 256, (world, B, H, W, J), dtype=np.uint8))
+    buf[..., :3 * P] = rgb.reshape(world, B, -1)
+    buf[..., lay["off_depth"]:lay["off_depth"] + 2 * P] = depth.reshape(world, B, -1).view(torch.uint8)
+    buf[..., lay["off_masks"]:lay["off_masks"] + J * P] = bits.reshape(world, B, -1)
+    for t, perm in ((buf, lambda x: x), (buf.transpose(0, 1), lambda x: x.transpose(0, 1))):
+        v = M.record_views(t, H, W, K)
+        assert torch.equal(v["rgb"], perm(rgb)) and torch.equal(v["depth_mm"], perm(depth)) and torch.equal(v["mask_bits"], perm(bits))
+        assert v["rgb"].data_ptr() == buf.data_ptr() and v["depth_mm"].dtype == torch.int16
+    # masks unpack to [.., K, H, W] planes
+    planes = M.unpack_mask_bits(M.record_views(buf[0], H, W, K)["mask_bits"], K)
+    assert planes.shape == (B, K, H, W)
+    for m in range(K):
+        assert torch.equal(planes[:, m], (bits[0, ..., m // 8] >> (m % 8)) & 1)
