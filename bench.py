@@ -298,9 +298,13 @@ class RealEngine:
         batch comes close to it (a multi-GB reallocation, tens of ms, once per scene and pipeline slot); small scenes start
         below their need and would otherwise pay that inside the timed region."""
         from pegasus_amd import rasterizer
+        # over the SAME batches the warm-up and the timed region run: a later batch with more instances than the first few
+        # (other cameras, other time steps of a dynamic sequence) would otherwise grow the workspace inside a timed repeat
+        # (round 4: one of five repeats of the dynamic runs took 8.3 instead of 5.4 ms per step)
+        n = max(2, self.n_slots, self.args.warmup + self.args.steps)
         for _ in range(3):
             before = dict(rasterizer._WS.capacity_hint)
-            run_steps(0, max(2, self.n_slots), False)     # every slot: its stream, workspace and frame set exist after this
+            run_steps(0, n, False)                        # every slot: its stream, workspace and frame set exist after this
             self.sync()
             if dict(rasterizer._WS.capacity_hint) == before:
                 break
@@ -554,6 +558,13 @@ def run_worker(args):
 
     eng.settle(run_steps)
     run_steps(0, args.warmup, gather_on)
+    # The scene, 512+ view specs and the workspaces are thousands of long-lived Python objects; the per-batch host work of a
+    # dynamic run (pose tables, BOP records: dicts of lists) allocates enough containers to trigger full collections, each of
+    # which walks all of them -- one repeat in five took 8 instead of 5.4 ms per step.  Everything alive now is set-up:
+    # move it out of the collector's sight.
+    import gc
+    gc.collect()
+    gc.freeze()
     repeats = max(1, args.repeats)
     gstat.update(host_s=0.0, wire_s=0.0, batches=0)
     runs = [timed(args.warmup, args.steps, gather_on) for _ in range(repeats)]
