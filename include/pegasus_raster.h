@@ -111,6 +111,12 @@ typedef struct PgrOutputs {
                                     the compositor's epilogue from the pixel it holds in registers -- needs
                                     PgrSemantic::mask_colors.  In a LAYERED call (pgr_forward_layers_async) the one output:
                                     [n_layers,H,W], plane k = layer k's image against mask_colors[k]. */
+    uint8_t *record;             /* optional: this view's FRAME RECORD (PgrRecordLayout below: uint8 rgb | uint16 depth mm |
+                                    mask bit planes, pgr_frame_record_layout(width, height, K) bytes), written by the
+                                    compositor's epilogue from the pixel it holds in registers -- bit for bit what
+                                    pgr_pack_records makes of color / depth / sem_masks, without the pass that re-reads them.
+                                    K = the semantic descriptor's k_objects when it carries mask_colors, else 0 (no mask
+                                    section).  What leaves the GPU for a finished frame (gather to the root rank, writers). */
 } PgrOutputs;
 
 /* Fused semantic pass: PEGASUS renders the objects alone, painted in flat semantic colours, to derive masks

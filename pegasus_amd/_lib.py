@@ -44,7 +44,7 @@ class PgrCamera(C.Structure):
 class PgrOutputs(C.Structure):
     _fields_ = [("color", C.c_void_p), ("depth", C.c_void_p), ("radii", C.c_void_p), ("final_T", C.c_void_p),
                 ("n_contrib", C.c_void_p), ("sem_color", C.c_void_p), ("sem_depth", C.c_void_p),
-                ("sem_masks", C.c_void_p)]
+                ("sem_masks", C.c_void_p), ("record", C.c_void_p)]
 
 
 class PgrSemantic(C.Structure):

@@ -35,6 +35,7 @@ struct alignas(16) ViewEntry {
     float* sem_depth;            // [H,W] objects-only depth (or NULL)
     const uint32_t* obj_last;    // [tiles] 1 + position of the last object entry of each sorted list (tile sort)
     uint8_t* sem_masks;          // [K,H,W] colour-distance masks of the semantic image / (layered call) of the layers, or NULL
+    uint8_t* record;             // the view's frame record (rgb u8 | depth u16 mm | mask bit planes), or NULL
 };
 static_assert(sizeof(ViewEntry) == 112, "ViewEntry layout");
 
@@ -56,10 +57,14 @@ struct SemanticDev {
 
 // One pixel against colours [c0, c1): masks[c, pix] = || (r,g,b) - colors[c] ||_2 <= thr with the arithmetic of
 // color_masks_kernel below, bit for bit (same expression tree; the wave-wide shortcut only skips work whose result is
-// known).  Every lane of the wave calls it; `inside` lanes store.
+// known).  Every lane of the wave calls it; `inside` lanes store.  masks == NULL: no planes.  rec_masks != NULL: the same
+// verdicts also go into the frame record's bit planes (byte j of a pixel = masks 8j .. 8j+7; c0 must be 0 then).
 __device__ __forceinline__ void pixel_masks(float r, float g, float b, const float* __restrict__ colors, int c0, int c1,
-                                            float thr, uint8_t* __restrict__ masks, size_t P, size_t pix, bool inside) {
+                                            float thr, uint8_t* __restrict__ masks, size_t P, size_t pix, bool inside,
+                                            uint8_t* __restrict__ rec_masks = nullptr) {
     const float far = thr * 1.000001f;
+    const int bytes = (c1 + 7) >> 3;
+    uint32_t bits = 0;
     for (int c = c0; c < c1; ++c) {
         const float d0 = r - colors[3 * c], d1 = g - colors[3 * c + 1], d2 = b - colors[3 * c + 2];
         const bool surely_out = fabsf(d0) > far || fabsf(d1) > far || fabsf(d2) > far;
@@ -68,9 +73,27 @@ __device__ __forceinline__ void pixel_masks(float r, float g, float b, const flo
             const float dist = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
             m = dist <= thr ? 1 : 0;
         }
-        if (inside) gstore(masks + (size_t)c * P + pix, m);
+        if (masks && inside) gstore(masks + (size_t)c * P + pix, m);
+        if (rec_masks) {
+            bits |= (uint32_t)m << (c & 7);
+            if ((c & 7) == 7 || c == c1 - 1) {
+                if (inside) gstore(rec_masks + pix * (size_t)bytes + (size_t)(c >> 3), (uint8_t)bits);
+                bits = 0;
+            }
+        }
     }
 }
+
+// the two casts of a frame record (pack_records_kernel's, bit for bit): uint8(v * 255) wrapping, uint16(d * 1000) wrapping
+__device__ __forceinline__ uint8_t quant_u8(float v) {
+    v = fminf(fmaxf(v * 255.0f, -2147483520.0f), 2147483520.0f);
+    return (uint8_t)((int)v & 0xFF);
+}
+__device__ __forceinline__ uint16_t quant_mm(float d) {
+    d = fminf(fmaxf(d * 1000.0f, -2147483520.0f), 2147483520.0f);
+    return (uint16_t)((int)d & 0xFFFF);
+}
+__device__ __forceinline__ size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -436,14 +459,25 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
                     layer + 1, sem.mask_thr, ve.sem_masks, P, pix, inside);
         return;
     }
+    // the frame record: what leaves the GPU for this view, from the registers that hold the pixel (no pass re-reads the images)
+    uint8_t* const rec = ve.record;
+    const size_t rec_depth = align16(3 * P), rec_masks = rec_depth + align16(2 * P);
     if (inside) {
-        gstore(o.color + 0 * P + pix, fmaf(T, cam.bg[0], Crg.x));
-        gstore(o.color + 1 * P + pix, fmaf(T, cam.bg[1], Crg.y));
-        gstore(o.color + 2 * P + pix, fmaf(T, cam.bg[2], Cbd.x));
-        if (o.depth) gstore(o.depth + pix, depth_out(Cbd.y, T));
+        const float cr = fmaf(T, cam.bg[0], Crg.x), cg = fmaf(T, cam.bg[1], Crg.y), cb = fmaf(T, cam.bg[2], Cbd.x);
+        const float dd = depth_out(Cbd.y, T);
+        gstore(o.color + 0 * P + pix, cr);
+        gstore(o.color + 1 * P + pix, cg);
+        gstore(o.color + 2 * P + pix, cb);
+        if (o.depth) gstore(o.depth + pix, dd);
         if (AUX) {
             if (o.final_T) gstore(o.final_T + pix, T);
             if (o.n_contrib) gstore(o.n_contrib + pix, last);
+        }
+        if (rec) {
+            gstore(rec + 3 * pix + 0, quant_u8(cr));
+            gstore(rec + 3 * pix + 1, quant_u8(cg));
+            gstore(rec + 3 * pix + 2, quant_u8(cb));
+            gstore(reinterpret_cast<uint16_t*>(rec + rec_depth + 2 * pix), quant_mm(dd));
         }
     }
     if (want_sem || sem_background) {
@@ -459,8 +493,9 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
             if (ve.sem_depth) gstore(ve.sem_depth + pix, want_sem ? depth_out(Sbd.y, Ts) : 0.0f);
         }
         // the K masks of that pixel, from the registers that hold it (round 3: a separate pass re-read 12 P bytes per view)
-        if (ve.sem_masks && sem.mask_colors)
-            pixel_masks(sr, sg, sb, sem.mask_colors, 0, sem.k, sem.mask_thr, ve.sem_masks, P, pix, inside);
+        if ((ve.sem_masks || rec) && sem.mask_colors)
+            pixel_masks(sr, sg, sb, sem.mask_colors, 0, sem.k, sem.mask_thr, ve.sem_masks, P, pix, inside,
+                        rec ? rec + rec_masks : nullptr);
     }
 }
 

@@ -188,6 +188,10 @@ static int zero_outputs(const PgrOutputs* out, size_t P, hipStream_t stream, int
         return PGR_ERR_LAUNCH_FAILURE;
     if (out->sem_masks && n_masks > 0 && !hip_ok(hipMemsetAsync(out->sem_masks, 0, (size_t)n_masks * P, stream), "memset masks"))
         return PGR_ERR_LAUNCH_FAILURE;
+    if (out->record) {
+        const size_t bytes = align_up(3 * P, 16) + align_up(2 * P, 16) + align_up((size_t)((n_masks + 7) / 8) * P, 16);
+        if (!hip_ok(hipMemsetAsync(out->record, 0, bytes, stream), "memset record")) return PGR_ERR_LAUNCH_FAILURE;
+    }
     if (out->final_T && !hip_ok(hipMemsetAsync(out->final_T, 0, P * sizeof(float), stream), "memset T"))
         return PGR_ERR_LAUNCH_FAILURE;
     if (out->n_contrib && !hip_ok(hipMemsetAsync(out->n_contrib, 0, P * sizeof(uint32_t), stream), "memset n"))
@@ -245,7 +249,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     // N == 0: outputs stay zero-filled, no background (SURVEY.md section 8a "Edge cases")
     if (N == 0) {
         for (int v = 0; v < n_views; ++v)
-            if (int rc = zero_outputs(&outs[v], P, stream, layers ? n_layers : (semantic ? semantic->k_objects : 0))) return rc;
+            if (int rc = zero_outputs(&outs[v], P, stream, layers ? n_layers : (semantic && semantic->mask_colors ? semantic->k_objects : 0))) return rc;
         return PGR_OK;
     }
 
@@ -296,6 +300,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         e.sem_depth = semantic ? outs[v].sem_depth : nullptr;
         e.obj_last = vw[v].obj_last;
         e.sem_masks = (semantic || layers) ? outs[v].sem_masks : nullptr;
+        e.record = layers ? nullptr : outs[v].record;
         want_sem = want_sem || e.sem_color;
         want_aux = want_aux || outs[v].final_T || outs[v].n_contrib;
         bins[v] = BinView{vw[v].crects, vw[v].splats, vw[v].tile_count, vw[v].rel, vw[v].ranges,

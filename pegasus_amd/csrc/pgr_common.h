@@ -37,6 +37,7 @@ __device__ __forceinline__ f32x4_t gload_quad(const float4* p) { return *(const 
 __device__ __forceinline__ void gstore(uint32_t* p, uint32_t v) { *(PGR_GLOBAL uint32_t*)p = v; }
 __device__ __forceinline__ void gstore(float* p, float v) { *(PGR_GLOBAL float*)p = v; }
 __device__ __forceinline__ void gstore(uint8_t* p, uint8_t v) { *(PGR_GLOBAL uint8_t*)p = v; }
+__device__ __forceinline__ void gstore(uint16_t* p, uint16_t v) { *(PGR_GLOBAL uint16_t*)p = v; }
 __device__ __forceinline__ void gstore(uint64_t* p, uint64_t v) { *(PGR_GLOBAL uint64_t*)p = v; }
 __device__ __forceinline__ void gstore(uint2* p, uint2 v) { *(PGR_GLOBAL u32x2_t*)p = u32x2_t{v.x, v.y}; }
 __device__ __forceinline__ void gstore(float4* p, float4 v) { *(PGR_GLOBAL f32x4_t*)p = f32x4_t{v.x, v.y, v.z, v.w}; }

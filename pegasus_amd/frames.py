@@ -99,7 +99,10 @@ class FrameRenderer:
                           t(view.world_view_transform), t(view.full_proj_transform), t(view.camera_center),
                           depth_mode=int(depth_mode))
 
-    def alloc_frames(self, batch: int, height: int, width: int, masks: bool = True):
+    def alloc_frames(self, batch: int, height: int, width: int, masks: bool = True, records: bool = False):
+        """``records``: also a uint8 [batch, record bytes] tensor the compositor's epilogue fills with every frame's RECORD
+        (uint8 RGB | uint16 depth mm | the K masks as bit planes: masks.record_layout / record_views) -- what leaves the GPU
+        for a finished frame, without a pass that re-reads the images."""
         dev = self.device
         f = dict(color=torch.empty((batch, 3, height, width), device=dev),
                  depth=torch.empty((batch, 1, height, width), device=dev))
@@ -107,7 +110,12 @@ class FrameRenderer:
             f["seg"] = torch.empty((batch, 3, height, width), device=dev)
             f["seg_depth"] = torch.empty((batch, 1, height, width), device=dev)
             f["masks"] = torch.empty((batch, self.K, height, width), dtype=torch.uint8, device=dev)
+        if records:
+            f["records"] = torch.empty((batch, self.record_bytes(height, width, masks)), dtype=torch.uint8, device=dev)
         return f
+
+    def record_bytes(self, height: int, width: int, masks: bool = True) -> int:
+        return M.record_layout(height, width, self.K if masks else 0)["bytes"]
 
     def _posed(self, poses, B):
         """poses [B, K, 20] (pegasus_amd.compose.pose_table per time step) -> the posed-objects argument."""
@@ -122,16 +130,20 @@ class FrameRenderer:
         return dict(object_id=self.semantic["object_id"], poses=t)
 
     def render_frames_async(self, specs: Sequence[R.ViewSpec], frames: dict, masks: bool = True, slot: int = 0,
-                            poses=None):
+                            poses=None, records: torch.Tensor = None):
         """The fast path: ONE batch call renders the scene (color, depth) and -- from the same per-tile lists --
         the objects-only semantic image (seg) and its K masks (compositor epilogue); enqueued on side stream ``slot`` (2 slots =
         two batches in flight on two streams; the streams are independent of each other and of the caller's stream
         after their start, so the batches overlap on the GPU).  Returns a ``wait()``-able handle; nothing
         synchronises the host.  Keep at most one batch in flight per slot.
-        ``poses`` [B, K, 20]: dynamic scene -- frame i shows object k at poses[i, k-1] (time steps as a batch)."""
+        ``poses`` [B, K, 20]: dynamic scene -- frame i shows object k at poses[i, k-1] (time steps as a batch).
+        ``records`` (default: frames["records"] if the frame set has them): uint8 [>= B, record bytes] that receives the
+        frames' records from the compositor's epilogue -- e.g. a FrameGather send buffer."""
         B = len(specs)
         dev = self.device
         cur = torch.cuda.current_stream(dev)
+        if records is None:
+            records = frames.get("records")
         if not hasattr(self, "_slot_streams"):
             self._slot_streams = {}
         # `slot` selects the workspace (and the caller's frame set); slots share `n_streams` streams round-robin when that
@@ -147,6 +159,11 @@ class FrameRenderer:
             for i in range(B):
                 outs[i]["sem_color"], outs[i]["sem_depth"] = frames["seg"][i], frames["seg_depth"][i]
                 outs[i]["sem_masks"] = frames["masks"][i]
+        if records is not None:
+            if records.shape[1] < self.record_bytes(int(specs[0].image_height), int(specs[0].image_width), fused) or records.stride(0) % 16:
+                raise ValueError("records: rows of at least record_bytes(H, W, masks) bytes with a 16-byte-aligned stride")
+            for i in range(B):
+                outs[i]["record"] = records[i]
         st.wait_stream(cur)
         posed = self._posed(poses, B)
         if posed is not None:
@@ -236,6 +253,9 @@ class FrameRenderer:
             for i in range(B):
                 outs[i]["sem_color"], outs[i]["sem_depth"] = frames["seg"][i], frames["seg_depth"][i]
                 outs[i]["sem_masks"] = frames["masks"][i]
+        if "records" in frames:
+            for i in range(B):
+                outs[i]["record"] = frames["records"][i]
         R.forward_views(self.means3d, self.opacities, specs, shs=self.shs, scales=self.scales, tie_index=self.tie_index,
                         tie_inv=self.tie_inv, rotations=self.rotations, sh_degree=self.sh_degree, want_radii=False,
                         outputs=outs, stage_ms=stage_ms, semantic=self.semantic if fused else None,

@@ -138,6 +138,9 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
     ``semantic`` may also carry ``mask_colors`` float32[K,3] (+ ``mask_threshold``): every output dict with a ``sem_masks``
     uint8[K,H,W] tensor then receives the K colour-distance masks of the semantic image from the compositor's epilogue
     (bit for bit what color_masks() computes from ``sem_color``), and ``object_id_u8`` (scene_prepare()).
+    An output dict with a ``record`` uint8[record_layout(H, W, K)["bytes"]] tensor (masks.record_layout; K = semantic["k"] when
+    the descriptor carries mask_colors, else 0) also receives the view's frame record from the compositor's epilogue: bit
+    for bit masks.pack_records of that view's color / depth / sem_masks.
     ``tie_index``: int32[N] permutation -- exact depth ties are broken by it instead of the position (PgrScene.tie_index);
     ``tie_inv``: its inverse from scene_prepare() (otherwise rebuilt per call).
     ``layers``: dict(layer_id int32[N], n_layers, mask_colors float32[n_layers,3], mask_threshold) -> LAYERED call
@@ -198,7 +201,8 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
                                   final_T=_ptr(r.get("final_T")), n_contrib=_ptr(r.get("n_contrib")),
                                   sem_color=_ptr(r.get("sem_color")) if semantic is not None else None,
                                   sem_depth=_ptr(r.get("sem_depth")) if semantic is not None else None,
-                                  sem_masks=_ptr(r.get("sem_masks")) if (semantic is not None or layers is not None) else None)
+                                  sem_masks=_ptr(r.get("sem_masks")) if (semantic is not None or layers is not None) else None,
+                                  record=_ptr(r.get("record")) if layers is None else None)
         results.append(r)
 
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

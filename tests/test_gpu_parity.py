@@ -843,3 +843,43 @@ def test_empty_scene_layered_and_fused_masks_stay_zero(gpu_device):
                     outputs=[out], semantic=sem)
     torch.cuda.synchronize()
     assert all(float(out[k].float().abs().max()) == 0.0 for k in ("color", "depth", "sem_color", "sem_depth", "sem_masks"))
+
+
+@pytest.mark.parametrize("size", [(320, 240), (333, 250)])
+def test_frame_records_from_the_compositor_equal_pack_records(gpu_device, size):
+    """PgrOutputs::record: the frame record written by the compositor's epilogue (uint8 RGB | uint16 depth mm | mask bit planes)
+    is bit for bit what pgr_pack_records makes of the frame's float images and masks -- fused frames (K masks), raster-only
+    frames (no mask section), a non-zero background, an image size that is not a multiple of the tile, the depth-mode switch,
+    and after an instance overflow re-rendered the batch."""
+    import torch
+    from pegasus_amd import frames as F, masks as M, rasterizer
+    w, h = size
+    cloud, views = scenes.scene_c3(scale=0.03, n_views=4, width=w, height=h)
+    act = cloud.activated()
+    fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"], cloud.object_id,
+                         sh_degree=3, device=gpu_device, bg=(0.3, 0.05, 0.6))
+    for masks, mode in ((True, 0), (False, 0), (True, 1)):
+        specs = [fr.view_spec(v, depth_mode=mode) for v in views]
+        f = fr.alloc_frames(4, h, w, masks=masks, records=True)
+        f["records"].fill_(0xAB)
+        fr.render_frames_async(specs, f, masks=masks, slot=0).wait()
+        want = M.pack_records(f["color"], f["depth"], f["masks"] if masks else None)
+        torch.cuda.synchronize()
+        lay = M.record_layout(h, w, fr.K if masks else 0)
+        assert f["records"].shape == want.shape == (4, lay["bytes"])
+        got, ref = M.record_views(f["records"], h, w, fr.K if masks else 0), M.record_views(want, h, w, fr.K if masks else 0)
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), (masks, mode, k)
+        g = fr.render_frames(specs, fr.alloc_frames(4, h, w, masks=masks, records=True), masks=masks)      # the blocking form too
+        assert all(torch.equal(M.record_views(g["records"], h, w, fr.K if masks else 0)[k], ref[k]) for k in ref)
+    for key in list(rasterizer._WS.capacity_hint):
+        rasterizer._WS.capacity_hint[key] = 1500
+    for kk in [k for k in rasterizer._WS.buf if isinstance(k, tuple) and len(k) == 2 and isinstance(k[1], tuple)]:
+        rasterizer._WS.buf.pop(kk)
+    specs = [fr.view_spec(v) for v in views]
+    f = fr.alloc_frames(4, h, w, records=True)
+    fr.render_frames_async(specs, f, slot=1).wait()
+    torch.cuda.synchronize()
+    want = M.pack_records(f["color"], f["depth"], f["masks"])
+    ref, got = M.record_views(want, h, w, fr.K), M.record_views(f["records"], h, w, fr.K)
+    assert all(torch.equal(got[k], ref[k]) for k in ref)
