@@ -29,6 +29,7 @@ The JSON line also carries
 from __future__ import annotations
 
 import argparse
+import collections
 import json
 import os
 import socket
@@ -97,6 +98,10 @@ def parse(argv=None):
                     help="TEST ONLY: exercise launch / sharding / gather / timing with a deterministic CPU frame source "
                          "(no rasterizer, gloo); the JSON line is flagged invalid")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--records", default="epilogue", choices=["epilogue", "pack"],
+                    help="N > 1: where the gathered frame records come from -- epilogue (default on RCCL): the compositor writes "
+                         "them straight into the gather's send buffers (PgrOutputs::record); pack: pgr_pack_records after the "
+                         "batch (one-rank RCCL A/B on one box: 5751 / 5717 vs 5617 / 5606 frames/s with the gather)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed repeats of the K steps inside this one invocation (BASELINE.md section 4: >= 5 repeats, "
                          "median + min): value / ms_per_step are the MEDIAN repeat, min / max / every repeat ride along")
@@ -246,12 +251,14 @@ class RealEngine:
         return bop_pose.batch_pose_records([self.views[g % len(self.views)] for g in ids],
                                            [self.m2w_seq[g % SEQUENCE_STEPS] for g in ids])
 
-    def enqueue(self, i, slot):
+    def enqueue(self, i, slot, records=None):
+        """``records``: a uint8 [B, record_bytes] tensor (a FrameGather send buffer) the compositor's epilogue fills with the
+        batch's frame records -- what leaves the GPU, written while the frames are made."""
         fr, a = self.fr, self.args
         if a.separate_semantic:
             return fr.render_batch_async(self.batch_views(i), self.frame_sets[slot], masks=self.with_masks, slot=slot)
         h = fr.render_frames_async(self.batch_views(i), self.frame_sets[slot], masks=self.with_masks, slot=slot,
-                                   poses=self.batch_poses(i))
+                                   poses=self.batch_poses(i), records=records)
         if self.with_sil:                     # 'seg_sil': all K silhouettes of the batch, one layered pass on its own stream
             _, hs = fr.render_silhouettes(self.batch_views(i), out=self.frame_sets[slot]["sil"], poses=self.batch_poses(i),
                                           slot=slot, wait=False)
@@ -334,7 +341,7 @@ class StubEngine:
         bits = (g % 256).to(torch.uint8).view(-1, 1, 1, 1).expand(-1, 4, 5, 1).contiguous()
         return {"rgb": rgb, "depth_mm": depth, "mask_bits": bits}
 
-    def enqueue(self, i, slot):
+    def enqueue(self, i, slot, records=None):
         ids = self.frame_ids(i)
 
         class _H:
@@ -473,17 +480,43 @@ def run_worker(args):
     # reordered, copied or allocated per batch.
     fg = stage = None
     gstat = {"host_s": 0.0, "wire_s": 0.0, "batches": 0}
+    # DIRECT records (RCCL, the measured configuration): the send buffers of the gather ARE where the compositor's epilogue
+    # writes every frame's record (PgrOutputs::record) -- no pack pass re-reads the images.  A ring of n_slots + 2 buffers:
+    # batch i renders into buffer i mod R, its gather starts when the batch is done and has two more batches of time before
+    # the buffer is rendered into again.
+    direct = False
+    ring = collections.deque()                     # ring indices of the batches in flight, oldest first
+    seq = {"enq": 0}
     if gather_on:
         from pegasus_amd import view_shard as VS
         host_wire = backend == "gloo"              # gloo moves host memory: rehearsals and CPU tests only
-        fg = VS.FrameGather(cap=B, record_bytes=eng.record_bytes(), device="cpu" if host_wire else dev, dst=0, depth=2,
-                            pin_memory=host_wire and not eng.stub)
+        direct = (args.records == "epilogue" and not host_wire and not eng.stub and not args.sync_steps
+                  and not args.separate_semantic)
+        fg = VS.FrameGather(cap=B, record_bytes=eng.record_bytes(), device="cpu" if host_wire else dev, dst=0,
+                            depth=n_slots + 2 if direct else 2, pin_memory=host_wire and not eng.stub)
         if host_wire and not eng.stub:             # device-side staging of the rehearsal: pack on the GPU, copy to pinned
             stage = [torch.empty((B, eng.record_bytes()), dtype=torch.uint8, device=dev) for _ in range(2)]
+
+    def enqueue(i, slot):
+        if not direct:
+            return eng.enqueue(i, slot)
+        r = seq["enq"] % fg.depth
+        seq["enq"] += 1
+        fg.finish(r)                               # the gather that read this buffer depth batches ago (RCCL: a stream dependency)
+        ring.append(r)
+        return eng.enqueue(i, slot, records=fg.send_buffer(r))
 
     def gather_finished(token, gather):
         """Pack a finished batch into this slot's send buffer and start its gather to rank 0 (grouped send/recv on RCCL:
         the peers stream over their own xGMI links).  Two slots: one gather is in flight beside the batch being packed."""
+        if direct:
+            r = ring.popleft()
+            if gather:
+                t0 = time.perf_counter()
+                fg.start(r)                        # the records are in the send buffer already: the compositor wrote them
+                gstat["batches"] += 1
+                gstat["host_s"] += time.perf_counter() - t0
+            return
         if not gather:
             return
         t0 = time.perf_counter()
@@ -521,7 +554,7 @@ def run_worker(args):
         pending = []                                  # at most n_slots - 1 older batches in flight
         for i in range(first, first + count):
             t_e = time.perf_counter()
-            h = eng.enqueue(i, i % n_slots)
+            h = enqueue(i, i % n_slots)
             t_w = time.perf_counter()
             pending.append(h)
             while len(pending) >= n_slots:
@@ -579,14 +612,26 @@ def run_worker(args):
     gather_check = None
     if use_dist and gather_on:
         i_chk = args.warmup + args.steps
-        token = eng.step_blocking(i_chk)
-        eng.sync()
-        gstat["batches"] = 0
-        gather_finished(token, True)
+        records_ok = True
+        if direct:                                    # one batch through the same path: render into send buffer 0, gather it
+            fg.finish_all()
+            seq["enq"] = 0
+            token = enqueue(i_chk, 0).wait()
+            eng.sync()
+            # the compositor's records against the pack kernel's on the same frames (sender side, every rank)
+            records_ok = bool(torch.equal(fg.send_buffer(0), eng.pack(token, torch.empty_like(fg.send_buffer(0)))))
+            gather_finished(token, True)
+        else:
+            token = eng.step_blocking(i_chk)
+            eng.sync()
+            gstat["batches"] = 0
+            gather_finished(token, True)
         recv = fg.finish(0)
         eng.sync()
         sums = [None] * world
-        dist.all_gather_object(sums, int(fg.send_buffer(0).to(torch.int64).sum().item()))
+        dist.all_gather_object(sums, (int(fg.send_buffer(0).to(torch.int64).sum().item()), records_ok))
+        records_ok = all(s_[1] for s_ in sums)
+        sums = [s_[0] for s_ in sums]
         if rank == 0:
             ok = all(int(recv[r].to(torch.int64).sum().item()) == sums[r] for r in range(world))
             if eng.stub:                              # the stub's frames are a function of their global id: check content too,
@@ -594,7 +639,7 @@ def run_worker(args):
                 ids = [((i_chk * B + k) * world + r) for k in range(B) for r in range(world)]
                 want = StubEngine.records_of(ids, torch, eng.H, eng.W).view(B, world, -1)
                 ok = ok and torch.equal(glob, want)
-            gather_check = "ok" if ok else "MISMATCH"
+            gather_check = "ok" if (ok and records_ok) else "MISMATCH"
         flag = torch.tensor([0 if (rank != 0 or gather_check == "ok") else 1], device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(flag)
         if int(flag.item()):
@@ -631,6 +676,8 @@ def run_worker(args):
                     "rank 0's preallocated [world, B, record] buffer (rank-major = global order under a transposed view: frame "
                     "g = i * world + r); two buffer slots, one gather in flight; nothing allocated or reordered per batch",
             "payload": "one record per frame: uint8 RGB [H,W,3] | uint16 depth mm [H,W] | K masks as bit planes (ceil(K/8) bytes per pixel)",
+            "records": ("written by the compositor's epilogue straight into the gather's send buffers (PgrOutputs::record; a ring of "
+                        f"{fg.depth} buffers), no pack pass" if direct else "pgr_pack_records into the send buffer after the batch"),
             "bytes_per_rank_and_batch": fg.bytes_per_rank_and_batch,
             "views_per_s_with_gather": round(value, 3),
             "views_per_s_render_only": round(total_views / elapsed_render_only, 3),
