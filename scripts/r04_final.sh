@@ -18,10 +18,12 @@ python bench.py --views 4096 --steps 128 --repeats 3 --no-drop-in --no-cpu-basel
 python bench.py --workload c5 --dynamic --views 200 --batch 40 --steps 5 --no-drop-in --no-cpu-baseline > ${P}_bench_c5_dynamic_200steps_1gpu.json 2>/dev/null
 python bench.py --facade > ${P}_bench_facade.json 2>/dev/null
 python bench.py --gpus 2 --share-devices --backend gloo --steps 6 --warmup 2 --no-drop-in > ${P}_bench_rehearsal_2ranks_1gpu.json 2>/dev/null
+python bench.py --force-dist --backend nccl --no-drop-in --no-cpu-baseline > ${P}_bench_rccl_1rank_forced.json 2>/dev/null
+python bench.py --force-dist --backend nccl --records pack --no-drop-in --no-cpu-baseline > ${P}_bench_rccl_1rank_forced_pack.json 2>/dev/null
 bash scripts/trace_run.sh r04 --no-drop-in > /dev/null 2>&1
 bash scripts/trace_run.sh r04_sync --no-drop-in --sync-steps > /dev/null 2>&1
 python scripts/silhouette_time.py 2>&1 | grep -v amdgpu.ids > ${P}_silhouette_time.txt
-( python scripts/fuzz_parity.py 80000 1500 2>&1 | tail -1; python scripts/fuzz_fused.py 4000 200 2>&1 | tail -1
+( python scripts/fuzz_parity.py 80000 1500 2>&1 | tail -1; python scripts/fuzz_fused.py 4000 200 2>&1 | tail -1; python scripts/fuzz_layered.py 2000 100 2>&1 | tail -1
   python scripts/soak_determinism.py 4 c3 2>&1 | tail -1; python scripts/full_size_parity.py 2>&1 | tail -1 ) | grep -v amdgpu.ids > ${P}_verification.txt
 for f in ${P}_bench_*.json; do python - "$f" <<'PY'
 import json, sys
