@@ -794,6 +794,14 @@ extern "C" int32_t pgr_debug_comp_stats(unsigned long long* out, int32_t reset) 
 }
 #endif
 
+#ifdef PGR_LAZY_PROBE
+extern "C" int32_t pgr_debug_set_lazy(uint32_t mode, uint32_t percent) {
+    const unsigned int v[2] = {mode, percent};
+    if (hipDeviceSynchronize() != hipSuccess) return -4;
+    return hipMemcpyToSymbol(HIP_SYMBOL(pgr::g_lazy), v, 8) == hipSuccess ? 0 : -4;
+}
+#endif
+
 #ifdef PGR_SORT_STATS
 extern "C" int32_t pgr_debug_sort_stats(unsigned long long* out, int32_t reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -4;

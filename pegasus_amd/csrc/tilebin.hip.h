@@ -553,6 +553,12 @@ __device__ __forceinline__ void merge_sort_tile(uint64_t* __restrict__ skeys, co
 #ifdef PGR_SORT_STATS
 __device__ unsigned long long g_sort_stats[8];   // [0] lists, [1] keys, [2] sum k^2, [3] rejected lists, [4] rejected keys
 #endif
+#ifdef PGR_LAZY_PROBE
+// MEASUREMENT PROBE ONLY (round 4, lazy-sort upper bounds; the lists it produces are WRONG behind the cut): keys whose bucket
+// starts at or behind g_lazy[1] percent of their list are [0] = 1: not ranked inside their bucket (arrival order),
+// [0] = 2: neither parked, ranked nor written (the output keeps what an earlier sort left there).
+__device__ unsigned int g_lazy[2];
+#endif
 
 constexpr uint32_t BUCKET_SQ_LIMIT = 8;
 
@@ -681,6 +687,9 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
         fin[e] = 0u;
         if (e * THREADS + t < n) {
             fin[e] = s_hist[br[e] >> 16];
+#ifdef PGR_LAZY_PROBE
+            if (g_lazy[0] == 2u && (fin[e] & 0xffffu) * 100u >= g_lazy[1] * (uint32_t)n) continue;
+#endif
             s_keys[(fin[e] & 0xffffu) + (br[e] & 0xffffu)] = ((uint64_t)d[e] << 32) | id[e];
         }
     }
@@ -695,7 +704,13 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
         if (e * THREADS + t < n) {
             const uint32_t s0 = fin[e] & 0xffffu, cnt = fin[e] >> 16;
             uint32_t rank = 0;
+#ifdef PGR_LAZY_PROBE
+            const bool lazy_back = g_lazy[0] != 0u && s0 * 100u >= g_lazy[1] * (uint32_t)n;
+            if (lazy_back) rank = br[e] & 0xffffu;
+            if (cnt > 1u && !lazy_back) {
+#else
             if (cnt > 1u) {
+#endif
                 const uint64_t key = ((uint64_t)d[e] << 32) | id[e];
                 uint32_t same = 0;                       // members with this key's depth bits (itself included)
                 // the first RANK_BATCH members in ONE LDS round trip (independent reads, index clamped into the bucket);
@@ -728,6 +743,9 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
                 }
             }
             fin[e] = s0 + rank;
+#ifdef PGR_LAZY_PROBE
+            if (lazy_back && g_lazy[0] == 2u) fin[e] = 0xffffffffu;
+#endif
         }
     }
     SORT_STAMP(6);      // rank inside the bucket
@@ -736,6 +754,9 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
 #pragma unroll
         for (int e = 0; e < E; ++e)
             if (e * THREADS + t < n) {
+#ifdef PGR_LAZY_PROBE
+                if (fin[e] == 0xffffffffu) continue;
+#endif
                 gstore(out + fin[e], id[e]);
                 if (n_env >= 0 && (int)id[e] >= n_env) best = max(best, pos_offset + fin[e] + 1u);
             }
@@ -752,9 +773,20 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
     uint32_t* s_idx = s_hist;
 #pragma unroll
     for (int e = 0; e < E; ++e)
+#ifdef PGR_LAZY_PROBE
+        if (e * THREADS + t < n && fin[e] != 0xffffffffu) s_idx[fin[e]] = id[e];
+#else
         if (e * THREADS + t < n) s_idx[fin[e]] = id[e];
+#endif
     __syncthreads();
+#ifdef PGR_LAZY_PROBE
+    {   // mode 2 writes only the front part (the back keeps what an earlier sort left there: valid indices, wrong order)
+        const int n_out = g_lazy[0] == 2u ? (int)(((unsigned long long)g_lazy[1] * (unsigned)n + 99ull) / 100ull) : n;
+        for (int i = t; i < min(n, n_out); i += THREADS) gstore(out + i, s_idx[i]);
+    }
+#else
     for (int i = t; i < n; i += THREADS) gstore(out + i, s_idx[i]);
+#endif
     SORT_STAMP(7);      // index image + output
     if (n_env >= 0) mark_last_object<THREADS>([&](int i) { return s_idx[i]; }, n, n_env, obj_last, pos_offset);
     SORT_STAMP(8);      // last object marker
