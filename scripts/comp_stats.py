@@ -1,5 +1,6 @@
-"""Debug: compositor work statistics from a -DPGR_COMP_STATS build
-(scripts/variant_sweep.sh build "2:0" -DPGR_COMP_ITEMS=4 -DPGR_COMP_STATS; copy it over csrc/libpegasus_raster.so)."""
+"""Debug: compositor work statistics from a -DPGR_COMP_STATS (-DPGR_SORT_STATS) build of the library, loaded through PGR_LIB
+(hipcc <pegasus_amd/build.py FLAGS> -DPGR_COMP_STATS -DPGR_SORT_STATS -o build_variants/lib_stats.so pegasus_raster.hip;
+PGR_LIB=$PWD/build_variants/lib_stats.so python scripts/comp_stats.py c3 frames -- the product .so is never overwritten)."""
 import ctypes as C
 import sys
 import torch
