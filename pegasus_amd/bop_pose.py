@@ -96,3 +96,44 @@ def batch_pose_records(views, object_poses_per_frame, translation_scale: float =
                                     boxes=boxes, dataset_ids=dataset_ids)
         cam[str(i)] = scene_camera_entry(fx, fy, w, h, R, t)
     return gt, cam
+
+
+def gt_info_from_masks(visible, silhouette, depth_valid=None):
+    """scene_gt_info entries (/root/reference/submodules/bop_toolkit/docs/bop_datasets_format.md:116-129) from the masks the
+    frame path already holds: ``silhouette`` [..., K, H, W] (FrameRenderer.render_silhouettes: every object alone) and
+    ``visible`` [..., K, H, W] (the frames' masks), ``depth_valid`` [..., H, W] (depth image != 0; default: all valid).
+    Torch tensors (any device) or numpy arrays of 0/1.  Follows calc_gt_info.py:139-172 of the BOP toolkit: px_count_all /
+    px_count_valid / px_count_visib, visib_fract = visible / all, bounding boxes (x, y, w, h) with w = x_max - x_min
+    (bop_toolkit_lib.misc.calc_2d_bbox) and both boxes [-1, -1, -1, -1] when no pixel is visible.  The toolkit counts the
+    silhouette of a mesh render including the part beyond the image border; a mask only has the part inside.
+    Returns a dict of integer / float arrays shaped [..., K] (boxes [..., K, 4]) on the host."""
+    import torch
+    vis = torch.as_tensor(visible).bool()
+    sil = torch.as_tensor(silhouette).bool().to(vis.device)
+    H, W = vis.shape[-2:]
+    valid = sil if depth_valid is None else sil & torch.as_tensor(depth_valid).bool().to(vis.device).unsqueeze(-3)
+
+    def box(m):
+        rows, cols = m.any(-1), m.any(-2)                        # [..., K, H], [..., K, W]
+        first = lambda t: t.to(torch.uint8).argmax(-1)           # index of the first True (0 when there is none)
+        y0, x0 = first(rows), first(cols)
+        y1, x1 = H - 1 - first(rows.flip(-1)), W - 1 - first(cols.flip(-1))
+        return torch.stack([x0, y0, x1 - x0, y1 - y0], -1)
+    count = lambda m: m.flatten(-2).sum(-1)
+    px_all, px_valid, px_visib = count(sil), count(valid), count(vis)
+    seen = (px_visib > 0).unsqueeze(-1)
+    none = torch.full_like(box(sil), -1)
+    out = dict(px_count_all=px_all, px_count_valid=px_valid, px_count_visib=px_visib,
+               visib_fract=torch.where(px_all > 0, px_visib.double() / px_all.clamp(min=1).double(), torch.zeros_like(px_all, dtype=torch.float64)),
+               bbox_obj=torch.where(seen, box(sil), none), bbox_visib=torch.where(seen, box(vis), none))
+    return {k: v.cpu().numpy() for k, v in out.items()}
+
+
+def scene_gt_info_entry(info: dict, index) -> list:
+    """The scene_gt_info.json list of one image from gt_info_from_masks' arrays: ``index`` selects the image (e.g. a batch
+    position); one dict per object, in the order of the masks' K axis (= the order of scene_gt's entries)."""
+    sel = {k: v[index] for k, v in info.items()}
+    return [{"px_count_all": int(sel["px_count_all"][k]), "px_count_valid": int(sel["px_count_valid"][k]),
+             "px_count_visib": int(sel["px_count_visib"][k]), "visib_fract": float(sel["visib_fract"][k]),
+             "bbox_obj": [int(e) for e in sel["bbox_obj"][k]], "bbox_visib": [int(e) for e in sel["bbox_visib"][k]]}
+            for k in range(sel["px_count_all"].shape[0])]

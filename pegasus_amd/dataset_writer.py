@@ -9,6 +9,9 @@ Layout and naming follow the reference's writer (/root/reference/src/visualizati
     <out>/train/<scene:06d>/mask/<frame:06d>_<obj:06d>.png         8-bit 0/255      silhouettes   ('seg_sil')
     <out>/train/<scene:06d>/sem_mask/<frame:06d>.png               8-bit RGB, uint8 of the semantic image ('sem_seg')
     <out>/train/<scene:06d>/scene_gt.json, scene_camera.json      pegasus_amd.bop_pose records
+    <out>/train/<scene:06d>/scene_gt_info.json                    per object and frame: pixel counts, visible fraction, 2D
+                                                                  boxes (BOP format, bop_datasets_format.md:116-129) -- written
+                                                                  when a batch brings both visible masks and silhouettes
 
 (the five image kinds of the reference's write_training_data, /root/reference/src/tools/pegasus_working.py:412-439, for the
 data points ['rgb','depth','seg_vis','seg_sil','sem_seg'] of /root/reference/pegasus.py:491)
@@ -83,7 +86,7 @@ class BopSceneWriter:
         self.scene = Path(out_dir) / "train" / f"{scene_id:06d}"
         for d in ("rgb", "depth", "mask_visib", "mask", "sem_mask"):
             (self.scene / d).mkdir(parents=True, exist_ok=True)
-        self.scene_gt, self.scene_camera = {}, {}
+        self.scene_gt, self.scene_camera, self.scene_gt_info = {}, {}, {}
         self.n_frames, self.level = 0, png_level
         self.workers = max(1, min(32, os.cpu_count() or 1) if workers is None else int(workers))
         self._pool = ThreadPoolExecutor(max_workers=self.workers) if self.workers > 1 else None
@@ -114,6 +117,11 @@ class BopSceneWriter:
         if silhouettes is None:
             silhouettes = frames.get("sil")
         sil = (silhouettes[:n] * 255).cpu().numpy() if silhouettes is not None else None
+        info = None
+        if silhouettes is not None and "masks" in frames:
+            # BOP's scene_gt_info from the masks the batch already holds, counted on the GPU (a few hundred numbers per batch)
+            from . import bop_pose
+            info = bop_pose.gt_info_from_masks(frames["masks"][:n], silhouettes[:n], packed["depth_mm"] != 0)
         futures = []
         for i in range(n):
             fid = self.n_frames if frame_ids is None else int(frame_ids[i])
@@ -129,6 +137,9 @@ class BopSceneWriter:
                     self._submit(self.scene / "mask" / f"{fid:06d}_{k:06d}.png", sil[i, k], futures)
             self.scene_gt[str(fid)] = scene_gt[str(i)]
             self.scene_camera[str(fid)] = scene_camera[str(i)]
+            if info is not None:
+                from . import bop_pose
+                self.scene_gt_info[str(fid)] = bop_pose.scene_gt_info_entry(info, i)
             self.n_frames += 1
         if futures:
             self._pending.append(futures)
@@ -151,11 +162,15 @@ class BopSceneWriter:
 
     def merge_records(self, others):
         """Adds the (scene_gt, scene_camera) dict pairs of other ranks' writers (disjoint frame ids)."""
-        for gt, cam in others:
-            self.scene_gt.update(gt)
-            self.scene_camera.update(cam)
+        for rec in others:
+            self.scene_gt.update(rec[0])
+            self.scene_camera.update(rec[1])
+            if len(rec) > 2:
+                self.scene_gt_info.update(rec[2])
 
     def write_records(self):
         order = lambda d: {k: d[k] for k in sorted(d, key=int)}
         (self.scene / "scene_gt.json").write_text(json.dumps(order(self.scene_gt)))
         (self.scene / "scene_camera.json").write_text(json.dumps(order(self.scene_camera)))
+        if self.scene_gt_info:
+            (self.scene / "scene_gt_info.json").write_text(json.dumps(order(self.scene_gt_info)))

@@ -87,7 +87,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         records = [None] * world if rank == 0 else None
-        dist.gather_object((w.scene_gt, w.scene_camera), records, dst=0)
+        dist.gather_object((w.scene_gt, w.scene_camera, w.scene_gt_info), records, dst=0)
         if rank == 0:
             w.merge_records(records[1:])
     if rank == 0:

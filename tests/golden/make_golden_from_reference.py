@@ -6,7 +6,11 @@ OUTPUTS are stored -- no reference source text.
 
 What imports: bop_toolkit view_sampler (with imageio/png stubbed),
 src.utility.pose_interpolation, src.utility.graphic_utils (``.to('cuda')`` patched to identity
-for generate_colors).  The rasterizer itself is absent, so no rasterizer golden can be produced.
+for generate_colors), bop_toolkit_lib.misc (calc_2d_bbox: the bounding boxes of scene_gt_info.json).
+The rasterizer itself is absent, so no rasterizer golden can be produced.
+
+``python tests/golden/make_golden_from_reference.py [section ...]`` regenerates only the named sections
+(views, interpolation, graphic_utils, trajectory, gt_info); default: all.
 """
 import json
 import math
@@ -22,6 +26,8 @@ OUT = Path(__file__).resolve().parent
 
 
 def main():
+    only = set(sys.argv[1:])
+    want = lambda name: not only or name in only
     assert REF.exists(), "reference checkout not present"
     sys.path.insert(0, str(REF))
     sys.path.insert(0, str(REF / "submodules" / "bop_toolkit"))
@@ -34,6 +40,10 @@ def main():
             except Exception:
                 sys.modules[name] = types.ModuleType(name)
 
+    if want("gt_info"):
+        gt_info_golden()
+    if only and only <= {"gt_info"}:
+        return
     # 1. BOP fibonacci hemisphere views (config-2/3 camera sets)
     from bop_toolkit_lib import view_sampler
     cases = {}
@@ -88,6 +98,43 @@ def main():
     np.savez_compressed(OUT / "simulation_steps_body1_first200.npz", t_q_xyzw=tq)
     (OUT / "simulation_steps_meta.json").write_text(json.dumps(meta))
     print("golden fixtures written to", OUT)
+
+
+def gt_info_golden():
+    """scene_gt_info.json entries (submodules/bop_toolkit/docs/bop_datasets_format.md:116-129) as
+    submodules/bop_toolkit/scripts/calc_gt_info.py:139-172 derives them from an object's silhouette mask, its visible mask and
+    the depth image -- the bounding boxes through the reference's own bop_toolkit_lib.misc.calc_2d_bbox."""
+    from bop_toolkit_lib import misc
+    rng = np.random.default_rng(23)
+    H, W, n = 37, 53, 24
+    sil = np.zeros((n, H, W), bool)
+    vis = np.zeros((n, H, W), bool)
+    depth_valid = rng.random((n, H, W)) > 0.1
+    for i in range(n):
+        if i % 6 == 5:
+            continue                                   # an object that is not in the image at all
+        y0, x0 = int(rng.integers(0, H - 4)), int(rng.integers(0, W - 4))
+        y1, x1 = int(rng.integers(y0 + 1, H + 1)), int(rng.integers(x0 + 1, W + 1))
+        blob = rng.random((y1 - y0, x1 - x0)) > 0.35
+        sil[i, y0:y1, x0:x1] = blob
+        if i % 6 != 4:                                 # (i % 6 == 4: fully occluded -> no visible pixel)
+            vis[i] = sil[i] & (rng.random((H, W)) > 0.4)
+    out = dict(px_count_all=[], px_count_valid=[], px_count_visib=[], visib_fract=[], bbox_obj=[], bbox_visib=[])
+    for i in range(n):
+        px_all, px_valid, px_visib = int(sil[i].sum()), int((depth_valid[i] & sil[i]).sum()), int(vis[i].sum())
+        bbox = bbox_visib = [-1, -1, -1, -1]
+        if px_visib > 0:
+            ys, xs = sil[i].nonzero()
+            bbox = misc.calc_2d_bbox(xs, ys, (W, H))
+            ys, xs = vis[i].nonzero()
+            bbox_visib = misc.calc_2d_bbox(xs, ys, (W, H))
+        out["px_count_all"].append(px_all); out["px_count_valid"].append(px_valid); out["px_count_visib"].append(px_visib)
+        out["visib_fract"].append(px_visib / float(px_all) if px_all > 0 else 0.0)
+        out["bbox_obj"].append([int(e) for e in bbox]); out["bbox_visib"].append([int(e) for e in bbox_visib])
+    np.savez_compressed(OUT / "bop_gt_info.npz", sil=np.packbits(sil, axis=-1), vis=np.packbits(vis, axis=-1),
+                        depth_valid=np.packbits(depth_valid, axis=-1), shape=np.asarray([n, H, W]),
+                        **{k: np.asarray(v) for k, v in out.items()})
+    print("bop_gt_info.npz written")
 
 
 if __name__ == "__main__":

@@ -184,6 +184,22 @@ def test_generate_writes_bop_layout(gpu_device, tmp_path):
     assert set(e0) >= {"cam_R_m2c", "cam_t_m2c", "T_w2c", "T_m2w", "obj_id", "bullet_obj_id", "3d_bounding_box_model_coord",
                        "3d_bounding_center", "projected_center", "projected_points"}
     assert np.array(e0["projected_points"]).shape == (8, 2) and len(e0["T_w2c"]) == 16
+    # scene_gt_info.json (BOP format, bop_datasets_format.md:116-129) from the same masks: counts and boxes agree with the PNGs
+    info = json.loads((scene / "scene_gt_info.json").read_text())
+    assert sorted(info) == sorted(gt) and len(info["3"]) == 8
+    for k in range(8):
+        e = info["3"][k]
+        assert e["px_count_visib"] == int((masks[k] == 255).sum()) and e["px_count_all"] == int((sil[k] == 255).sum())
+        assert e["px_count_valid"] == int(((sil[k] == 255) & (depth != 0)).sum())
+        if e["px_count_visib"]:
+            ys, xs = np.nonzero(masks[k])
+            assert e["bbox_visib"] == [int(xs.min()), int(ys.min()), int(xs.max() - xs.min()), int(ys.max() - ys.min())]
+            ys, xs = np.nonzero(sil[k])
+            assert e["bbox_obj"] == [int(xs.min()), int(ys.min()), int(xs.max() - xs.min()), int(ys.max() - ys.min())]
+            assert abs(e["visib_fract"] - e["px_count_visib"] / e["px_count_all"]) < 1e-12
+        else:
+            assert e["bbox_visib"] == [-1, -1, -1, -1] and e["bbox_obj"] == [-1, -1, -1, -1]
+    assert sum(e["px_count_visib"] for e in info["3"]) > 0
 
 
 @pytest.mark.gpu
@@ -337,7 +353,7 @@ def test_generate_view_sharded_over_two_ranks_writes_the_same_dataset(gpu_device
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     files = sorted(p.relative_to(one) for p in one.rglob("*") if p.is_file())
-    assert files == sorted(p.relative_to(two) for p in two.rglob("*") if p.is_file()) and len(files) == 7 * (3 + 16) + 2
+    assert files == sorted(p.relative_to(two) for p in two.rglob("*") if p.is_file()) and len(files) == 7 * (3 + 16) + 3
     for f in files:
         if f.suffix == ".png":
             assert (one / f).read_bytes() == (two / f).read_bytes(), f

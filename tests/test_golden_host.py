@@ -47,3 +47,27 @@ def test_pose_sequence_fixture_schema():
     tq = np.load(GOLD / "simulation_steps_body1_first200.npz")["t_q_xyzw"]
     assert tq.shape == (200, 7)
     np.testing.assert_allclose(np.linalg.norm(tq[:, 3:], axis=1), 1.0, atol=1e-6)
+
+
+def test_scene_gt_info_matches_the_bop_toolkit_golden():
+    """bop_pose.gt_info_from_masks against entries computed with the reference's own bop_toolkit_lib.misc.calc_2d_bbox and
+    the counting rules of its scripts/calc_gt_info.py:139-172 (tests/golden/make_golden_from_reference.py gt_info): random
+    silhouettes and visible masks incl. absent and fully occluded objects, a depth image with holes."""
+    import torch
+    from pegasus_amd import bop_pose
+    g = np.load(GOLD / "bop_gt_info.npz")
+    n, H, W = (int(v) for v in g["shape"])
+    unpack = lambda a: np.unpackbits(a, axis=-1)[..., :W].astype(bool)
+    sil, vis, valid = unpack(g["sil"]), unpack(g["vis"]), unpack(g["depth_valid"])
+    # as n images of one object each, and as one batch of 2 images x n/2 objects sharing the per-image depth mask
+    one = bop_pose.gt_info_from_masks(torch.from_numpy(vis[:, None]), torch.from_numpy(sil[:, None]), torch.from_numpy(valid))
+    for k in ("px_count_all", "px_count_valid", "px_count_visib", "bbox_obj", "bbox_visib"):
+        np.testing.assert_array_equal(one[k][:, 0], g[k], err_msg=k)
+    np.testing.assert_allclose(one["visib_fract"][:, 0], g["visib_fract"], rtol=0, atol=1e-15)
+    e = bop_pose.scene_gt_info_entry(one, 3)
+    assert e == [{"px_count_all": int(g["px_count_all"][3]), "px_count_valid": int(g["px_count_valid"][3]),
+                  "px_count_visib": int(g["px_count_visib"][3]), "visib_fract": float(g["visib_fract"][3]),
+                  "bbox_obj": g["bbox_obj"][3].tolist(), "bbox_visib": g["bbox_visib"][3].tolist()}]
+    assert g["bbox_visib"][4].tolist() == [-1, -1, -1, -1] and one["bbox_obj"][5, 0].tolist() == [-1, -1, -1, -1]
+    numpy_in = bop_pose.gt_info_from_masks(vis[:, None], sil[:, None])             # numpy inputs, all depth valid
+    np.testing.assert_array_equal(numpy_in["px_count_valid"][:, 0], g["px_count_all"])
