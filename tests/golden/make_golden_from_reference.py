@@ -131,9 +131,19 @@ def gt_info_golden():
         out["px_count_all"].append(px_all); out["px_count_valid"].append(px_valid); out["px_count_visib"].append(px_visib)
         out["visib_fract"].append(px_visib / float(px_all) if px_all > 0 else 0.0)
         out["bbox_obj"].append([int(e) for e in bbox]); out["bbox_visib"].append([int(e) for e in bbox_visib])
+    # projection of model points into the image (scene_gt's projected_points / projected_center): the toolkit's project_pts
+    from scipy.spatial.transform import Rotation as Rot
+    proj = dict(K=[], R=[], t=[], pts=[], uv=[])
+    for i in range(12):
+        K = np.array([[rng.uniform(400, 1200), 0, rng.uniform(200, 600)], [0, rng.uniform(400, 1200), rng.uniform(200, 600)], [0, 0, 1.0]])
+        R = Rot.random(random_state=int(rng.integers(1 << 30))).as_matrix()
+        t = np.array([[rng.normal(0, 0.2)], [rng.normal(0, 0.2)], [rng.uniform(0.5, 3.0)]])
+        pts = rng.normal(0, 0.1, (9, 3))
+        proj["K"].append(K); proj["R"].append(R); proj["t"].append(t[:, 0]); proj["pts"].append(pts)
+        proj["uv"].append(misc.project_pts(pts, K, R, t))
     np.savez_compressed(OUT / "bop_gt_info.npz", sil=np.packbits(sil, axis=-1), vis=np.packbits(vis, axis=-1),
                         depth_valid=np.packbits(depth_valid, axis=-1), shape=np.asarray([n, H, W]),
-                        **{k: np.asarray(v) for k, v in out.items()})
+                        **{k: np.asarray(v) for k, v in out.items()}, **{"proj_" + k: np.asarray(v) for k, v in proj.items()})
     print("bop_gt_info.npz written")
 
 

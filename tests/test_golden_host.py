@@ -71,3 +71,13 @@ def test_scene_gt_info_matches_the_bop_toolkit_golden():
     assert g["bbox_visib"][4].tolist() == [-1, -1, -1, -1] and one["bbox_obj"][5, 0].tolist() == [-1, -1, -1, -1]
     numpy_in = bop_pose.gt_info_from_masks(vis[:, None], sil[:, None])             # numpy inputs, all depth valid
     np.testing.assert_array_equal(numpy_in["px_count_valid"][:, 0], g["px_count_all"])
+
+
+def test_projected_points_match_the_bop_toolkit_golden():
+    """bop_pose.project_points (scene_gt's projected_points / projected_center: P = K T[:3] on homogeneous points, the
+    reference's writer at /root/reference/src/tools/pegasus_working.py:547-563) against bop_toolkit_lib.misc.project_pts."""
+    from pegasus_amd import bop_pose
+    g = np.load(GOLD / "bop_gt_info.npz")
+    for K, R, t, pts, uv in zip(g["proj_K"], g["proj_R"], g["proj_t"], g["proj_pts"], g["proj_uv"]):
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+        np.testing.assert_allclose(bop_pose.project_points(K, T, pts), uv, rtol=0, atol=1e-10)
