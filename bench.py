@@ -98,6 +98,10 @@ def parse(argv=None):
                     help="TEST ONLY: exercise launch / sharding / gather / timing with a deterministic CPU frame source "
                          "(no rasterizer, gloo); the JSON line is flagged invalid")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--cpu-only", action="store_true",
+                    help="BASELINE.json configs[0] (plumbing, no GPU): time ONLY the CPU oracle on the chosen workload's cameras "
+                         "(default there: --workload c1, the 10 k-Gaussian cube at 256x256) and print a line flagged cpu_only; "
+                         "the product path is not involved and needs no HIP device")
     ap.add_argument("--records", default="epilogue", choices=["epilogue", "pack"],
                     help="N > 1: where the gathered frame records come from -- epilogue (default on RCCL): the compositor writes "
                          "them straight into the gather's send buffers (PgrOutputs::record); pack: pgr_pack_records after the "
@@ -1000,9 +1004,39 @@ def drop_in_numbers(eng, n_frames=4, n_render_calls=48):
             "sample": f"{n_frames} frames, {min(n_render_calls, len(cams))} render() calls; same scene and cameras as the batch path"}
 
 
+def run_cpu_only(args):
+    """configs[0]: the CPU oracle alone (the checker timed as the reported CPU baseline -- the only role in which bench.py may
+    run anything under oracle/)."""
+    import oracle
+    oracle.build()
+    cloud, views, label = build_workload(args.workload, args.scale, max(1, min(args.views, 8)))
+    act = cloud.activated()
+    n_cpu = os.cpu_count() or 1
+    rows = {}
+    for threads in sorted({1, min(8, n_cpu), n_cpu}):
+        oracle.forward(**act, sh_degree=3, **views[0].raster_kwargs(), num_threads=threads, want_binning=False)     # warm
+        t0, n = time.perf_counter(), 0
+        while n < 200 and (n < 3 or time.perf_counter() - t0 < args.cpu_budget_s / 3):
+            oracle.forward(**act, sh_degree=3, **views[n % len(views)].raster_kwargs(), num_threads=threads, want_binning=False)
+            n += 1
+        rows[threads] = n / (time.perf_counter() - t0)
+    best = max(rows, key=rows.get)
+    emit({"metric": f"CPU oracle views/sec (RGB+depth) on {cloud.n}-Gaussian scene @{views[0].width}x{views[0].height} (no GPU)",
+          "value": round(rows[best], 3), "unit": "views/s", "n_gpus": 0, "higher_is_better": True, "dtype": "f32",
+          "data": "synthetic", "cpu_only": True, "config": {"workload": label},
+          "cpu_baseline": {"value": round(rows[best], 3), "unit": "views/s", "cores": best, "kind": "port",
+                           "per_thread_count": {str(k): round(v, 3) for k, v in rows.items()},
+                           "sample": "oracle/pgr_oracle.c (reference-style lists) on the workload's first cameras"}})
+    return 0
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
+    if args.cpu_only:
+        if "--workload" not in " ".join(argv):
+            args.workload = "c1"
+        return run_cpu_only(args)
     if (args.gpus or 1) > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args, argv)
     if args.facade:

@@ -164,3 +164,12 @@ def test_dynamic_sequence_two_ranks_rehearsal(gpu_device):
     g = line["config"]["gather"]
     assert g["check"] == "ok" and g["views_per_s_with_gather"] > 0 and len(line["per_rank_s"]["all"]) == 2
     assert line["config"]["objects"] == 20
+
+
+def test_cpu_only_line_for_config_0():
+    """BASELINE.json configs[0] (10 k-Gaussian cube, 256x256, CPU rasterizer: plumbing, no GPU): `bench.py --cpu-only` times
+    the oracle alone and says so; no HIP device is touched."""
+    p, line = _run([sys.executable, "bench.py", "--cpu-only", "--cpu-budget-s", "1.5"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line["cpu_only"] is True and line["n_gpus"] == 0 and line["value"] > 0
+    assert "C1" in line["config"]["workload"] and line["cpu_baseline"]["kind"] == "port"
