@@ -818,12 +818,20 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
     except (OSError, ValueError, KeyError):
         pass
 
+    # the two side legs must not be able to lose the headline: a failure in one of them is recorded in its place
+    def side_leg(fn, *a, **kw):
+        try:
+            return fn(*a, **kw)
+        except Exception as e:                              # noqa: BLE001 (reported in the line, with its type)
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            return {"error": f"{type(e).__name__}: {e}"[:500]}
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = _cpu_baseline(args, eng)
+        cpu = side_leg(_cpu_baseline, args, eng)
     drop_in = None
     if world == 1 and not args.no_drop_in and with_masks and not args.dynamic and args.workload in ("c3", "c5"):
-        drop_in = drop_in_numbers(eng, n_frames=4, n_render_calls=48)
+        drop_in = side_leg(drop_in_numbers, eng, n_frames=4, n_render_calls=48)
 
     N_label = f"{N / 1e6:.2g}M"
     line.update(
