@@ -76,8 +76,6 @@ typedef struct PgrScene {
                                     computes it once into caller-owned memory. */
 } PgrScene;
 
-/* The fields of GaussianRasterizationSettings that describe one view.  Scalars are host values;
- * the four small tensors stay on the device exactly as PEGASUS's Camera holds them. */
 /* The depth image's blend rule.  The reference's rasterizer is the absent fork `depth-diff-gaussian-rasterization`
  * (/root/reference/setup.sh:19); the widely used fork of that name writes the un-normalised expected depth, which the
  * in-tree evidence is consistent with (/root/reference/pegasus.py:355 scales it to millimetres as is) -- but the rule
@@ -87,6 +85,8 @@ typedef struct PgrScene {
  *                                                                             nothing was blended) */
 typedef enum PgrDepthMode { PGR_DEPTH_EXPECTED = 0, PGR_DEPTH_NORMALIZED = 1 } PgrDepthMode;
 
+/* The fields of GaussianRasterizationSettings that describe one view.  Scalars are host values;
+ * the four small tensors stay on the device exactly as PEGASUS's Camera holds them. */
 typedef struct PgrCamera {
     int32_t image_width, image_height;
     float tanfovx, tanfovy;
@@ -98,8 +98,9 @@ typedef struct PgrCamera {
 } PgrCamera;
 
 typedef struct PgrOutputs {
-    float *color;                /* [3,H,W]  required */
-    float *depth;                /* [1,H,W]  required: sum_i T_i alpha_i z_i (no bg, not normalised) */
+    float *color;                /* [3,H,W]  required (except in a layered call, which writes no image) */
+    float *depth;                /* [1,H,W]  required (same exception): sum_i T_i alpha_i z_i, no bg term; PgrCamera::depth_mode
+                                    selects the normalised form */
     int32_t *radii;              /* [n]      required */
     float *final_T;              /* [H,W]    optional (NULL) */
     uint32_t *n_contrib;         /* [H,W]    optional (NULL) */
@@ -134,8 +135,9 @@ typedef struct PgrSemantic {
     const float *mask_colors;    /* device [k_objects,3]: the colours the masks are thresholded against (the c_k of
                                     /root/reference/src/gs/render.py:60-63,89-93), or NULL = no sem_masks output */
     float mask_threshold;        /* L2 distance, the reference's 0.1 */
-} PgrSemantic;                   /* checked before anything is enqueued: object_id, colors non-NULL, n_env >= 0,
-                                    k_objects > 0, outs[v].sem_color non-NULL for every view */
+} PgrSemantic;                   /* checked before anything is enqueued: object_id (unless the scene is empty), colors non-NULL,
+                                    n_env >= 0, k_objects > 0, outs[v].sem_color non-NULL for every view, mask_colors
+                                    non-NULL if any view passes sem_masks */
 
 /* Device pointers into one view's slice of a workspace, for stage-level parity tests and for backward. */
 typedef struct PgrWorkspaceView {
