@@ -883,3 +883,28 @@ def test_frame_records_from_the_compositor_equal_pack_records(gpu_device, size):
     want = M.pack_records(f["color"], f["depth"], f["masks"])
     ref, got = M.record_views(want, h, w, fr.K), M.record_views(f["records"], h, w, fr.K)
     assert all(torch.equal(got[k], ref[k]) for k in ref)
+
+
+@pytest.mark.parametrize("size", [(1, 1), (2, 3), (17, 3), (15, 33), (64, 1)])
+def test_tiny_and_ragged_images_through_the_round4_outputs(gpu_device, size):
+    """One-pixel, one-row, sub-tile and odd-sized images (record sections that start at odd byte counts, quarters that lie
+    partly or wholly outside the image) through the outputs round 4 added: layered silhouettes == per-object passes, records
+    from the epilogue == pgr_pack_records, fused masks == separate pass."""
+    import torch
+    from pegasus_amd import frames as F, masks as M
+    W, H = size
+    for k_obj in (1, 3):
+        cloud, views, _ = scenes.merged_scene(500 + W + H, 400, k_obj, 300, 3, W, H, plane_size=0.6)
+        act = cloud.activated()
+        fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"], cloud.object_id,
+                             sh_degree=3, device=gpu_device, bg=(0.1, 0.2, 0.3))
+        specs = [fr.view_spec(v) for v in views]
+        assert torch.equal(fr.render_silhouettes(specs).clone(), fr.render_silhouettes_per_object(specs).clone())
+        f = fr.alloc_frames(3, H, W, records=True)
+        fr.render_frames_async(specs, f, slot=0).wait()
+        want = M.pack_records(f["color"], f["depth"], f["masks"])
+        ref = fr.render_batch(specs)
+        torch.cuda.synchronize()
+        got_v, want_v = M.record_views(f["records"], H, W, fr.K), M.record_views(want, H, W, fr.K)
+        assert all(torch.equal(got_v[k], want_v[k]) for k in ("rgb", "depth_mm", "mask_bits"))
+        assert all(torch.equal(f[k], ref[k]) for k in ("color", "depth", "seg", "masks"))
