@@ -292,6 +292,7 @@ class FrameRenderer:
         if st is None:
             st = self._sil_streams[slot] = torch.cuda.Stream(dev)
         st.wait_stream(cur)
+        out.record_stream(st)                  # written on the slot's stream: the allocator must not recycle it under the pass
         if posed is not None:
             posed["poses"].record_stream(st)
         with torch.cuda.stream(st):
