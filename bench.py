@@ -45,6 +45,12 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_LANE_OPS = 78.6e12   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (SURVEY.md section 8d "secondary ceiling")
+# Vector-issue ceiling: 1024 SIMDs x 2.4 GHz / CYCLES_PER_WAVE_INST.  A wave64 single-rate VALU instruction (v_fma_f32,
+# v_mul, v_add, v_mov, v_cndmask) occupies its SIMD's issue port for 4 cycles on gfx950 -- measured with the shader's own
+# cycle counter, profiles/r05_valu_rates.txt (scripts/microbench/valu_rates.hip); the guide's "v_fma_f32 2 cyc" is the
+# datasheet FP32 rate, which only the packed forms (v_pk_fma_f32: 2 FMAs per lane in the same 4 cycles) reach.
+CYCLES_PER_WAVE_INST = 4.0
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / CYCLES_PER_WAVE_INST
 LANE_OPS_PER_EVAL = 20         # VALU lane-ops of one pixel-Gaussian evaluation (same section)
 SEQUENCE_STEPS = 200           # BASELINE.json configs[4]: "Dynamic 200-step physics sequence"
 
@@ -57,6 +63,10 @@ def parse(argv=None):
     ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c5"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink Gaussian counts (debug only; INVALID as a result)")
     ap.add_argument("--views", type=int, default=512, help="distinct cameras cycled through (configs[2]: 512 views)")
+    ap.add_argument("--camera-set", default="fibonacci", choices=["fibonacci", "fibonacci_above_9deg"],
+                    help="c3 / c5 cameras: fibonacci (default) = the first --views directions of the BOP toolkit's Fibonacci upper "
+                         "hemisphere, elevation 0..90 degrees, as SURVEY.md section 8d names them; fibonacci_above_9deg = the "
+                         "subset rounds 1-4 rendered (directions below ~8.6 degrees skipped and back-filled), for A/B only")
     ap.add_argument("--batch", type=int, default=32,
                     help="views per step (one batch call); 16 default steps x 32 = the 512 views of configs[2], each once")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -158,7 +168,17 @@ def self_launch(args, argv) -> int:
 # --------------------------------------------------------------------------------------------------------------------
 # workload
 
-def build_workload(name, scale, n_views, with_poses=False):
+CAMERA_SET_TEXT = {
+    "fibonacci": "first {n} directions of the BOP toolkit's Fibonacci upper hemisphere (sample_views mode='fibonacci', elevation "
+                 "0..90 degrees, grazing views included; golden: tests/golden/bop_fibonacci_views.npz), radius cycling 0.8..1.2 m, "
+                 "looking at the scene centre",
+    "fibonacci_above_9deg": "NOT the stated camera set: Fibonacci hemisphere directions with eye_dir.z > 0.15 (elevation above "
+                            "~8.6 degrees) only, the skipped ones back-filled by repeating directions at other radii (what rounds "
+                            "1-4 rendered; A/B only)",
+}
+
+
+def build_workload(name, scale, n_views, with_poses=False, camera_set="fibonacci"):
     from pegasus_amd import scenes
     rest = None
     if name == "c1":
@@ -168,10 +188,12 @@ def build_workload(name, scale, n_views, with_poses=False):
         cloud, views = scenes.scene_c2(n=int(150_000 * scale), n_views=n_views)
         label = "C2 single object 150k Gaussians, 800x800 hemisphere views"
     elif name == "c5":
-        cloud, views, rest = scenes.merged_scene(5, int(3_400_000 * scale), 20, int(80_000 * scale), n_views)
+        cloud, views, rest = scenes.merged_scene(5, int(3_400_000 * scale), 20, int(80_000 * scale), n_views,
+                                                 camera_set=camera_set)
         label = "C5 5M-Gaussian scene (3.4M environment + 20 objects), 800x800"
     else:
-        cloud, views, rest = scenes.merged_scene(3, int(1_360_000 * scale), 8, int(80_000 * scale), n_views)
+        cloud, views, rest = scenes.merged_scene(3, int(1_360_000 * scale), 8, int(80_000 * scale), n_views,
+                                                 camera_set=camera_set)
         label = "C3 merged env + 8 objects, 2M Gaussians, 800x800"
     if scale != 1.0:
         label += f" [scale={scale}: NOT the baseline config]"
@@ -204,7 +226,8 @@ class RealEngine:
         self.args, self.rank, self.world, self.dev, self.torch = args, rank, world, dev, torch
         B = self.B = max(1, args.batch)
         n_views_total = max(args.views, B) * world
-        cloud, views, label, rest = build_workload(args.workload, args.scale, n_views_total, with_poses=True)
+        cloud, views, label, rest = build_workload(args.workload, args.scale, n_views_total, with_poses=True,
+                                                   camera_set=args.camera_set)
         self.cloud, self.views, self.label = cloud, views, label
         self.act = act = cloud.activated()
         fr = self.fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"],
@@ -314,10 +337,10 @@ class RealEngine:
         # (round 4: one of five repeats of the dynamic runs took 8.3 instead of 5.4 ms per step)
         n = max(2, self.n_slots, self.args.warmup + self.args.steps)
         for _ in range(3):
-            before = dict(rasterizer._WS.capacity_hint)
+            before = rasterizer.capacity_hints()
             run_steps(0, n, False)                        # every slot: its stream, workspace and frame set exist after this
             self.sync()
-            if dict(rasterizer._WS.capacity_hint) == before:
+            if rasterizer.capacity_hints() == before:
                 break
 
 
@@ -470,11 +493,17 @@ def run_worker(args):
         if world != 1 or eng.stub:
             raise SystemExit("--facade measures the single-process drop-in path: run it with --gpus 1")
         d = drop_in_numbers(eng, n_frames=16, n_render_calls=128)
+        d_dyn = drop_in_numbers(eng, n_frames=16, n_render_calls=8, dynamic=True)
+        d["dynamic"] = {k: d_dyn[k] for k in ("mode", "frames_per_s", "ms_per_frame", "frames_per_s_all_data_points", "ms_per_part")}
+        mode = "DYNAMIC scene: every object re-posed between frames through the reference's three pose calls, the objects-only " \
+               "semantic scene rebuilt every frame" if args.dynamic else \
+               "static scene: the objects-only semantic scene and its render are shared by the two semantic wrappers and kept " \
+               "while no object moves"
         emit({"metric": "drop-in frames/sec through PEGASUS's per-camera loop (RGB+depth+visible masks+semantic "
-                        f"mask, one render() per data point; static scene: the objects-only semantic scene and its render are "
-                        f"shared by the two semantic wrappers and kept while no object moves) on {eng.cloud.n / 1e6:.2g}M-Gaussian scene @{eng.W}x{eng.H}",
-              "value": d["frames_per_s"], "unit": "frames/s", "n_gpus": 1, "higher_is_better": True,
-              "dtype": "f32", "data": "synthetic", "config": {"workload": eng.label, "objects": eng.fr.K},
+                        f"mask, one render() per data point; {mode}) on {eng.cloud.n / 1e6:.2g}M-Gaussian scene @{eng.W}x{eng.H}",
+              "value": d["dynamic"]["frames_per_s"] if args.dynamic else d["frames_per_s"], "unit": "frames/s", "n_gpus": 1,
+              "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+              "config": {"workload": eng.label, "objects": eng.fr.K, "camera_set": args.camera_set},
               "drop_in": d})
         return 0
     B, n_slots = eng.B, eng.n_slots
@@ -623,7 +652,12 @@ def run_worker(args):
             token = enqueue(i_chk, 0).wait()
             eng.sync()
             # the compositor's records against the pack kernel's on the same frames (sender side, every rank)
-            records_ok = bool(torch.equal(fg.send_buffer(0), eng.pack(token, torch.empty_like(fg.send_buffer(0)))))
+            # (section by section: neither writer touches the 16-byte alignment padding between the sections)
+            from pegasus_amd import masks as M_
+            k_rec = eng.fr.K if eng.with_masks else 0
+            got = M_.record_views(fg.send_buffer(0), eng.H, eng.W, k_rec)
+            want = M_.record_views(eng.pack(token, torch.zeros_like(fg.send_buffer(0))), eng.H, eng.W, k_rec)
+            records_ok = all(bool(torch.equal(got[kk], want[kk])) for kk in want)
             gather_finished(token, True)
         else:
             token = eng.step_blocking(i_chk)
@@ -759,9 +793,13 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
     dom_ms = float(mean_ms[dom]) / launches
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     evals_per_s = evals * B / (mean_ms[4] * 1e-3) if mean_ms[4] > 0 else None
+    # `bound` starts as "hbm" (the formula's bytes against the HBM peak) and is replaced below by what the counters show for
+    # this kernel when they are on file: the compositor and the binning walks are vector-ISSUE bound, not bandwidth bound
     roofline = {
         "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "hbm": {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5)},
+        "hbm_frac": round(achieved / HBM_PEAK_GBS, 5),
         "kernel_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(dom_bytes),
         "launches_per_step": launches,
         "stage_ms_per_view": {k: round(float(m) / B, 4) for k, m in zip(_lib.STAGE_NAMES, mean_ms)},
@@ -804,6 +842,24 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
             if "valu_busy" in k:
                 roofline["valu_issue"] = {"busy_frac": k["valu_busy"], "lds_busy_frac": k.get("lds_busy"), "kernel": kern,
                                           "definition": pmc.get("busy_definition")}
+                # What bounds the dominant kernel, by the counters: the larger of its VALU-issue occupancy, its LDS occupancy
+                # and its HBM fraction (counter traffic / live duration).  The kernel's wave-instruction count is a property of
+                # the workload (SQ_INSTS_VALU per launch, profiles/pmc.json); its duration is measured live, above.
+                hbm_live = k["traffic_bytes_per_launch"] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if dom_ms > 0 else 0.0
+                cand = {"valu_issue": float(k["valu_busy"]), "lds": float(k.get("lds_busy") or 0.0), "hbm": hbm_live}
+                bound = max(cand, key=cand.get)
+                roofline["bound_by_counters"] = {kk: round(v, 4) for kk, v in cand.items()}
+                if bound == "valu_issue" and "valu_insts_per_launch" in k and dom_ms > 0:
+                    inst_rate = k["valu_insts_per_launch"] / (dom_ms * 1e-3)
+                    roofline.update(bound="valu_issue", achieved=round(inst_rate / 1e9, 3), peak=round(VALU_ISSUE_PEAK / 1e9, 1),
+                                    unit="G wave-inst/s", frac=round(inst_rate / VALU_ISSUE_PEAK, 4),
+                                    frac_definition="vector wave-instructions of this kernel per launch (SQ_INSTS_VALU, "
+                                                    "profiles/pmc.json) / its live HIP-event duration, against 1024 SIMDs x 2.4 GHz / "
+                                                    f"{CYCLES_PER_WAVE_INST:g} cycles per wave64 instruction (profiles/r05_valu_rates.txt); "
+                                                    "busy_frac in valu_issue is the same quantity from SQ_ACTIVE_INST_VALU under the "
+                                                    "profiler's clock; the HBM figure of the same kernel is `hbm` / `hbm_frac`")
+                elif bound == "lds":
+                    roofline.update(bound="lds", frac=round(cand["lds"], 4), achieved=None, peak=None, unit="LDS-busy fraction")
                 # the whole path as an instruction budget: vector wave-instructions per view of every kernel one frames
                 # batch launches (the other two compositor variants in the file belong to the profiled / raster-only passes)
                 per_view = {name: kk["valu_insts_per_launch"] / B for name, kk in pmc["kernels"].items()
@@ -811,7 +867,7 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
                 total = sum(per_view.values())
                 roofline["valu_issue"]["path"] = {
                     "wave_insts_per_view": round(total), "wave_insts_per_s": round(total * value / world, 1),
-                    "peak_wave_insts_per_s": 1024 * 2.4e9 / 4, "frac": round(total * value / world / (1024 * 2.4e9 / 4), 4),
+                    "peak_wave_insts_per_s": VALU_ISSUE_PEAK, "frac": round(total * value / world / VALU_ISSUE_PEAK, 4),
                     "share": {name: round(v / total, 3) for name, v in sorted(per_view.items(), key=lambda kv: -kv[1]) if v / total >= 0.005},
                     "definition": "SQ_INSTS_VALU per 32-view launch / 32, summed over the kernels of one frames batch; "
                                   "x frames/s = vector wave-instructions issued per second, against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"}
@@ -832,6 +888,10 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
     drop_in = None
     if world == 1 and not args.no_drop_in and with_masks and not args.dynamic and args.workload in ("c3", "c5"):
         drop_in = side_leg(drop_in_numbers, eng, n_frames=4, n_render_calls=48)
+        dyn = side_leg(drop_in_numbers, eng, n_frames=4, n_render_calls=4, dynamic=True)
+        if isinstance(drop_in, dict) and "error" not in drop_in:
+            drop_in["dynamic"] = ({k: dyn[k] for k in ("mode", "frames_per_s", "ms_per_frame", "frames_per_s_all_data_points",
+                                                       "ms_per_part")} if "error" not in dyn else dyn)
 
     N_label = f"{N / 1e6:.2g}M"
     line.update(
@@ -839,6 +899,8 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
                 f"rendered views/sec (RGB+depth, raster only) on {N_label}-Gaussian scene @{W}x{H}"),
         config={"workload": eng.label, "gaussians": N, "width": W, "height": H, "views_per_step": B,
                 "distinct_views": len(eng.views) // world, "objects": fr.K,
+                "camera_set": (args.camera_set + ": " + CAMERA_SET_TEXT[args.camera_set].format(n=len(eng.views))
+                               if args.workload in ("c3", "c5") else "the workload's own views"),
                 "sequence": (f"dynamic: every frame is a time step of the reference's recorded drop (simulation_steps.json "
                              f"body 1, steps 0..{SEQUENCE_STEPS - 1}, per-object phase offsets; poses composed absolutely and "
                              f"applied inside the preprocess) + BOP pose records" if args.dynamic else
@@ -912,7 +974,7 @@ def _cpu_baseline(args, eng):
 # --------------------------------------------------------------------------------------------------------------------
 # the drop-in path: what unchanged PEGASUS calls
 
-def drop_in_numbers(eng, n_frames=4, n_render_calls=48):
+def drop_in_numbers(eng, n_frames=4, n_render_calls=48, dynamic=False):
     """PEGASUS's own per-camera loop on this scene (/root/reference/pegasus.py:254-358): per frame one deepcopy + merge of
     the scene, then render_rgb_and_depth, render_visib_mask and render_semanticsegmentation_mask through
     pegasus_amd/render.py's wrappers (same names and arguments as /root/reference/src/gs/render.py) -- and the latency of a
@@ -947,7 +1009,32 @@ def drop_in_numbers(eng, n_frames=4, n_render_calls=48):
     H, W = eng.H, eng.W
 
     parts = {"compose": 0.0, "render_rgb_and_depth": 0.0, "render_visib_mask": 0.0, "render_semanticsegmentation_mask": 0.0,
-             "render_silhouette_mask": 0.0}
+             "render_silhouette_mask": 0.0, "update_object_pose": 0.0}
+
+    # DYNAMIC mode of the unchanged loop (/root/reference/pegasus.py:387-390 -> src/gs/pegasus_setup.py:178-226): after every
+    # frame each object receives the DELTA between two samples of its recorded trajectory through the reference's three
+    # calls (apply_transformation_on_xyz, apply_rotation_on_splats, apply_rotation_on_sh) -- which replaces its tensors, so
+    # the kept objects-only semantic scene of pegasus_amd/render.py is rebuilt every frame
+    traj = None
+    if dynamic:
+        from scipy.spatial.transform import Rotation
+        from pegasus_amd import trajectory as TJ
+        traj = TJ.load_fixture()
+    step = {"i": 0}
+
+    def update_object_pose():
+        i = step["i"] = step["i"] + 1
+        for k, obj in objects.items():
+            a, b = min(len(traj) - 1, i + 5 * (k - 1)), min(len(traj) - 1, i - 1 + 5 * (k - 1))
+            t_delta = torch.from_numpy(traj[a, 0:3] - traj[b, 0:3]).type(torch.float32).to(dev)
+            q_delta = Rotation.from_quat(traj[a, 3:7]) * Rotation.from_quat(traj[b, 3:7]).inv()
+            Rm = torch.from_numpy(q_delta.as_matrix()).type(torch.float32).to(dev)
+            T = torch.eye(4, dtype=torch.float32, device=dev)
+            T[:3, :3] = Rm
+            T[:3, 3] = t_delta
+            obj.apply_transformation_on_xyz(T=T)                     # pegasus_setup.py:195-208
+            obj.apply_rotation_on_splats(R=Rm)
+            obj.apply_rotation_on_sh(R=Rm)
 
     def lap(name, t_prev):
         torch.cuda.synchronize()
@@ -972,6 +1059,9 @@ def drop_in_numbers(eng, n_frames=4, n_render_calls=48):
         if silhouettes or clock:                                     # 'seg_sil' (pegasus.py:491's fifth data point)
             sil = RW.render_silhouette_mask(cam, objects, env, W, H, color_set, pipe, bg)
             t = lap("render_silhouette_mask", t) if clock else t
+        if traj is not None:
+            update_object_pose()
+            t = lap("update_object_pose", t) if clock else t
         return scene
 
     with torch.no_grad():
@@ -999,7 +1089,8 @@ def drop_in_numbers(eng, n_frames=4, n_render_calls=48):
             GR.render(c, scene, pipe, bg)
         torch.cuda.synchronize()
         t_call = (time.perf_counter() - t0) / min(n_render_calls, len(cams))
-    return {"frames_per_s": round(1.0 / t_frame, 2), "ms_per_frame": round(t_frame * 1e3, 3),
+    return {"mode": "dynamic" if dynamic else "static",
+            "frames_per_s": round(1.0 / t_frame, 2), "ms_per_frame": round(t_frame * 1e3, 3),
             "frames_per_s_all_data_points": round(1.0 / t_frame_all, 2),
             "render_call_ms": round(t_call * 1e3, 4), "render_calls_per_s": round(1.0 / t_call, 1),
             "ms_per_part": {k: round(v / n_frames * 1e3, 3) for k, v in parts.items()},
@@ -1007,8 +1098,10 @@ def drop_in_numbers(eng, n_frames=4, n_render_calls=48):
                      "as the reference returns them) and render_semanticsegmentation_mask -- the ['rgb','seg_vis','sem_seg'] "
                      "data points of /root/reference/pegasus.py:254-358, one camera per frame (frames_per_s_all_data_points: + "
                      "render_silhouette_mask, 'seg_sil': all K objects in one layered call, K float64 masks to the host).  STATIC scene: the two semantic "
-                     "wrappers share one objects-only scene and one render per camera, kept while no object moves; a dynamic "
-                     "run rebuilds that scene every frame and is slower than this figure",
+                     "wrappers share one objects-only scene and one render per camera, kept while no object moves.  DYNAMIC "
+                     "(mode = dynamic): after every frame each object is moved by the delta of its recorded trajectory through the "
+                     "reference's three pose calls (pegasus.py:387-390, pegasus_setup.py:178-208), so the objects-only scene is "
+                     "rebuilt every frame",
             "sample": f"{n_frames} frames, {min(n_render_calls, len(cams))} render() calls; same scene and cameras as the batch path"}
 
 
@@ -1017,7 +1110,7 @@ def run_cpu_only(args):
     run anything under oracle/)."""
     import oracle
     oracle.build()
-    cloud, views, label = build_workload(args.workload, args.scale, max(1, min(args.views, 8)))
+    cloud, views, label = build_workload(args.workload, args.scale, max(1, min(args.views, 8)), camera_set=args.camera_set)
     act = cloud.activated()
     n_cpu = os.cpu_count() or 1
     rows = {}

@@ -14,6 +14,7 @@ import os
 # from build_variants/ instead of overwriting the product .so)
 LIB_PATH = Path(os.environ.get("PGR_LIB") or Path(__file__).resolve().parent / "csrc" / "libpegasus_raster.so")
 
+PGR_ABI_VERSION = 2          # include/pegasus_raster.h PGR_ABI_VERSION
 PGR_OK = 0
 PGR_ERR_INVALID_ARGUMENT = -1
 PGR_ERR_WORKSPACE_TOO_SMALL = -2
@@ -164,12 +165,23 @@ def lib():
             handle = C.CDLL(str(LIB_PATH))
         except OSError as e:
             raise RasterizerLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        # the ABI version first, binding only that symbol: a stale or variant build (PGR_LIB) then fails with the
+        # version message, not with an AttributeError on whichever newer entry point it lacks
+        try:
+            ver_fn = handle.pgr_abi_version
+        except AttributeError as e:
+            raise RasterizerLibraryError(f"{LIB_PATH} does not export pgr_abi_version: not a pegasus_raster library") from e
+        ver_fn.restype, ver_fn.argtypes = C.c_int32, []
+        if ver_fn() != PGR_ABI_VERSION:
+            raise RasterizerLibraryError(f"{LIB_PATH}: ABI version {ver_fn()} but this package binds version "
+                                         f"{PGR_ABI_VERSION}; rebuild with `python -m pegasus_amd.build`")
         for name, (res, args) in SYMBOLS.items():
-            fn = getattr(handle, name)
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise RasterizerLibraryError(f"{LIB_PATH} does not export {name} (include/pegasus_raster.h)") from e
             fn.restype = res
             fn.argtypes = args
-        if handle.pgr_abi_version() != 2:
-            raise RasterizerLibraryError("libpegasus_raster.so ABI version mismatch")
         _lib = handle
     return _lib
 

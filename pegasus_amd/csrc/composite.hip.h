@@ -115,14 +115,6 @@ constexpr int PAIR_UNROLL = PGR_PAIR_UNROLL;   // entry pairs per trip of the co
 #define PGR_COMP_OCC
 #endif
 
-#ifdef PGR_COMP_STATS
-// debug build only: [0] list entries walked, [1] live entries after the skip test, [2] wave-entries evaluated,
-// [3] pixel-entries with the pixel still alive, [4] pixel-entries blended, [5] waves, [6] batches, [7] semantic wave-entries
-// [8] fused waves, [9] tail batches (scene pixels saturated, semantic walk only), [10] tail entries walked, [11] tail entries gathered (object entries),
-// [12] tail entries live after the skip test, [13] waves that enter the tail, [14] waves that walk to the last object entry
-// [15] longest wave in shader clocks, [16] its batches, [17..20] waves with > 16 / 32 / 64 / 96 batches, [21] sum of wave clocks
-__device__ unsigned long long g_comp_stats[32];
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // composite_quarter_kernel: ONE WAVE per quarter tile (8 x 8 pixels), one pixel per lane; ONE launch covers every
@@ -232,12 +224,6 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
     const float rx0 = (float)qx0, ry0 = (float)qy0;
     const float rx1 = fminf(rx0 + 7.0f, (float)(W - 1)), ry1 = fminf(ry0 + 7.0f, (float)(H - 1));
 
-#ifdef PGR_COMP_STATS
-    unsigned long long st_walk = 0, st_live = 0, st_eval = 0, st_alive = 0, st_blend = 0, st_batches = 0, st_sem = 0;
-    unsigned long long st_tb = 0, st_tw = 0, st_tg = 0, st_tl = 0, st_tend = 0;
-    unsigned long long st_mode_b[3] = {0, 0, 0}, st_mode_e[3] = {0, 0, 0};     // batches / parked entries per pair-loop mode
-    const unsigned long long st_t0 = __builtin_readcyclecounter();
-#endif
     for (int base = 0; base < n; base += WAVE_BATCH) {
         if (alive == 0ull && (sem_alive == 0ull || base >= n_sem)) break;
         // The skip test only has to cover pixels that can still change: the bounding box of the alive lanes (lane =
@@ -273,11 +259,6 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
         const int cnt = __popcll(mask);
         const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-#ifdef PGR_COMP_STATS
-        st_walk += min(WAVE_BATCH, n - base); st_live += cnt; st_batches++;
-        if (FUSED && alive == 0ull) { st_tb++; st_tw += min(WAVE_BATCH, n_sem - base); st_tg += __popcll(__ballot(have)); st_tl += cnt;
-                                      if (base + WAVE_BATCH >= n_sem) st_tend = 1; }
-#endif
         if (live) {
             float* gq = s_gf + 12 * (pos >> 1) + (pos & 1);
             gq[0] = p.x;  gq[2] = p.y;
@@ -320,9 +301,6 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
         int mode = MODE_PLAIN;
         if (FUSED && objbits != 0ull) mode = (pure && objbits == parked_bits) ? MODE_RIDE : MODE_GENERAL;
         if (FUSED && mode == MODE_PLAIN && cnt > 0) pure = false;
-#ifdef PGR_COMP_STATS
-        if (FUSED && cnt > 0) { st_mode_b[mode] += 1; st_mode_e[mode] += (unsigned long long)cnt; }
-#endif
         bool all_done = false;
         auto pair_loop = [&](auto mode_tag) __attribute__((always_inline)) {
         constexpr int MODE = decltype(mode_tag)::value;
@@ -367,9 +345,6 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
                     alive &= ~stop;
                     const unsigned long long blend = valid & ~stop;
                     const bool bl = __builtin_amdgcn_inverse_ballot_w64(blend);
-#ifdef PGR_COMP_STATS
-                    st_eval++; st_alive += __popcll(alive | stop); st_blend += __popcll(blend);
-#endif
                     // blended: T' = fma(-alpha, T, T) = test_T; not blended: weight 0 (exact no-op) and T unchanged
                     const float w = bl ? alpha * T : 0.0f;
                     const f32x2 wv = {w, w};
@@ -379,17 +354,11 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
                     if (AUX) last = bl ? s_i[2 * k + u] : last;
                     if (MODE == MODE_RIDE) {                 // every entry of this batch rides: no test, state set behind the loop
                         const float4 sc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_s) + oc + (2 * ku + u) * 16);
-#ifdef PGR_COMP_STATS
-                        st_sem += 1ull << 32;
-#endif
                         Srg = __builtin_elementwise_fma((f32x2){sc.x, sc.y}, wv, Srg);
                         Sbd = __builtin_elementwise_fma((f32x2){sc.z, sc.w}, wv, Sbd);
                     }
                     if (SEM && pure && obj_entry) {          // same weight, same stop mask: two FMAs are the whole blend
                         const float4 sc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_s) + oc + (2 * ku + u) * 16);
-#ifdef PGR_COMP_STATS
-                        st_sem += 1ull << 32;
-#endif
                         Srg = __builtin_elementwise_fma((f32x2){sc.x, sc.y}, wv, Srg);
                         Sbd = __builtin_elementwise_fma((f32x2){sc.z, sc.w}, wv, Sbd);
                         Ts = T;
@@ -401,9 +370,6 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
                     if (const unsigned long long valid = sem_alive & hit; obj_entry && valid != 0ull) {
                         const float4 sc = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_s) + oc + (2 * ku + u) * 16);
                         const float depth = sc.w;
-#ifdef PGR_COMP_STATS
-                        st_sem++;
-#endif
                         const float test_T = fmaf(-alpha, Ts, Ts);
                         const unsigned long long stop = valid & __builtin_amdgcn_ballot_w64(test_T < T_EPS);
                         sem_alive &= ~stop;
@@ -429,22 +395,6 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
         if (all_done) break;
         __syncthreads();
     }
-#ifdef PGR_COMP_STATS
-    if (lane == 0) {
-        atomicAdd(&g_comp_stats[0], st_walk); atomicAdd(&g_comp_stats[1], st_live); atomicAdd(&g_comp_stats[2], st_eval);
-        atomicAdd(&g_comp_stats[3], st_alive); atomicAdd(&g_comp_stats[4], st_blend); atomicAdd(&g_comp_stats[5], 1ull);
-        atomicAdd(&g_comp_stats[6], st_batches); atomicAdd(&g_comp_stats[7], st_sem);
-        { const unsigned long long dt = __builtin_readcyclecounter() - st_t0;
-          if (atomicMax(&g_comp_stats[15], dt) < dt) g_comp_stats[16] = st_batches;
-          if (st_batches > 16) atomicAdd(&g_comp_stats[17], 1ull); if (st_batches > 32) atomicAdd(&g_comp_stats[18], 1ull);
-          if (st_batches > 64) atomicAdd(&g_comp_stats[19], 1ull); if (st_batches > 96) atomicAdd(&g_comp_stats[20], 1ull);
-          atomicAdd(&g_comp_stats[21], dt); }
-        if (FUSED) { atomicAdd(&g_comp_stats[8], 1ull); atomicAdd(&g_comp_stats[9], st_tb); atomicAdd(&g_comp_stats[10], st_tw);
-                     atomicAdd(&g_comp_stats[11], st_tg); atomicAdd(&g_comp_stats[12], st_tl); atomicAdd(&g_comp_stats[13], st_tb ? 1ull : 0ull);
-                     atomicAdd(&g_comp_stats[14], st_tend);
-                     for (int m = 0; m < 3; ++m) { atomicAdd(&g_comp_stats[22 + m], st_mode_b[m]); atomicAdd(&g_comp_stats[25 + m], st_mode_e[m]); } }
-    }
-#endif
     const size_t P = (size_t)W * H;
     const size_t pix = pix32;
     // depth rule (PgrDepthMode): the un-normalised sum, or the sum over 1 - T_final (= the blended weights' total)

@@ -22,9 +22,6 @@
 #include "pgr_common.h"
 #include "preprocess.hip.h"
 #include "tilebin.hip.h"
-#ifdef PGR_REACH_BITS
-#include "composite_reach.hip.h"      // experiment build only (round 4: reach bits per quarter; measured negative)
-#endif
 
 namespace pgr {
 
@@ -395,10 +392,6 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
             bin_table, L.tiles, sort_queue + qs, n_queue + 1);
     }
     tile_sort_kernel<<<items, SORT_THREADS, 0, stream>>>(bin_table, L.tiles, sort_queue, n_queue);
-#ifdef PGR_REACH_BITS
-    const bool reach_path = !want_sem && !layers && getenv("PGR_REACH") && getenv("PGR_REACH")[0] == '1';
-    if (reach_path) reach_bits_kernel<<<dim3(L.tiles, n_views), 256, 0, stream>>>(view_table, L.tiles, bin_table);
-#endif
     mark(4);
     // ---- stage 4: compositing of every (view, tile, quarter) work item in ONE launch; with `semantic` the same
     // walk also produces the objects-only semantic image
@@ -416,12 +409,6 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         sd = SemanticDev{semantic->object_id, ids_u8, semantic->colors, semantic->n_env, semantic->k_objects,
                          semantic->mask_colors, semantic->mask_threshold, layer_tiles};
     }
-#ifdef PGR_REACH_BITS
-    if (reach_path) {
-        if (want_aux) composite_reach_kernel<true><<<slots, WAVE, 0, stream>>>(view_table, items_per_view, work_order, bin_table);
-        else composite_reach_kernel<false><<<slots, WAVE, 0, stream>>>(view_table, items_per_view, work_order, bin_table);
-    } else
-#endif
     if (layers) {
         sd.mask_colors = layers->mask_colors; sd.mask_thr = layers->mask_threshold; sd.k = n_layers;
         // empty (layer, tile) lists have no work item: their pixels hold the background's verdict
@@ -785,45 +772,9 @@ int32_t pgr_pack_records(const float* color_b3hw, const float* depth_bhw, const 
 
 }  // extern "C"
 
-#ifdef PGR_COMP_STATS
-extern "C" int32_t pgr_debug_comp_stats(unsigned long long* out, int32_t reset) {
-    if (hipDeviceSynchronize() != hipSuccess) return -4;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pgr::g_comp_stats), 256) != hipSuccess) return -4;
-    if (reset) { unsigned long long z[32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(pgr::g_comp_stats), z, 256) != hipSuccess) return -4; }
-    return 0;
-}
-#endif
 
-#ifdef PGR_LAZY_PROBE
-extern "C" int32_t pgr_debug_set_lazy(uint32_t mode, uint32_t percent) {
-    const unsigned int v[2] = {mode, percent};
-    if (hipDeviceSynchronize() != hipSuccess) return -4;
-    return hipMemcpyToSymbol(HIP_SYMBOL(pgr::g_lazy), v, 8) == hipSuccess ? 0 : -4;
-}
-#endif
 
-#ifdef PGR_SORT_STATS
-extern "C" int32_t pgr_debug_sort_stats(unsigned long long* out, int32_t reset) {
-    if (hipDeviceSynchronize() != hipSuccess) return -4;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pgr::g_sort_stats), 64) != hipSuccess) return -4;
-    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(pgr::g_sort_stats), z, 64) != hipSuccess) return -4; }
-    return 0;
-}
-#endif
 
-#ifdef PGR_SORT_TIMING
-// copies up to `cap` records (12 x u64 each) to the host and resets the recorder; returns the number recorded
-extern "C" int32_t pgr_debug_sort_timing(unsigned long long* out, int32_t cap) {
-    if (hipDeviceSynchronize() != hipSuccess) return -4;
-    unsigned int n = 0;
-    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(pgr::g_sort_rec_n), 4) != hipSuccess) return -4;
-    const unsigned int take = std::min<unsigned int>(std::min<unsigned int>(n, (unsigned)cap), (unsigned)pgr::SORT_REC_MAX);
-    if (take && hipMemcpyFromSymbol(out, HIP_SYMBOL(pgr::g_sort_rec), (size_t)take * 96) != hipSuccess) return -4;
-    const unsigned int zero = 0;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(pgr::g_sort_rec_n), &zero, 4) != hipSuccess) return -4;
-    return (int32_t)take;
-}
-#endif
 
 // ---- 3-nearest-neighbour mean squared distance (simple_knn.distCUDA2) ---------------------------------------------
 namespace {

@@ -550,33 +550,9 @@ __device__ __forceinline__ void merge_sort_tile(uint64_t* __restrict__ skeys, co
 // is a count of the smaller keys among the bucket's few members.  ~10 LDS operations per key instead of the merge
 // sort's ~35 (log2(n) merge-path rounds).  Lists whose depths pile up (sum of squared bucket counts > 8 n) are
 // rejected and take the merge sort; the result never depends on which path ran.
-#ifdef PGR_SORT_STATS
-__device__ unsigned long long g_sort_stats[8];   // [0] lists, [1] keys, [2] sum k^2, [3] rejected lists, [4] rejected keys
-#endif
-#ifdef PGR_LAZY_PROBE
-// MEASUREMENT PROBE ONLY (round 4, lazy-sort upper bounds; the lists it produces are WRONG behind the cut): keys whose bucket
-// starts at or behind g_lazy[1] percent of their list are [0] = 1: not ranked inside their bucket (arrival order),
-// [0] = 2: neither parked, ranked nor written (the output keeps what an earlier sort left there).
-__device__ unsigned int g_lazy[2];
-#endif
 
 constexpr uint32_t BUCKET_SQ_LIMIT = 8;
 
-#ifdef PGR_SORT_TIMING
-// debug build only: shader-clock stamps of wave 0 at the phase boundaries of bucket_sort_tile, one record per list
-// (no atomics on shared words while the kernel runs: one slot claim at the end).  scripts/sort_timing.py
-constexpr int SORT_REC_MAX = 1 << 18;
-__device__ unsigned long long g_sort_rec[SORT_REC_MAX][12];    // [0..8] phase cycles, [9] tier, [10] keys, [11] start stamp
-__device__ unsigned int g_sort_rec_n;
-#define SORT_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
-    ts_[k] = now_ - t_prev_; t_prev_ = now_; } } while (0)
-#define SORT_FLUSH() do { if (threadIdx.x == 0) { const unsigned int slot_ = atomicAdd(&g_sort_rec_n, 1u); \
-    if (slot_ < (unsigned)SORT_REC_MAX) { for (int k_ = 0; k_ < 9; ++k_) g_sort_rec[slot_][k_] = ts_[k_]; \
-    g_sort_rec[slot_][9] = TIER_; g_sort_rec[slot_][10] = (unsigned long long)n; g_sort_rec[slot_][11] = t_start_; } } } while (0)
-#else
-#define SORT_STAMP(k) do { } while (0)
-#define SORT_FLUSH() do { } while (0)
-#endif
 
 // Sorts n <= THREADS*E keys of `bucket` into out[] (indices) -- same contract as merge_sort_tile without keys_out.
 // NB = number of buckets (multiple of THREADS; THREADS*E = one per key of capacity).  DIRECT: sorted indices go
@@ -597,11 +573,6 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
     uint32_t* s_hist = reinterpret_cast<uint32_t*>(lds + (size_t)KEYS * 8);    // [NB], later the sorted indices
     uint32_t* s_misc = s_hist + NB;                                            // [0] min [1] max [2] sum k^2 [4..] wave totals
     const int t = threadIdx.x, lane = t & (WAVE - 1), wave = t / WAVE;
-#ifdef PGR_SORT_TIMING
-    constexpr int TIER_ = THREADS == 256 ? 0 : (THREADS == 512 ? 1 : (E == 8 ? 2 : 3));
-    unsigned long long t_prev_ = __builtin_readcyclecounter(), ts_[9] = {};
-    const unsigned long long t_start_ = t_prev_;
-#endif
 
     // All E loads of a thread are issued back to back (index clamped into the list, n >= 1) and waited for once: a
     // load inside `if (i < n)` is not hoisted by the compiler, and E branches each ending in s_waitcnt vmcnt(0) made
@@ -622,14 +593,14 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
     for (int i = t; i < NB; i += THREADS) s_hist[i] = 0u;
     if (t < 4 + WAVES) s_misc[t] = t == 0 ? 0xffffffffu : 0u;
     __syncthreads();
-    SORT_STAMP(0);      // key load + zero fill
+    // -- key load + zero fill done
     // block min / max of the depth bits: DPP prefix inside the wave (VALU only: a ds_bpermute butterfly pays six LDS
     // round trips), one LDS atomic per wave.  min as max of the complement (0 is the prefix-max identity).
     dmin = ~wave_inclusive_max(~dmin);
     dmax = wave_inclusive_max(dmax);
     if (lane == WAVE - 1) { atomicMin(&s_misc[0], dmin); atomicMax(&s_misc[1], dmax); }
     __syncthreads();
-    SORT_STAMP(1);      // min / max
+    // -- min / max done
     const uint32_t mn = s_misc[0];
     const float scale = (float)NB / ((float)(s_misc[1] - mn) + 1.0f);
     // monotone in d: uint->float conversion, multiplication by a positive constant, truncation and clamp all are
@@ -643,7 +614,7 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
         }
     }
     __syncthreads();
-    SORT_STAMP(2);      // histogram atomics
+    // -- histogram atomics done
     // pass A: every wave owns NB / WAVES consecutive buckets (CH chunks of 64): totals and sum of squares
     const int wbase = wave * (WAVE * CH);
     uint32_t tot = 0, sq = 0;
@@ -656,16 +627,9 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
     sq = wave_inclusive_scan(sq);
     if (lane == WAVE - 1) { s_misc[4 + wave] = tot; atomicAdd(&s_misc[2], sq); }
     __syncthreads();
-    SORT_STAMP(3);      // totals + squares
+    // -- totals + squares done
     // average occupancy is n / NB by construction: reject when the squares exceed what an even spread would cost
     const bool reject = s_misc[2] > BUCKET_SQ_LIMIT * (uint32_t)n * (uint32_t)((CAP + NB - 1) / NB);
-#ifdef PGR_SORT_STATS
-    if (t == 0) {
-        atomicAdd(&g_sort_stats[0], 1ull); atomicAdd(&g_sort_stats[1], (unsigned long long)n);
-        atomicAdd(&g_sort_stats[2], (unsigned long long)s_misc[2]);
-        if (reject) { atomicAdd(&g_sort_stats[3], 1ull); atomicAdd(&g_sort_stats[4], (unsigned long long)n); }
-    }
-#endif
     if (reject) { __syncthreads(); return false; }
     // pass B: exclusive scan of the counts -> bucket starts
     uint32_t carry = 0;
@@ -680,21 +644,18 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
         carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
     }
     __syncthreads();
-    SORT_STAMP(4);      // scan
+    // -- scan done
     uint32_t fin[E];     // here: bucket start | members << 16
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         fin[e] = 0u;
         if (e * THREADS + t < n) {
             fin[e] = s_hist[br[e] >> 16];
-#ifdef PGR_LAZY_PROBE
-            if (g_lazy[0] == 2u && (fin[e] & 0xffffu) * 100u >= g_lazy[1] * (uint32_t)n) continue;
-#endif
             s_keys[(fin[e] & 0xffffu) + (br[e] & 0xffffu)] = ((uint64_t)d[e] << 32) | id[e];
         }
     }
     __syncthreads();
-    SORT_STAMP(5);      // keys to their buckets
+    // -- keys to their buckets done
     // exact place inside the bucket: number of smaller keys among its members.  A key alone in its bucket (about half
     // of them at one bucket per key) is in place already: no LDS access at all.  (Tried and measured slower: advancing
     // the keys of a thread in lockstep, member m of every key's bucket per round -- the predicated reads did not
@@ -704,13 +665,7 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
         if (e * THREADS + t < n) {
             const uint32_t s0 = fin[e] & 0xffffu, cnt = fin[e] >> 16;
             uint32_t rank = 0;
-#ifdef PGR_LAZY_PROBE
-            const bool lazy_back = g_lazy[0] != 0u && s0 * 100u >= g_lazy[1] * (uint32_t)n;
-            if (lazy_back) rank = br[e] & 0xffffu;
-            if (cnt > 1u && !lazy_back) {
-#else
             if (cnt > 1u) {
-#endif
                 const uint64_t key = ((uint64_t)d[e] << 32) | id[e];
                 uint32_t same = 0;                       // members with this key's depth bits (itself included)
                 // the first RANK_BATCH members in ONE LDS round trip (independent reads, index clamped into the bucket);
@@ -743,20 +698,14 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
                 }
             }
             fin[e] = s0 + rank;
-#ifdef PGR_LAZY_PROBE
-            if (lazy_back && g_lazy[0] == 2u) fin[e] = 0xffffffffu;
-#endif
         }
     }
-    SORT_STAMP(6);      // rank inside the bucket
+    // -- rank inside the bucket done
     if (DIRECT) {
         uint32_t best = 0;
 #pragma unroll
         for (int e = 0; e < E; ++e)
             if (e * THREADS + t < n) {
-#ifdef PGR_LAZY_PROBE
-                if (fin[e] == 0xffffffffu) continue;
-#endif
                 gstore(out + fin[e], id[e]);
                 if (n_env >= 0 && (int)id[e] >= n_env) best = max(best, pos_offset + fin[e] + 1u);
             }
@@ -765,32 +714,19 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
             for (int m = 1; m < WAVE; m <<= 1) best = max(best, (uint32_t)__shfl_xor((int)best, m));
             if (lane == 0 && best) gatomic_max(obj_last, best);
         }
-        SORT_STAMP(7);  // direct output
-        SORT_FLUSH();
+        // -- direct output done
         return true;
     }
     __syncthreads();
     uint32_t* s_idx = s_hist;
 #pragma unroll
     for (int e = 0; e < E; ++e)
-#ifdef PGR_LAZY_PROBE
-        if (e * THREADS + t < n && fin[e] != 0xffffffffu) s_idx[fin[e]] = id[e];
-#else
         if (e * THREADS + t < n) s_idx[fin[e]] = id[e];
-#endif
     __syncthreads();
-#ifdef PGR_LAZY_PROBE
-    {   // mode 2 writes only the front part (the back keeps what an earlier sort left there: valid indices, wrong order)
-        const int n_out = g_lazy[0] == 2u ? (int)(((unsigned long long)g_lazy[1] * (unsigned)n + 99ull) / 100ull) : n;
-        for (int i = t; i < min(n, n_out); i += THREADS) gstore(out + i, s_idx[i]);
-    }
-#else
     for (int i = t; i < n; i += THREADS) gstore(out + i, s_idx[i]);
-#endif
-    SORT_STAMP(7);      // index image + output
+    // -- index image + output done
     if (n_env >= 0) mark_last_object<THREADS>([&](int i) { return s_idx[i]; }, n, n_env, obj_last, pos_offset);
-    SORT_STAMP(8);      // last object marker
-    SORT_FLUSH();
+    // -- last object marker done
     return true;
 }
 

@@ -40,6 +40,7 @@ def main():
         raise SystemExit("pegasus_amd.generate needs a HIP device")
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count()}"
+    torch.cuda.set_device(device)            # every default-device allocation and the synchronize() below: THIS rank's GPU
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -59,7 +60,10 @@ def main():
         p = act["means3d"][cloud.object_id == k].astype(np.float64)
         lo, hi = p.min(0), p.max(0)
         boxes[k] = (np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])]), p.mean(0))
-    w = BopSceneWriter(args.out, workers=args.writers)
+    writers = args.writers
+    if writers is None and world > 1:        # N ranks share the host's cores: their encoder pools must not add up to N x 32
+        writers = max(1, min(32, (os.cpu_count() or 1) // world))
+    w = BopSceneWriter(args.out, workers=writers)
     t0 = time.perf_counter()
     t_gpu = 0.0
     mine = list(range(rank, args.frames, world))          # frame f -> rank f mod world
@@ -79,7 +83,7 @@ def main():
         specs = [fr.view_spec(v) for v in vs]
         frames = fr.render_frames(specs, poses=poses)
         sil = fr.render_silhouettes(specs, poses=poses) if fr.K else None          # 'seg_sil': one layered pass for all objects
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(device)
         t_gpu += time.perf_counter() - t1
         gt, cam = bop_pose.batch_pose_records(vs, m2w, boxes=boxes)
         w.add_batch(frames, gt, cam, n=len(vs), silhouettes=sil, frame_ids=ids)

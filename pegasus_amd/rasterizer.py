@@ -71,6 +71,41 @@ def _grown_capacity(need: int, factor: float) -> int:
     return min(MAX_INSTANCES, int(need * factor) + 1024)
 
 
+def reset_capacity(hint: Optional[int] = None, *, free_workspaces: bool = True) -> None:
+    """Public reset hook of the module's instance-capacity bookkeeping.
+
+    ``hint=None`` forgets every learned capacity (the next call of each scene shape starts from its default);
+    ``hint=k`` sets every capacity learned so far to ``k`` list entries per view (tests force overflows that way).
+    ``free_workspaces`` also drops the cached asynchronous workspaces, so the next batch really is allocated at the new
+    capacity.  The library itself keeps no state: this is host-side bookkeeping of the torch-owned scratch."""
+    if hint is None:
+        _WS.capacity_hint.clear()
+    else:
+        for key in list(_WS.capacity_hint):
+            _WS.capacity_hint[key] = int(hint)
+    if free_workspaces:
+        drop_async_workspaces()
+
+
+def drop_async_workspaces() -> None:
+    """Releases the cached workspaces of the asynchronous slots (the next batch of each slot allocates afresh)."""
+    for key in [k for k in _WS.buf if isinstance(k, tuple) and len(k) == 2 and isinstance(k[1], tuple)]:
+        _WS.buf.pop(key)
+
+
+def capacity_hints() -> dict:
+    """Learned per-view instance capacities, keyed by (device, n, width, height[, "layers", n_layers])."""
+    return dict(_WS.capacity_hint)
+
+
+def set_capacity_hint(key, hint: Optional[int]) -> None:
+    """Sets (or with ``None`` forgets) the learned capacity of one scene shape (key as in capacity_hints())."""
+    if hint is None:
+        _WS.capacity_hint.pop(key, None)
+    else:
+        _WS.capacity_hint[key] = int(hint)
+
+
 def last_forward_info() -> dict:
     """Bookkeeping of the most recent forward: num_instances per view, capacities, workspace tensor."""
     return dict(_LAST_INFO)
@@ -113,6 +148,7 @@ class PendingBatch:
             self._event = None
             if status == _lib.PGR_ERR_INSTANCE_OVERFLOW:
                 self._was_redone = True
+                _WS.capacity_hint[self._key] = max(_WS.capacity_hint.get(self._key, 0), _grown_capacity(peak, 1.6))   # raises beyond MAX_INSTANCES
                 self.results = self._redo()          # synchronous path grows the workspace and retries
             else:
                 _lib.check(status, "pgr_forward_batch_async")
@@ -283,8 +319,19 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
                   tie_index=tie_index, tie_inv=tie_inv)
         if layers is not None:          # a layered call is asynchronous only: the retry after an overflow is one too
             def redo():
-                pb2 = forward_views(means3D_in, opacities_in, views, async_slot=async_slot, layers=layers, **kw)
-                return pb2.wait()
+                # bounded like the fused path: every attempt runs at the capacity the device asked for (a view that needs
+                # more than MAX_INSTANCES raises from _grown_capacity instead of overflowing for ever)
+                for _attempt in range(3):
+                    pb2 = forward_views(means3D_in, opacities_in, views, async_slot=async_slot, layers=layers, **kw)
+                    pb2._redo = None
+                    pb2._event.synchronize()
+                    need2 = (C.c_int64 * nv)()
+                    status2 = L.pgr_batch_status(C.c_void_p(pb2._scratch.data_ptr()), nv, need2)
+                    if status2 != _lib.PGR_ERR_INSTANCE_OVERFLOW:
+                        _lib.check(status2, "pgr_forward_layers_async")
+                        return pb2.results
+                    _WS.capacity_hint[key] = _grown_capacity(max(need2), 1.6)
+                raise RuntimeError("instance capacity did not converge")
         else:
             redo = lambda: forward_views(means3D_in, opacities_in, views, **kw)
         pb = PendingBatch(results, ev, scratch, nv, key, max_inst, redo)

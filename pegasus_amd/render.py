@@ -99,6 +99,21 @@ _ALL = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rota
 _kept_scene = {}       # the objects-only scene of the last call and, per camera, its render
 
 
+def reset_cache():
+    """Forgets the kept objects-only scene and its last render (the next semantic wrapper call rebuilds both)."""
+    _kept_scene.clear()
+
+
+def swap_cache(state=None):
+    """Replaces the kept objects-only scene by ``state`` (None: empty) and returns what was kept before -- lets a caller
+    run a cold render beside a warm slot and put the slot back."""
+    before = dict(_kept_scene)
+    _kept_scene.clear()
+    if state:
+        _kept_scene.update(state)
+    return before
+
+
 def _fingerprint(tensors):
     """Identity of a set of tensors as far as torch can tell without reading them: object, version counter, storage,
     shape.  None (= never equal) for tensors without a version counter (torch.inference_mode)."""

@@ -174,9 +174,20 @@ def scene_c2(seed: int = 2, n: int = 150_000, n_views: int = 64, width=800, heig
     return cloud, object_views(n_views, 0.45, width, height, 1000.0 * width / 800.0, min_views_on_sphere=128)
 
 
+CAMERA_SETS = {
+    # "512 (C3) / 4096 (C4) views from the fibonacci sampler" -- the first n_views of the BOP
+    # toolkit's Fibonacci upper hemisphere (elevation 0 .. 90 degrees, grazing views included)
+    "fibonacci": None,
+    # rounds 1-4 rendered this subset: directions below ~8.6 degrees of elevation (eye_dir.z <= 0.15, 15 % of the set)
+    # skipped and back-filled by repeating directions at other radii.  Kept for A/B against the earlier rounds' numbers.
+    "fibonacci_above_9deg": 0.15,
+}
+
+
 def merged_scene(seed: int, n_env: int, n_objects: int, n_per_object: int, n_views: int,
-                 width=800, height=800, plane_size=2.0):
+                 width=800, height=800, plane_size=2.0, camera_set: str = "fibonacci"):
     """C3/C4/C5 construction: ground-plane environment + objects resting on it."""
+    min_z = CAMERA_SETS[camera_set]
     from scipy.spatial.transform import Rotation as Rot
     rng = np.random.default_rng(seed)
     parts = [ground_plane(rng, n_env, plane_size, math.log(0.004), 0.5, 0.1, 0.01)]
@@ -205,7 +216,7 @@ def merged_scene(seed: int, n_env: int, n_objects: int, n_per_object: int, n_vie
     while len(views) < n_views:
         R, t = base[k % len(base)]
         eye_dir = -R.T @ t
-        if eye_dir[2] > 0.15:  # skip grazing views below ~9 degrees elevation
+        if min_z is None or eye_dir[2] > min_z:
             radius = 0.8 + 0.4 * ((len(views) * 0.6180339887498949) % 1.0)
             eye = eye_dir * radius + target
             views.append(make_view(R, -R @ eye, width, height, fx=1000.0 * width / 800.0,
@@ -216,13 +227,15 @@ def merged_scene(seed: int, n_env: int, n_objects: int, n_per_object: int, n_vie
     return cloud, views, poses
 
 
-def scene_c3(seed: int = 3, n_views: int = 512, scale: float = 1.0, width=800, height=800):
+def scene_c3(seed: int = 3, n_views: int = 512, scale: float = 1.0, width=800, height=800, camera_set="fibonacci"):
     """C3/C4: 1.36 M environment + 8 x 80 k objects = 2.0 M Gaussians (scale < 1 shrinks all counts)."""
-    cloud, views, _ = merged_scene(seed, int(1_360_000 * scale), 8, int(80_000 * scale), n_views, width, height)
+    cloud, views, _ = merged_scene(seed, int(1_360_000 * scale), 8, int(80_000 * scale), n_views, width, height,
+                                   camera_set=camera_set)
     return cloud, views
 
 
-def scene_c5(seed: int = 5, n_views: int = 200, scale: float = 1.0, width=800, height=800):
+def scene_c5(seed: int = 5, n_views: int = 200, scale: float = 1.0, width=800, height=800, camera_set="fibonacci"):
     """C5: 3.4 M environment + 20 x 80 k objects = 5.0 M Gaussians."""
-    cloud, views, _ = merged_scene(seed, int(3_400_000 * scale), 20, int(80_000 * scale), n_views, width, height)
+    cloud, views, _ = merged_scene(seed, int(3_400_000 * scale), 20, int(80_000 * scale), n_views, width, height,
+                                   camera_set=camera_set)
     return cloud, views

@@ -55,7 +55,7 @@ class FrameGather:
         kw = dict(dtype=torch.uint8, device=device)
         if pin_memory and torch.device(device).type == "cpu":
             kw["pin_memory"] = True
-        self.send = [torch.empty((self.cap, self.record_bytes), **kw) for _ in range(self.depth)]
+        self.send = [torch.zeros((self.cap, self.record_bytes), **kw) for _ in range(self.depth)]      # (zeroed once: the 16-byte padding between a record's sections is never written)
         self.recv = ([torch.empty((self.world, self.cap, self.record_bytes), **kw) for _ in range(self.depth)]
                      if self.rank == dst else None)
         # the per-rank receive views handed to the collective: made once (unbind returns views of recv)

@@ -24,5 +24,5 @@ def run(first, n, log=None):
 run(0, 4); torch.cuda.synchronize()
 log = []
 t0 = time.perf_counter(); run(4, 12, log); torch.cuda.synchronize(); t1 = time.perf_counter()
-print(wl, "ms per step", (t1 - t0) / 12 * 1e3, "hint", dict(R._WS.capacity_hint))
+print(wl, "ms per step", (t1 - t0) / 12 * 1e3, "hint", R.capacity_hints())
 print("(enqueue ms, wait ms) per step:", log)

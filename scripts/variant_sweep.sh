@@ -2,7 +2,7 @@
 # Compositor tuning sweep: builds libpegasus_raster.so variants (here, no GPU needed) or runs bench.py over them (GPU box).
 #   scripts/variant_sweep.sh build "U:W U:W ..." [extra -D flags]   -> build_variants/lib_u<U>_w<W>.so
 #     W = PGR_COMP_WAVES (compositor occupancy cap, 0 = compiler's choice); U is a label only (the unroll knob of the
-#     half-tile compositor it once selected is gone) -- pass other knobs as extra -D flags (-DPGR_COMP_STATS, ...)
+#     half-tile compositor it once selected is gone) -- pass other knobs as extra -D flags
 #   scripts/variant_sweep.sh run  [bench args]                      -> one result line per variant
 set -e
 cd "$(dirname "$0")/.."

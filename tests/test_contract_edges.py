@@ -40,7 +40,7 @@ def test_instance_total_just_beyond_32_bits_reports_overflow(gpu_device):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
     spec = R.ViewSpec(H, W, v.tanfovx, v.tanfovy, t(np.zeros(3)), t(v.world_view_transform), t(v.full_proj_transform),
                       t(v.camera_center))
-    R._WS.capacity_hint.pop((dev, n, W, H), None)
+    R.set_capacity_hint((dev, n, W, H), None)
     with pytest.raises(RuntimeError, match="per-view limit"):
         R.forward_views(means, op, [spec], colors_precomp=col, scales=scales, rotations=rot, want_radii=False)
     torch.cuda.synchronize()
@@ -107,10 +107,7 @@ def test_batch_in_which_only_some_views_overflow(gpu_device):
     need.sort()
     assert need[0] < need[-1], need
     between = (need[0] + need[-1]) // 2                    # room for the lightest view, not for the heaviest
-    for key in list(rasterizer._WS.capacity_hint):
-        rasterizer._WS.capacity_hint[key] = between
-    for kk in [k for k in rasterizer._WS.buf if isinstance(k, tuple) and len(k) == 2 and isinstance(k[1], tuple)]:
-        rasterizer._WS.buf.pop(kk)
+    rasterizer.reset_capacity(between)
     out = fr.alloc_frames(len(specs), 240, 320)
     fr.render_frames_async(specs, out, slot=0).wait()
     torch.cuda.synchronize()

@@ -279,7 +279,7 @@ def test_semantic_wrappers_follow_objects_cameras_and_backgrounds(gpu_device):
 
         def both(cam, background, cold):
             if cold:
-                prender._kept_scene.clear()
+                prender.reset_cache()
             vis, seg = prender.render_visib_mask(cam, env, objs, colors, H, W, pipe, background)
             sem = prender.render_semanticsegmentation_mask(cam, env, objs, colors, H, W, pipe, background, False)
             return vis.copy(), seg.clone(), sem.copy()
@@ -323,10 +323,9 @@ def test_semantic_wrappers_follow_objects_cameras_and_backgrounds(gpu_device):
             for _ in range(2):
                 objs[1].apply_translation_on_xyz(torch.tensor([0.004, 0.0, 0.001], device=dev))
             warm = both(cams[0], bg, cold=False)
-            saved = dict(prender._kept_scene)
-            cold = both(cams[0], bg, cold=True)
-            prender._kept_scene.clear()
-            prender._kept_scene.update(saved)
+            saved = prender.swap_cache(None)
+            cold = both(cams[0], bg, cold=False)           # (the slot is empty: a cold render)
+            prender.swap_cache(saved)
             assert same(warm, cold), step
 
 

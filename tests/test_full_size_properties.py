@@ -9,15 +9,23 @@ from pegasus_amd import scenes
 
 pytestmark = pytest.mark.gpu
 
+SPREAD_VIEWS = (128, 300, 60, 500)      # elevations 14.5, 35.9, 6.7 and 77.5 degrees
+GRAZING_VIEWS = (0, 1, 2, 3)            # elevations 0, 0.11, 0.22, 0.33 degrees (below the ~8.6 degrees rounds 1-4 started at)
+
 
 @pytest.fixture(scope="module")
 def c3_full(gpu_device):
     import torch
     from pegasus_amd.frames import FrameRenderer
-    cloud, views = scenes.scene_c3(n_views=4)
+    # configs[2]'s own camera set (the 512 Fibonacci views, elevation ascending): four spread over the hemisphere for the
+    # property tests, and the four lowest (0 .. 0.34 degrees: the camera 5 cm above the ground plane, the longest
+    # ground-plane lists) for the grazing-view tests
+    cloud, all_views = scenes.scene_c3(n_views=512)
+    views = [all_views[i] for i in SPREAD_VIEWS]
     act = cloud.activated()
     fr = FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"], cloud.object_id,
                        device=gpu_device)
+    fr.grazing_views = [all_views[i] for i in GRAZING_VIEWS]
     return cloud, views, act, fr
 
 
@@ -70,6 +78,68 @@ def test_full_size_view_matches_oracle(c3_full, oracle, gpu_device):
     g = dict(color=res[0]["color"].cpu().numpy(), out_depth=res[0]["depth"].cpu().numpy(),
              final_T=res[0]["final_T"].cpu().numpy(), n_contrib=res[0]["n_contrib"].cpu().numpy())
     assert_images_match(g, o)
+
+
+def test_grazing_views_match_oracle(c3_full, oracle, gpu_device):
+    """The four lowest cameras of configs[2]'s Fibonacci set (elevation < 0.4 degrees; rounds 1-4 skipped everything below
+    ~8.6 degrees) at FULL size, as one batch: radii and per-tile lists bit-exact against the oracle, images within 1e-4,
+    n_contrib exact -- and, for the lowest one, the same against the oracle's REFERENCE-STYLE lists."""
+    import math
+    import torch
+    from helpers import assert_images_match, fetch_workspace
+    from test_gpu_parity import _last_blended
+    from pegasus_amd import rasterizer as R
+    cloud, _, act, fr = c3_full
+    views = fr.grazing_views
+    for v in views:
+        eye = -v.R_c2w @ v.t_w2c
+        assert math.degrees(math.asin((eye[2] - 0.05) / np.linalg.norm(eye - np.array([0, 0, 0.05])))) < 0.4
+    act_r = {k: np.ascontiguousarray(a[fr.order]) for k, a in act.items()}
+    res = R.forward_views(fr.means3d, fr.opacities, [fr.view_spec(v) for v in views], shs=fr.shs, scales=fr.scales,
+                          rotations=fr.rotations, sh_degree=3, want_radii=True, want_aux=True, tie_index=fr.tie_index)
+    torch.cuda.synchronize()
+    for i, v in enumerate(views):
+        w = fetch_workspace(i, cloud.n, v.width, v.height)
+        o = oracle.forward(**act_r, sh_degree=3, **v.raster_kwargs(), num_threads=8, cull_mode=1, tie_index=fr.order)
+        lens = o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]
+        assert lens.max() > 16384 and o["num_instances"] > 3_000_000          # the ground plane seen edge-on
+        np.testing.assert_array_equal(res[i]["radii"].cpu().numpy(), o["radii"])
+        np.testing.assert_array_equal(w["gauss_sorted"], o["gauss_sorted"])
+        np.testing.assert_array_equal(w["ranges"], o["ranges"])
+        g = dict(color=res[i]["color"].cpu().numpy(), out_depth=res[i]["depth"].cpu().numpy(),
+                 final_T=res[i]["final_T"].cpu().numpy(), n_contrib=res[i]["n_contrib"].cpu().numpy())
+        assert_images_match(g, o)
+        if i == 0:
+            o0 = oracle.forward(**act_r, sh_degree=3, **v.raster_kwargs(), num_threads=8, cull_mode=0, tie_index=fr.order)
+            assert o0["num_instances"] > 1.3 * o["num_instances"]
+            np.testing.assert_array_equal(res[i]["radii"].cpu().numpy(), o0["radii"])
+            amb = o0["ambig"].astype(bool)
+            assert amb.mean() <= 5e-4
+            assert np.abs(g["color"] - o0["color"])[:, ~amb].max() <= 1e-4
+            assert np.abs(g["out_depth"] - o0["out_depth"])[:, ~amb].max() <= 1e-4
+            lg = _last_blended(w["gauss_sorted"], w["ranges"], g["n_contrib"], v.width, v.height)
+            lo = _last_blended(o0["gauss_sorted"], o0["ranges"], o0["n_contrib"], v.width, v.height)
+            np.testing.assert_array_equal(lg[~amb], lo[~amb])
+
+
+def test_grazing_views_fused_frames_equal_separate_passes(c3_full, gpu_device):
+    """The frames path (fused semantic image + masks + records) on the grazing cameras == the separate passes, bit for bit,
+    and the masks see the objects standing on the plane."""
+    import torch
+    from pegasus_amd import masks as M
+    cloud, _, act, fr = c3_full
+    specs = [fr.view_spec(v) for v in fr.grazing_views]
+    H, W = fr.grazing_views[0].height, fr.grazing_views[0].width
+    fa = fr.alloc_frames(len(specs), H, W, records=True)
+    fr.render_frames_async(specs, fa, slot=0).wait()
+    sep = fr.render_batch(specs)
+    for k in ("color", "depth", "seg", "masks"):
+        assert torch.equal(fa[k], sep[k]), k
+    assert fa["masks"].sum().item() > 10_000
+    ref = M.pack_records(fa["color"], fa["depth"], fa["masks"])
+    got, want = M.record_views(fa["records"], H, W, fr.K), M.record_views(ref, H, W, fr.K)
+    for k in ("rgb", "depth_mm", "mask_bits"):
+        assert torch.equal(got[k], want[k]), k
 
 
 def test_full_size_view_against_reference_style_lists(c3_full, oracle, gpu_device):

@@ -295,10 +295,7 @@ def test_async_frame_pipeline_matches_sync(gpu_device):
         assert torch.equal(fa[k], ref[k][:3]), k
         assert torch.equal(fb[k], ref[k][3:]), k
     # force an overflow on the async path: shrink the capacity hint, the handle must transparently re-render
-    for key in list(rasterizer._WS.capacity_hint):
-        rasterizer._WS.capacity_hint[key] = 1000
-    for kk in [k for k in rasterizer._WS.buf if isinstance(k, tuple) and len(k) == 2 and isinstance(k[1], tuple)]:
-        rasterizer._WS.buf.pop(kk)
+    rasterizer.reset_capacity(1000)
     fc = fr.alloc_frames(3, 240, 320)
     fr.render_batch_async(specs[:3], fc, slot=0).wait()
     torch.cuda.synchronize()
@@ -323,10 +320,7 @@ def test_fused_semantic_pass_is_bit_identical(gpu_device):
     for k in ("color", "depth", "seg", "seg_depth", "masks"):
         assert torch.equal(f[k], ref[k]), k
     assert int(f["masks"].sum()) > 0
-    for key in list(rasterizer._WS.capacity_hint):
-        rasterizer._WS.capacity_hint[key] = 2000
-    for kk in [k for k in rasterizer._WS.buf if isinstance(k, tuple) and len(k) == 2 and isinstance(k[1], tuple)]:
-        rasterizer._WS.buf.pop(kk)
+    rasterizer.reset_capacity(2000)
     f2 = fr.alloc_frames(5, 240, 320)
     fr.render_frames_async(specs, f2, slot=1).wait()
     torch.cuda.synchronize()
@@ -363,11 +357,10 @@ def test_count_walk_verdicts_every_mode(oracle, gpu_device, monkeypatch):
     need = int(o2["num_instances"])
     assert 1000 < need < n // 3, need
     dev = torch.device(gpu_device)
-    for key in list(rasterizer._WS.capacity_hint):
+    for key in rasterizer.capacity_hints():
         if key[1] == n:
-            rasterizer._WS.capacity_hint[key] = need + 64
-    for kk in [k for k in rasterizer._WS.buf if isinstance(k, tuple) and len(k) == 2 and isinstance(k[1], tuple)]:
-        rasterizer._WS.buf.pop(kk)
+            rasterizer.set_capacity_hint(key, need + 64)
+    rasterizer.drop_async_workspaces()
     g3, _ = _run_both(oracle, cloud2, views[0], gpu_device)
     assert rasterizer.last_forward_info()["used_max_instances"] == need + 64
     assert (need + 64) * 12 // 768 < (n + 63) // 64        # fewer regions than groups
@@ -678,10 +671,7 @@ def test_layered_silhouettes_after_an_instance_overflow(gpu_device):
                          sh_degree=3, device=gpu_device)
     specs = [fr.view_spec(v) for v in views]
     ref = fr.render_silhouettes(specs).clone()
-    for key in list(rasterizer._WS.capacity_hint):
-        rasterizer._WS.capacity_hint[key] = 1500
-    for kk in [k for k in rasterizer._WS.buf if isinstance(k, tuple) and len(k) == 2 and isinstance(k[1], tuple)]:
-        rasterizer._WS.buf.pop(kk)
+    rasterizer.reset_capacity(1500)
     again = fr.render_silhouettes(specs).clone()
     torch.cuda.synchronize()
     assert torch.equal(ref, again)
@@ -872,10 +862,7 @@ def test_frame_records_from_the_compositor_equal_pack_records(gpu_device, size):
             assert torch.equal(got[k], ref[k]), (masks, mode, k)
         g = fr.render_frames(specs, fr.alloc_frames(4, h, w, masks=masks, records=True), masks=masks)      # the blocking form too
         assert all(torch.equal(M.record_views(g["records"], h, w, fr.K if masks else 0)[k], ref[k]) for k in ref)
-    for key in list(rasterizer._WS.capacity_hint):
-        rasterizer._WS.capacity_hint[key] = 1500
-    for kk in [k for k in rasterizer._WS.buf if isinstance(k, tuple) and len(k) == 2 and isinstance(k[1], tuple)]:
-        rasterizer._WS.buf.pop(kk)
+    rasterizer.reset_capacity(1500)
     specs = [fr.view_spec(v) for v in views]
     f = fr.alloc_frames(4, h, w, records=True)
     fr.render_frames_async(specs, f, slot=1).wait()
