@@ -236,7 +236,11 @@ int32_t pgr_scene_prepare(const PgrScene *scene, const PgrSemantic *semantic, vo
  * rows; projection, lists and blending of a layer are those of rendering its Gaussians alone), and the compositor's
  * epilogue writes outs[v].sem_masks[k-1] = || pixel - mask_colors[k-1] ||_2 <= mask_threshold.  No colour image is
  * written (outs[v].color / depth may be NULL).  layer_id must be non-decreasing along the scene (PEGASUS merges object
- * after object); Gaussians with layer_id 0 are dropped.  `posed` as in pgr_forward_posed_async (may be NULL). */
+ * after object); Gaussians with layer_id 0 are dropped.  `posed` as in pgr_forward_posed_async (may be NULL).
+ * EMPTY LAYERS: the plane of a layer no Gaussian carries is all 0, whatever the background -- the reference never renders
+ * an object that is not in gs_object_list and leaves its mask column 0 (/root/reference/src/gs/render.py:44-63); an
+ * empty scene (n == 0) is the same rule for every layer.  A layer WITH Gaussians of which none reaches a pixel holds the
+ * background's verdict || bg - mask_colors[k-1] ||_2 <= mask_threshold there, as a render of that object alone would. */
 typedef struct PgrLayers {
     const int32_t *layer_id;     /* device [n] */
     int32_t n_layers;

@@ -524,14 +524,25 @@ inline void launch_composite(uint32_t slots, hipStream_t stream, const ViewEntry
 // Layered call: the mask of a pixel no list entry touches is the background's verdict -- || bg - c_k ||_2 <= thr, the value
 // pixel_masks() computes for an untouched pixel (fmaf(1, bg, 0) = bg), bit for bit.  Planes are pre-filled with it, and
 // only the non-empty (layer, tile) lists get compositor waves (9 of 10 lists of a silhouette pass are empty).
+// A layer WITHOUT ANY Gaussian (an object id no Gaussian carries) keeps a zero plane, whatever the background: the
+// reference never renders such an object and leaves its column of the mask array 0
+// (/root/reference/src/gs/render.py:44-63) -- the same rule as an empty scene (N == 0: every plane 0).  layer_id is
+// non-decreasing, so presence is one binary search per workgroup.
 // grid = (ceil(P / 1024), n_layers, n_views), 256 threads x 4 pixels
-__global__ void layer_mask_fill_kernel(const ViewEntry* __restrict__ views, const float* __restrict__ colors, float thr, size_t P) {
+__global__ void layer_mask_fill_kernel(const ViewEntry* __restrict__ views, const float* __restrict__ colors, float thr, size_t P,
+                                       const int32_t* __restrict__ layer_id, int n) {
     const ViewEntry& ve = views[blockIdx.z];
     if (!ve.sem_masks) return;
     const CameraDev& cam = *ve.cam;
     const int c = blockIdx.y;
+    int lo = 0, hi = n;                       // first Gaussian with layer_id >= c + 1 (wave-uniform: scalar loads)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (layer_id[mid] < c + 1) lo = mid + 1; else hi = mid;
+    }
+    const bool present = lo < n && layer_id[lo] == c + 1;
     const float d0 = cam.bg[0] - colors[3 * c], d1 = cam.bg[1] - colors[3 * c + 1], d2 = cam.bg[2] - colors[3 * c + 2];
-    const uint8_t m = sqrtf(d0 * d0 + d1 * d1 + d2 * d2) <= thr ? 1 : 0;
+    const uint8_t m = present && sqrtf(d0 * d0 + d1 * d1 + d2 * d2) <= thr ? 1 : 0;
     uint8_t* plane = ve.sem_masks + (size_t)c * P;
     const size_t p0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (p0 >= P) return;

@@ -413,7 +413,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         sd.mask_colors = layers->mask_colors; sd.mask_thr = layers->mask_threshold; sd.k = n_layers;
         // empty (layer, tile) lists have no work item: their pixels hold the background's verdict
         layer_mask_fill_kernel<<<dim3((unsigned)((P + 1023) / 1024), n_layers, n_views), 256, 0, stream>>>(
-            view_table, layers->mask_colors, layers->mask_threshold, P);
+            view_table, layers->mask_colors, layers->mask_threshold, P, layers->layer_id, N);
         launch_composite<false, false, true>(slots, stream, view_table, items_per_view, work_order, sd);
     } else if (want_aux && want_sem)
         launch_composite<true, true>(slots, stream, view_table, items_per_view, work_order, sd);

@@ -162,3 +162,49 @@ def _async_worker(rank, world, port, q):
 def test_async_gather_of_quantised_batches():
     """The generic dict form: uint8 / int16 frames as ONE record per frame in ONE gather, asynchronous."""
     _spawn(_async_worker, 2)
+
+
+def _full_size_worker(rank, world, port, q):
+    """FrameGather at the REAL sizes of an 8-rank run: 32 records of 3.84 MB per rank and batch (800x800, K <= 8:
+    masks.record_layout's layout restated below), rank 0's receive buffer world x B x record = 0.98 GB.  Exercises the
+    buffer arithmetic (offsets beyond 2^31 bytes, the transposed global view) that the 48-byte records above cannot."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pegasus_amd import view_shard as vs
+        P = 800 * 800
+        a16 = lambda v: (v + 15) // 16 * 16
+        rec = a16(3 * P) + a16(2 * P) + a16(1 * P)             # rgb u8 | depth u16 | one mask byte per pixel
+        assert rec == 3_840_000
+        cap = 32
+        fg = vs.FrameGather(cap, rec, "cpu", dst=0, depth=1)
+        assert fg.bytes_per_rank_and_batch == cap * rec == 122_880_000
+        buf = fg.send_buffer(0)
+        # a record is a function of its global id: a ramp whose phase is the id, and the id itself at both ends
+        ramp = torch.arange(rec, dtype=torch.int32)
+        for i in range(cap):
+            g = vs.global_id(rank, i, world)
+            buf[i] = ((ramp + g * 97) % 251).to(torch.uint8)
+            buf[i, 0], buf[i, -1] = g % 256, g // 256
+        fg.start(0)
+        got = fg.finish(0)
+        ok = True
+        if rank == 0:
+            assert got.numel() == world * cap * rec == 983_040_000 and got.numel() * 1 > 2**29
+            glob = fg.global_view(0)                             # [cap, world, rec]: [i, r] = frame i * world + r
+            assert tuple(glob.shape) == (cap, world, rec)
+            ids = glob[:, :, 0].to(torch.int64) + 256 * glob[:, :, -1].to(torch.int64)
+            ok = ok and torch.equal(ids.reshape(-1), torch.arange(cap * world))
+            for g in (0, 1, world, cap * world - 1, cap * world // 2 + 3):       # whole records, first / last / middle
+                want = ((ramp + g * 97) % 251).to(torch.uint8)
+                want[0], want[-1] = g % 256, g // 256
+                ok = ok and torch.equal(glob[g // world, g % world], want)
+        q.put(("ok" if ok else "mismatch", rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_gather_world8_at_the_real_record_size():
+    """world 8 x 32 frames x 3.84 MB = 0.98 GB into rank 0 (round-4 verdict item 8)."""
+    _spawn(_full_size_worker, 8)
