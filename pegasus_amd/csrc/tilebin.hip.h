@@ -395,6 +395,19 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const BinView* __restri
         bv.counters[1] = carry_s > (unsigned long long)max_instances ? 1u : 0u;
     }
     if (!order_state) return;
+    if (gridDim.x == 1) {
+        // one view, one workgroup: the counts are this workgroup's own LDS words -- no agent-scope atomics, ticket or fences
+        // (two __threadfence() are ~7 us of the ~14 us this kernel takes in a single-view call, where every launch is latency)
+        __syncthreads();
+        if (threadIdx.x < NUM_XCD) {
+            uint32_t acc = 0;
+            for (int c = 0; c < ORDER_CLASSES_USED; ++c) {
+                gstore(order_state + threadIdx.x * ORDER_CLASSES_USED + c, acc);
+                acc += hist[threadIdx.x * ORDER_CLASSES_USED + c];
+            }
+        }
+        return;
+    }
     if (threadIdx.x < ORDER_BINS && hist[threadIdx.x]) gatomic_add(order_state + threadIdx.x, hist[threadIdx.x]);
     __threadfence();
     __syncthreads();
@@ -552,6 +565,9 @@ __device__ __forceinline__ void merge_sort_tile(uint64_t* __restrict__ skeys, co
 // rejected and take the merge sort; the result never depends on which path ran.
 
 constexpr uint32_t BUCKET_SQ_LIMIT = 8;
+#ifndef PGR_SORT_POS
+#define PGR_SORT_POS 1          // 1: position-owned ranking (bucket_sort_tile_pos); 0: rounds 1-4 (bucket_sort_tile) -- A/B builds
+#endif
 
 
 // Sorts n <= THREADS*E keys of `bucket` into out[] (indices) -- same contract as merge_sort_tile without keys_out.
@@ -730,6 +746,185 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
     return true;
 }
 
+// ---- bucket sort, position-owned ranking (round 5) -----------------------------------------------------------------
+// Same map, same buckets, same result as bucket_sort_tile above; what changes is WHO ranks a key and how often the
+// workgroup meets at a barrier.
+//   * Once the keys are parked (bucket start + arrival slot) the image is sorted by bucket; the exact place of a key is
+//     decided by the thread that owns its PARKED POSITION, not by the thread that loaded it: position i is read back
+//     coalesced, its bucket recomputed from its depth bits (4 VALU), the bucket's extent read from the counter word (lanes
+//     of a wave read consecutive or equal words), the members of a multi-key bucket are the position's own neighbours.
+//     The random LDS reads of the ranking and the random store + read-back of an index image (rounds 1-4: 23 % of the
+//     sort's LDS-array cycles at a 2.1 - 2.9-fold conflict factor, scripts/sim/sort_bank_conflicts.py) are gone; the
+//     sorted indices go straight to global memory from position order (a wave's 64 stores fall into the 64..130-entry
+//     window its positions map to: whole lines).
+//   * Wave-level partial results (min, max, totals, squares) go to per-wave words instead of atomics on shared words,
+//     which need no zero-fill barrier in front: five workgroup barriers per list instead of eight.
+// lds: KEYS*8 + NB*4 + 256 bytes.
+constexpr int SORT_MISC_BYTES = 256;
+
+template <int THREADS, int E, int NB = THREADS * E, int KEYS = THREADS * E>
+__device__ __forceinline__ bool bucket_sort_tile_pos(unsigned char* __restrict__ lds, const uint2* __restrict__ bucket,
+                                                     uint32_t* __restrict__ out, int n, int n_env,
+                                                     uint32_t* __restrict__ obj_last, uint32_t pos_offset = 0,
+                                                     const int32_t* __restrict__ tie = nullptr) {
+    constexpr int CAP = THREADS * E, WAVES = THREADS / WAVE, CH = NB / (WAVES * WAVE);   // 64-bucket chunks per wave
+    static_assert(NB % (WAVES * WAVE) == 0, "bucket count");
+    static_assert(4 * WAVES * 4 <= SORT_MISC_BYTES, "per-wave words must fit the bytes the callers reserve behind the counters");
+    static_assert(KEYS <= CAP, "key image");
+    uint64_t* s_keys = reinterpret_cast<uint64_t*>(lds);                       // [KEYS] (n <= KEYS <= CAP)
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(lds + (size_t)KEYS * 8);    // [NB] counts -> start | members << 16
+    uint32_t* s_wmin = s_hist + NB;                                            // [WAVES] per-wave minimum of the depth bits
+    uint32_t* s_wmax = s_wmin + WAVES;                                         // [WAVES] maximum
+    uint32_t* s_wtot = s_wmax + WAVES;                                         // [WAVES] keys in the wave's buckets
+    uint32_t* s_wsq = s_wtot + WAVES;                                          // [WAVES] sum of squared bucket counts
+    const int t = threadIdx.x, lane = t & (WAVE - 1), wave = t / WAVE;
+
+    // all E loads in flight at once, index clamped into the list (n >= 1)
+    uint32_t d[E], id[E];
+    uint32_t dmin = 0xffffffffu, dmax = 0u;
+    {
+        uint2 v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = gload(bucket + min(e * THREADS + t, n - 1));
+        for (int i = t; i < NB; i += THREADS) s_hist[i] = 0u;              // (beside the loads)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool in = e * THREADS + t < n;
+            d[e] = in ? v[e].x : 0xffffffffu; id[e] = in ? v[e].y : 0xffffffffu;
+            dmin = min(dmin, d[e]); dmax = max(dmax, in ? v[e].x : 0u);
+        }
+    }
+    dmin = ~wave_inclusive_max(~dmin);          // min as max of the complement (0 is the prefix-max identity)
+    dmax = wave_inclusive_max(dmax);
+    if (lane == WAVE - 1) { s_wmin[wave] = dmin; s_wmax[wave] = dmax; }
+    __syncthreads();                            // 1: counters zero, per-wave extremes visible
+    uint32_t mn = 0xffffffffu, mx = 0u;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { mn = min(mn, s_wmin[w]); mx = max(mx, s_wmax[w]); }
+    const float scale = (float)NB / ((float)(mx - mn) + 1.0f);
+    // monotone in d: uint->float conversion, multiplication by a positive constant, truncation and clamp all are
+    auto bucket_of = [&](uint32_t depth) { return min((uint32_t)((float)(depth - mn) * scale), (uint32_t)(NB - 1)); };
+    uint32_t br[E];      // bucket << 16 | arrival slot inside the bucket
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        br[e] = 0u;
+        if (e * THREADS + t < n) {
+            const uint32_t b = bucket_of(d[e]);
+            br[e] = (b << 16) | atomicAdd(&s_hist[b], 1u);
+        }
+    }
+    __syncthreads();                            // 2: histogram complete
+    // pass A: every wave owns NB / WAVES consecutive buckets (CH chunks of 64): totals and sum of squares
+    const int wbase = wave * (WAVE * CH);
+    constexpr bool KEEP_H = E <= 8;             // the counts stay in registers between the passes (16 keys per thread: no room)
+    uint32_t h[KEEP_H ? CH : 1];
+    uint32_t tot = 0, sq = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const uint32_t hc = s_hist[wbase + c * WAVE + lane];
+        if (KEEP_H) h[c] = hc;
+        tot += hc; sq += hc * hc;
+    }
+    tot = wave_inclusive_scan(tot);
+    sq = wave_inclusive_scan(sq);
+    if (lane == WAVE - 1) { s_wtot[wave] = tot; s_wsq[wave] = sq; }
+    __syncthreads();                            // 3: per-wave totals visible
+    uint32_t carry = 0, sqsum = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        const uint32_t tw = s_wtot[w];
+        carry += w < wave ? tw : 0u;
+        sqsum += s_wsq[w];
+    }
+    // average occupancy is n / NB by construction: reject when the squares exceed what an even spread would cost
+    if (sqsum > BUCKET_SQ_LIMIT * (uint32_t)n * (uint32_t)((CAP + NB - 1) / NB)) { __syncthreads(); return false; }
+    // pass B: exclusive scan of the counts -> bucket start | members << 16
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const uint32_t hc = KEEP_H ? h[c] : s_hist[wbase + c * WAVE + lane];
+        const uint32_t incl = wave_inclusive_scan(hc);
+        s_hist[wbase + c * WAVE + lane] = (carry + incl - hc) | (hc << 16);
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+    }
+    __syncthreads();                            // 4: bucket starts
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (e * THREADS + t < n)
+            s_keys[(s_hist[br[e] >> 16] & 0xffffu) + (br[e] & 0xffffu)] = ((uint64_t)d[e] << 32) | id[e];
+    __syncthreads();                            // 5: every key parked in its bucket
+    // exact place inside the bucket, by parked position: all E keys of the thread and their buckets' extents in flight
+    // at once, then the members of the multi-key buckets (neighbouring positions)
+    // (EB positions per round: sixteen 64-bit keys and their extents at once do not fit the open-ended tier's 128 VGPRs)
+    constexpr int EB = E < 8 ? E : 8;
+    uint32_t best = 0;
+#pragma unroll
+    for (int e0 = 0; e0 < E; e0 += EB) {
+        uint64_t key[EB];
+        uint32_t ext[EB];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) key[e] = s_keys[min((e0 + e) * THREADS + t, n - 1)];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) ext[e] = s_hist[bucket_of((uint32_t)(key[e] >> 32))];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int i = (e0 + e) * THREADS + t;
+            if (i < n) {
+                const uint32_t s0 = ext[e] & 0xffffu, cnt = ext[e] >> 16;
+                const uint32_t kd = (uint32_t)(key[e] >> 32), kid = (uint32_t)key[e];
+                uint32_t rank = (uint32_t)i - s0;                    // alone in its bucket: in place
+                if (cnt > 1u) {
+                    rank = 0;
+                    uint32_t same = 0;                               // members with this key's depth bits (itself included)
+                    constexpr uint32_t RANK_BATCH = 4;               // the first members in ONE LDS round trip
+                    uint64_t kb[RANK_BATCH];
+#pragma unroll
+                    for (uint32_t m = 0; m < RANK_BATCH; ++m) kb[m] = s_keys[s0 + min(m, cnt - 1u)];
+#pragma unroll
+                    for (uint32_t m = 0; m < RANK_BATCH; ++m) {
+                        const bool in = m < cnt;
+                        rank += (in && kb[m] < key[e]) ? 1u : 0u;
+                        same += (in && (uint32_t)(kb[m] >> 32) == kd) ? 1u : 0u;
+                    }
+                    for (uint32_t j = s0 + RANK_BATCH; j < s0 + cnt; ++j) {
+                        const uint64_t kj = s_keys[j];
+                        rank += kj < key[e] ? 1u : 0u;
+                        same += (uint32_t)(kj >> 32) == kd ? 1u : 0u;
+                    }
+                    if (tie && same > 1u) {
+                        // exact depth tie between different Gaussians: the CALLER's index decides (a few keys per list)
+                        const int32_t mine = gload(tie + kid);
+                        rank = 0;
+                        for (uint32_t j = s0; j < s0 + cnt; ++j) {
+                            const uint64_t kj = s_keys[j];
+                            const uint32_t dj = (uint32_t)(kj >> 32);
+                            rank += (dj < kd || (dj == kd && (uint32_t)kj != kid && gload(tie + (uint32_t)kj) < mine)) ? 1u : 0u;
+                        }
+                    }
+                }
+                const uint32_t f = s0 + rank;
+                gstore(out + f, kid);
+                if (n_env >= 0 && (int)kid >= n_env) best = max(best, pos_offset + f + 1u);
+            }
+        }
+    }
+    if (n_env >= 0) {
+        best = wave_inclusive_max(best);
+        if (lane == WAVE - 1 && best) gatomic_max(obj_last, best);
+    }
+    return true;
+}
+
+template <int THREADS, int E, int NB = THREADS * E, bool DIRECT = false, int KEYS = THREADS * E>
+__device__ __forceinline__ bool sort_list_in_lds(unsigned char* __restrict__ lds, const uint2* __restrict__ bucket,
+                                                 uint32_t* __restrict__ out, int n, int n_env, uint32_t* __restrict__ obj_last,
+                                                 uint32_t pos_offset = 0, const int32_t* __restrict__ tie = nullptr) {
+#if PGR_SORT_POS
+    return bucket_sort_tile_pos<THREADS, E, NB, KEYS>(lds, bucket, out, n, n_env, obj_last, pos_offset, tie);
+#else
+    return bucket_sort_tile<THREADS, E, NB, DIRECT, KEYS>(lds, bucket, out, n, n_env, obj_last, pos_offset, tie);
+#endif
+}
+
 // Lists beyond one LDS sort (> CAP keys): ONE counting-sort pass by coarse depth bucket through the alt buffer
 // (L2-resident), cut at the first bucket start at or after every multiple of CAP / 2 -- with no bucket larger than
 // CAP / 2 every segment holds < CAP keys, and all of its depths precede the next segment's -- then each segment is
@@ -822,7 +1017,7 @@ __device__ __forceinline__ bool partition_sort_long(unsigned char* __restrict__ 
         const uint32_t a = s_cut[g];
         if (a >= (uint32_t)n) break;
         const int n_seg = (int)(s_cut[g + 1] - a);
-        if (!bucket_sort_tile<THREADS, E, SORT_LARGE_BUCKETS, true, SORT_LARGE_KEYS>(lds, alt + a, out + a, n_seg, n_env, obj_last, a, tie))
+        if (!sort_list_in_lds<THREADS, E, SORT_LARGE_BUCKETS, true, SORT_LARGE_KEYS>(lds, alt + a, out + a, n_seg, n_env, obj_last, a, tie))
             merge_sort_tile<THREADS, E>(reinterpret_cast<uint64_t*>(lds), alt + a, out + a, n_seg, nullptr, n_env, obj_last, a,
                                         tie, inv);
         __syncthreads();
@@ -881,19 +1076,19 @@ __device__ __forceinline__ void sort_item(const BinView* __restrict__ views, int
 __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* __restrict__ views, int tiles,
                                                                  const uint4* __restrict__ queue,
                                                                  const uint32_t* __restrict__ n_queue) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[SORT_THREADS * 8 * 12 + 128];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[SORT_THREADS * 8 * 12 + SORT_MISC_BYTES];
     uint64_t* skeys = reinterpret_cast<uint64_t*>(lds);     // merge sort: SORT_THREADS * 9 keys fit as well
     if (blockIdx.x >= *n_queue) return;
     const uint2* bucket; uint32_t* out; int n; ObjOut oo;
     sort_item(views, tiles, queue[blockIdx.x], bucket, out, n, oo);
     if (n <= SORT_THREADS * 2) {
-        if (!bucket_sort_tile<SORT_THREADS, 2>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+        if (!sort_list_in_lds<SORT_THREADS, 2>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
             merge_sort_tile<SORT_THREADS, 2>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
     } else if (n <= SORT_THREADS * 4) {
-        if (!bucket_sort_tile<SORT_THREADS, 4>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+        if (!sort_list_in_lds<SORT_THREADS, 4>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
             merge_sort_tile<SORT_THREADS, 4>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
     } else {
-        if (!bucket_sort_tile<SORT_THREADS, 8>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+        if (!sort_list_in_lds<SORT_THREADS, 8>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
             merge_sort_tile<SORT_THREADS, 8>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
     }
 }
@@ -916,7 +1111,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? PGR_T1_WAVES : 4)) void 
     constexpr int CAP = THREADS * E;
     static_assert(!LAST || CAP == SORT_LARGE_MAX, "the open-ended tier");
     // bucket sort image: 12 B per key, or (last tier) keys + 4096 counters = 144 KiB; the merge sort's padded keys fit
-    constexpr size_t LDS_BYTES = LAST ? (size_t)SORT_LARGE_KEYS * 8 + SORT_LARGE_BUCKETS * 4 + 128 : (size_t)CAP * 12 + 128;
+    constexpr size_t LDS_BYTES = LAST ? (size_t)SORT_LARGE_KEYS * 8 + SORT_LARGE_BUCKETS * 4 + SORT_MISC_BYTES : (size_t)CAP * 12 + SORT_MISC_BYTES;
     static_assert((size_t)THREADS * (E + 1) * 8 <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "lds");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     __shared__ uint32_t s_cut[LAST ? PART_MAX_SEGMENTS + 3 : 1];
@@ -927,10 +1122,10 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? PGR_T1_WAVES : 4)) void 
         sort_item(views, tiles, queue[k], bucket, out, n, oo, &alt);
         {
             if constexpr (!LAST) {
-                if (!bucket_sort_tile<THREADS, E>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+                if (!sort_list_in_lds<THREADS, E>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
                     merge_sort_tile<THREADS, E>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
             } else if (n <= SORT_LARGE_KEYS) {
-                if (!bucket_sort_tile<THREADS, E, SORT_LARGE_BUCKETS, true, SORT_LARGE_KEYS>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+                if (!sort_list_in_lds<THREADS, E, SORT_LARGE_BUCKETS, true, SORT_LARGE_KEYS>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
                     merge_sort_tile<THREADS, E>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
             } else if (partition_sort_long<THREADS, E>(lds, s_cut, bucket, reinterpret_cast<uint2*>(alt), out, n, oo.n_env,
                                                        oo.last, oo.tie, oo.inv)) {

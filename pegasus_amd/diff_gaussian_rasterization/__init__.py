@@ -49,15 +49,32 @@ def last_forward_info() -> dict:
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings: GaussianRasterizationSettings, want_aux: bool = False):
+                        raster_settings: GaussianRasterizationSettings, want_aux: bool = False, after_enqueue=None):
     """Forward rasterization of one view.  Returns (color, radii, depth) -- plus (final_T, n_contrib)
-    when ``want_aux``."""
+    when ``want_aux``.
+
+    The call is ENQUEUED without a host round trip (pgr_forward_posed_async: tables through pinned memory), then
+    ``after_enqueue(result_dict)`` runs -- work that only needs the outputs in stream order, e.g. render()'s visibility
+    filter, is queued behind the compositor while the GPU is still busy -- and only then the host waits for the batch's
+    status words.  A single view leaves the GPU idle between its kernels, so host microseconds after the wait are
+    wall-clock microseconds (round 5: 0.54 -> see profiles/r05_single_view_timeline.txt).  ``after_enqueue`` runs again
+    if an instance overflow re-rendered the view."""
     rs = raster_settings
     view = rasterizer.ViewSpec(rs.image_height, rs.image_width, rs.tanfovx, rs.tanfovy, rs.bg, rs.viewmatrix,
                                rs.projmatrix, rs.campos)
-    r = rasterizer.forward_views(means3D, opacities, [view], shs=sh, colors_precomp=colors_precomp, scales=scales,
-                                 rotations=rotations, cov3D_precomp=cov3Ds_precomp, sh_degree=rs.sh_degree,
-                                 scale_modifier=rs.scale_modifier, want_radii=True, want_aux=want_aux)[0]
+    pb = rasterizer.forward_views(means3D, opacities, [view], shs=sh, colors_precomp=colors_precomp, scales=scales,
+                                  rotations=rotations, cov3D_precomp=cov3Ds_precomp, sh_degree=rs.sh_degree,
+                                  scale_modifier=rs.scale_modifier, want_radii=True, want_aux=want_aux,
+                                  async_slot=("single-view", 0))
+    if isinstance(pb, list):            # (an empty view list cannot happen here; an empty SCENE still returns a handle)
+        r = pb[0]
+    else:
+        pb.record_info = True
+        if after_enqueue is not None:
+            after_enqueue(pb.results[0])
+        r = pb.wait()[0]
+        if after_enqueue is not None and getattr(pb, "_was_redone", False):
+            after_enqueue(r)
     if want_aux:
         return r["color"], r["radii"], r["depth"], r["final_T"], r["n_contrib"]
     return r["color"], r["radii"], r["depth"]

@@ -140,25 +140,52 @@ class GaussianModel:
         self.apply_rotation_on_xyz(R=T[:3, :3])
         self.apply_translation_on_xyz(t=T[:3, 3])
 
-    def _pose(self, T, rotate_xyz):
-        T = np.asarray(torch.as_tensor(T).detach().cpu().numpy(), dtype=np.float64)
-        if not rotate_xyz:
-            T = T.copy(); T[:3, 3] = 0
-        center = self._xyz.double().mean(0).cpu().numpy()
-        return compose.make_pose(T, center)
+    @staticmethod
+    def _host_matrix(M) -> np.ndarray:
+        """A pose matrix on the host, float64.  PEGASUS hands the SAME device tensor R to apply_rotation_on_splats and
+        apply_rotation_on_sh (pegasus_setup.py:195-208): its host copy (one device round trip) is kept for the next call."""
+        if not torch.is_tensor(M):
+            return np.asarray(M, dtype=np.float64)
+        try:
+            key = (id(M), M._version, M.data_ptr())
+        except RuntimeError:
+            key = None
+        hit = GaussianModel._host_matrix_slot
+        if key is not None and hit is not None and hit[0] == key:
+            return hit[1]
+        host = np.asarray(M.detach().cpu().numpy(), dtype=np.float64)
+        GaussianModel._host_matrix_slot = (key, host, M)       # (keeps M alive: its id cannot be recycled under the key)
+        return host
+
+    _host_matrix_slot = None
+
+    @classmethod
+    def _rotation_pose(cls, R):
+        """PgrObjectPose of a pure rotation about the origin (quaternion + SH band matrices), built once per R: the
+        reference's update calls apply_rotation_on_splats(R) and apply_rotation_on_sh(R) with the same tensor."""
+        host = cls._host_matrix(R)
+        hit = cls._rotation_pose_slot
+        if hit is not None and hit[0] is host:
+            return hit[1]
+        T = np.eye(4); T[:3, :3] = host
+        pose = compose.make_pose(T, np.zeros(3))
+        cls._rotation_pose_slot = (host, pose)
+        return pose
+
+    _rotation_pose_slot = None
 
     def apply_rotation_on_splats(self, R):
-        T = np.eye(4); T[:3, :3] = np.asarray(torch.as_tensor(R).detach().cpu().numpy(), dtype=np.float64)
-        xyz_keep = self._xyz.clone()
+        """q' = q_R (x) q for every splat (reference :496-505).  Orientation only: no rotation centre is needed, so the
+        object's mean is not fetched to the host (rounds 1-4 did, a device round trip per call)."""
         out_rot = torch.empty_like(self._rotation)
-        compose.compose_object(self._xyz.contiguous(), self._rotation.contiguous(), None, self._pose(T, False),
+        compose.compose_object(self._xyz.contiguous(), self._rotation.contiguous(), None, self._rotation_pose(R),
                                torch.empty_like(self._xyz), out_rot, None)
-        self._rotation, self._xyz = out_rot, xyz_keep
+        self._rotation = out_rot
 
     def apply_rotation_on_sh(self, R):
-        T = np.eye(4); T[:3, :3] = np.asarray(torch.as_tensor(R).detach().cpu().numpy(), dtype=np.float64)
+        """SH bands 1-3 rotated with the object (reference :507-546)."""
         out_rest = torch.empty_like(self._features_rest)
-        compose.compose_object(self._xyz.contiguous(), None, self._features_rest.contiguous(), self._pose(T, False),
+        compose.compose_object(self._xyz.contiguous(), None, self._features_rest.contiguous(), self._rotation_pose(R),
                                torch.empty_like(self._xyz), None, out_rest)
         self._features_rest = out_rest
 

@@ -30,6 +30,7 @@ from .sh_utils import sh_basis
 # ``invalidate_activations(model)``.  Tensors without a version counter (created under torch.inference_mode()) are simply
 # not cached.
 _SLOTS = weakref.WeakKeyDictionary()
+_ZERO_PROBES = {}        # no-grad "viewspace_points": one zero tensor per (shape, dtype, device)
 _SOURCES = {"get_opacity": ("_opacity",), "get_scaling": ("_scaling",), "get_rotation": ("_rotation",),
             "get_features": ("_features_dc", "_features_rest")}
 
@@ -60,12 +61,31 @@ def _kept(pc, getter: str):
 
 # ---- the three input groups of a rasterizer call ---------------------------------------------------------------------------
 
+def _camera_matrices(cam):
+    """(viewmatrix, projmatrix, campos) as the kernels read them: fp32, contiguous.  The reference's Camera keeps
+    ``world_view_transform`` as a TRANSPOSED VIEW (`torch.tensor(..).transpose(0, 1).cuda()`), so every render() paid a
+    copy kernel + launch for it (two per call in the round-4 trace); the contiguous copies are kept on the camera while the
+    three tensors are the same objects with the same version counters (inference only, like the model's activations)."""
+    src = (cam.world_view_transform, cam.full_proj_transform, cam.camera_center)
+    if torch.is_grad_enabled():
+        return src
+    try:
+        key = tuple((id(t), t._version, t.data_ptr(), tuple(t.shape), t.stride()) for t in src)
+        slot = getattr(cam, "_pgr_matrices", None)
+        if slot is None or slot[0] != key:
+            slot = (key, tuple(t.detach().float().contiguous() for t in src), src)
+            cam._pgr_matrices = slot
+        return slot[1]
+    except (RuntimeError, AttributeError, TypeError):      # inference tensors, objects that take no attribute
+        return src
+
+
 def _view(cam, pc, pipe, bg, scaling_modifier) -> GaussianRasterizationSettings:
+    vm, pm, cp = _camera_matrices(cam)
     return GaussianRasterizationSettings(
         image_height=int(cam.image_height), image_width=int(cam.image_width),
         tanfovx=math.tan(0.5 * cam.FoVx), tanfovy=math.tan(0.5 * cam.FoVy),
-        bg=bg, scale_modifier=scaling_modifier,
-        viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, campos=cam.camera_center,
+        bg=bg, scale_modifier=scaling_modifier, viewmatrix=vm, projmatrix=pm, campos=cp,
         sh_degree=pc.active_sh_degree, prefiltered=False, debug=bool(getattr(pipe, "debug", False)))
 
 
@@ -95,8 +115,16 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     xyz = pc.get_xyz
     # "viewspace_points": a zero tensor shaped like the means whose .grad receives the screen-space (NDC-scaled) gradient
     # of the 2D means -- training-style callers read it for densification.  A leaf that asks for a gradient only when
-    # autograd is on; the render loops run under torch.no_grad() (pegasus.py:248) and get plain zeros.
-    probe = torch.zeros_like(xyz, requires_grad=torch.is_grad_enabled())
+    # autograd is on; the render loops run under torch.no_grad() (pegasus.py:248) and get plain zeros -- ONE zero tensor
+    # per shape and device, not a 24 MB fill per call (nothing writes it without autograd).
+    if torch.is_grad_enabled():
+        probe = torch.zeros_like(xyz, requires_grad=True)
+    else:
+        pkey = (tuple(xyz.shape), xyz.dtype, xyz.device)
+        probe = _ZERO_PROBES.get(pkey)
+        if probe is None:
+            _ZERO_PROBES.clear()                                   # (one scene shape at a time: a merged scene grows per object)
+            probe = _ZERO_PROBES[pkey] = torch.zeros_like(xyz)
     settings = _view(viewpoint_camera, pc, pipe, bg_color, scaling_modifier)
     inputs = dict(means3D=xyz, means2D=probe, opacities=_kept(pc, "get_opacity"),
                   **_colour(pc, pipe, viewpoint_camera, override_color), **_geometry(pc, pipe, scaling_modifier))
@@ -106,7 +134,11 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         # the render loops (torch.no_grad(), pegasus.py:248): straight to the forward, without building an nn.Module per call
         # and going through its __call__ machinery (0.571 -> 0.553 ms per call on the 2 M-Gaussian scene: a single view
         # leaves the GPU idle between its kernels, so host microseconds are wall-clock microseconds)
+        # "visibility_filter" is queued behind the compositor before the host waits for the call's status
+        extra = {}
         image, radii, depth = rasterize_gaussians(
             inputs["means3D"], inputs["means2D"], inputs.get("shs"), inputs.get("colors_precomp"), inputs["opacities"],
-            inputs.get("scales"), inputs.get("rotations"), inputs.get("cov3D_precomp"), settings)
+            inputs.get("scales"), inputs.get("rotations"), inputs.get("cov3D_precomp"), settings,
+            after_enqueue=lambda r: extra.__setitem__("vis", r["radii"] > 0))
+        return {"render": image, "depth": depth, "viewspace_points": probe, "visibility_filter": extra["vis"], "radii": radii}
     return {"render": image, "depth": depth, "viewspace_points": probe, "visibility_filter": radii > 0, "radii": radii}

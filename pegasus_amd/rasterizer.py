@@ -134,6 +134,7 @@ class PendingBatch:
         self.results, self._event, self._scratch, self._nv = results, event, scratch, nv
         self._key, self._max_inst, self._redo = key, max_inst, redo
         self.num_instances = None
+        self.record_info = False     # True: wait() fills last_forward_info() like a synchronous call (single-view drop-in)
 
     def wait(self):
         if self._event is not None:
@@ -146,6 +147,12 @@ class PendingBatch:
                 _WS.capacity_hint[self._key] = max(_WS.capacity_hint.get(self._key, 0), _grown_capacity(peak, 1.6))   # few, large steps:
                 # every growth reallocates the multi-GB workspace (tens of ms)
             self._event = None
+            if self.record_info and status != _lib.PGR_ERR_INSTANCE_OVERFLOW:
+                ws = self._keep[1]
+                _LAST_INFO.clear()
+                _LAST_INFO.update(num_instances=self.num_instances, max_instances=int(self._max_inst),
+                                  used_max_instances=int(self._max_inst), n=int(self._key[1]), width=int(self._key[2]),
+                                  height=int(self._key[3]), n_views=self._nv, workspace=ws, workspace_bytes=int(ws.numel()))
             if status == _lib.PGR_ERR_INSTANCE_OVERFLOW:
                 self._was_redone = True
                 _WS.capacity_hint[self._key] = max(_WS.capacity_hint.get(self._key, 0), _grown_capacity(peak, 1.6))   # raises beyond MAX_INSTANCES

@@ -19,7 +19,7 @@ rows = list(db.execute(f"select {start},{end},{namec} from {t} order by {start}"
 
 def short(name):
     m = re.search(r"pgr::(\w+)(<[^(]*>)?", name)
-    return (m.group(1) + (m.group(2) or "")) if m else re.sub(r"\(.*", "", name)[:48]
+    return (m.group(1) + (m.group(2) or "")) if m else name[:200]
 
 
 # a call = the kernels from one preprocess_batch_kernel to the next
@@ -56,7 +56,10 @@ for c in calls:
 n = len(calls)
 print(f"{'kernel':50s} {'avg us':>9s} {'gap before us':>14s}")
 for k in order:
-    print(f"{k:50s} {dur[k] / cnt[k] / 1e3:9.2f} {gap[k] / cnt[k] / 1e3:14.2f}")
+    print(f"{k[:50]:50s} {dur[k] / cnt[k] / 1e3:9.2f} {gap[k] / cnt[k] / 1e3:14.2f}")
+for k in order:
+    if len(k) > 50:
+        print("#", k)
 print(f"per call: first kernel start -> last kernel end {span / n / 1e3:.1f} us, kernels busy {busy / n / 1e3:.1f} us, "
       f"idle between kernels {(span - busy) / n / 1e3:.1f} us")
 gaps_between = [(b[0][0] - a[-1][1]) / 1e3 for a, b in zip(calls, calls[1:])]

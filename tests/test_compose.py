@@ -89,7 +89,7 @@ def test_scene_composer_renders_like_a_host_merged_cloud(oracle, gpu_device):
                                        o.object_id))
     merged = scenes.SplatCloud.concat([env, *posed])
     act = merged.activated()
-    _, views = scenes.scene_c3(scale=0.001, n_views=2, width=320, height=240)
+    _, views = scenes.scene_c3(scale=0.001, n_views=2, width=320, height=240, camera_set="fibonacci_above_9deg")
     for v in views:
         spec = rasterizer.ViewSpec(v.height, v.width, v.tanfovx, v.tanfovy, torch.zeros(3, device=gpu_device),
                                    *(torch.from_numpy(a).to(gpu_device) for a in

@@ -38,7 +38,7 @@ def test_render_facade_and_mask_wrappers(oracle, gpu_device):
         colors = torch.from_numpy(masks.generate_colors(len(objs))).to(dev)
         prender.assign_semantic_colors(objs, colors)
 
-        v = scenes.scene_c3(scale=0.001, n_views=1, width=320, height=240)[1][0]
+        v = scenes.scene_c3(scale=0.001, n_views=1, width=320, height=240, camera_set="fibonacci_above_9deg")[1][0]
         H, W = v.height, v.width
         cam = Camera(colmap_id=0, R=v.R_c2w, T=v.t_w2c, FoVx=v.fovx, FoVy=v.fovy, image=torch.empty((3, H, W)),
                      gt_alpha_mask=None, image_name="0", uid=0, data_device=str(dev))
@@ -265,7 +265,8 @@ def test_semantic_wrappers_follow_objects_cameras_and_backgrounds(gpu_device):
     obj_c = [scenes.rigid_transform(scenes.box_object(rng, 4000, (0.1, 0.12, 0.16), np.log(0.004), 0.3, 0.2, k + 1),
                                     np.eye(3), np.array([0.15 * k - 0.08, 0.05 * k, 0.09])) for k in range(2)]
     mk = lambda c: GaussianModel.from_arrays(c.xyz, c.features_dc, c.features_rest, c.opacity, c.scaling, c.rotation, device=dev)
-    views = scenes.scene_c3(scale=0.001, n_views=2, width=320, height=240)[1]
+    # (cameras that look DOWN on the hand-placed objects: the default set starts at elevation 0)
+    views = scenes.scene_c3(scale=0.001, n_views=2, width=320, height=240, camera_set="fibonacci_above_9deg")[1]
     cams = [Camera(colmap_id=i, R=v.R_c2w, T=v.t_w2c, FoVx=v.fovx, FoVy=v.fovy, image=None, image_width=v.width,
                    image_height=v.height, gt_alpha_mask=None, image_name=str(i), uid=i, data_device=str(dev))
             for i, v in enumerate(views)]
