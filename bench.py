@@ -67,6 +67,12 @@ def parse(argv=None):
                     help="c3 / c5 cameras: fibonacci (default) = the first --views directions of the BOP toolkit's Fibonacci upper "
                          "hemisphere, elevation 0..90 degrees, as SURVEY.md section 8d names them; fibonacci_above_9deg = the "
                          "subset rounds 1-4 rendered (directions below ~8.6 degrees skipped and back-filled), for A/B only")
+    ap.add_argument("--width", type=int, default=800, help="image width (c3 / c5; 800 = the baseline config)")
+    ap.add_argument("--height", type=int, default=800, help="image height (c3 / c5; 800 = the baseline config)")
+    ap.add_argument("--objects", type=int, default=0,
+                    help="objects of the merged scene (c3 / c5; 0 = the config's own 8 / 20).  --width 640 --height 480 --objects 6 "
+                         "--data-points all is the reference's own default run (/root/reference/pegasus.py:486-503): reported as a "
+                         "side workload, never as the headline")
     ap.add_argument("--batch", type=int, default=32,
                     help="views per step (one batch call); 16 default steps x 32 = the 512 views of configs[2], each once")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -178,7 +184,7 @@ CAMERA_SET_TEXT = {
 }
 
 
-def build_workload(name, scale, n_views, with_poses=False, camera_set="fibonacci"):
+def build_workload(name, scale, n_views, with_poses=False, camera_set="fibonacci", width=800, height=800, objects=0):
     from pegasus_amd import scenes
     rest = None
     if name == "c1":
@@ -188,15 +194,17 @@ def build_workload(name, scale, n_views, with_poses=False, camera_set="fibonacci
         cloud, views = scenes.scene_c2(n=int(150_000 * scale), n_views=n_views)
         label = "C2 single object 150k Gaussians, 800x800 hemisphere views"
     elif name == "c5":
-        cloud, views, rest = scenes.merged_scene(5, int(3_400_000 * scale), 20, int(80_000 * scale), n_views,
-                                                 camera_set=camera_set)
-        label = "C5 5M-Gaussian scene (3.4M environment + 20 objects), 800x800"
+        cloud, views, rest = scenes.merged_scene(5, int(3_400_000 * scale), objects or 20, int(80_000 * scale), n_views,
+                                                 width, height, camera_set=camera_set)
+        label = f"C5 5M-Gaussian scene (3.4M environment + {objects or 20} objects), {width}x{height}"
     else:
-        cloud, views, rest = scenes.merged_scene(3, int(1_360_000 * scale), 8, int(80_000 * scale), n_views,
-                                                 camera_set=camera_set)
-        label = "C3 merged env + 8 objects, 2M Gaussians, 800x800"
+        cloud, views, rest = scenes.merged_scene(3, int(1_360_000 * scale), objects or 8, int(80_000 * scale), n_views,
+                                                 width, height, camera_set=camera_set)
+        label = f"C3 merged env + {objects or 8} objects, {cloud.n / 1e6:.3g}M Gaussians, {width}x{height}"
     if scale != 1.0:
         label += f" [scale={scale}: NOT the baseline config]"
+    if name in ("c3", "c5") and ((width, height) != (800, 800) or objects not in (0, 8 if name == "c3" else 20)):
+        label += " [image size / object count differ: NOT the baseline config]"
     if with_poses:
         return cloud, views, label, rest
     return cloud, views, label
@@ -227,7 +235,8 @@ class RealEngine:
         B = self.B = max(1, args.batch)
         n_views_total = max(args.views, B) * world
         cloud, views, label, rest = build_workload(args.workload, args.scale, n_views_total, with_poses=True,
-                                                   camera_set=args.camera_set)
+                                                   camera_set=args.camera_set, width=args.width, height=args.height,
+                                                   objects=args.objects)
         self.cloud, self.views, self.label = cloud, views, label
         self.act = act = cloud.activated()
         fr = self.fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"],
@@ -827,7 +836,8 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
         kern = pmc["stage_kernel"].get(dom_name)
         k = pmc["kernels"].get(kern) if kern else None
         fused_default = with_masks and not args.separate_semantic
-        if k and pmc.get("workload") == args.workload and pmc.get("batch") == B and pmc.get("fused") == fused_default:
+        if (k and pmc.get("workload") == args.workload and pmc.get("batch") == B and pmc.get("fused") == fused_default
+                and (W, H) == (800, 800) and not args.objects and args.scale == 1.0):
             roofline["traffic"] = int(k["traffic_bytes_per_launch"])
             roofline["traffic_detail"] = {kk: k[kk] for kk in ("kernel", "dispatches", "fetch_size_kib_per_launch",
                                                                "write_size_kib_per_launch") if kk in k}
@@ -887,8 +897,8 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
         cpu = side_leg(_cpu_baseline, args, eng)
     drop_in = None
     if world == 1 and not args.no_drop_in and with_masks and not args.dynamic and args.workload in ("c3", "c5"):
-        drop_in = side_leg(drop_in_numbers, eng, n_frames=4, n_render_calls=48)
-        dyn = side_leg(drop_in_numbers, eng, n_frames=4, n_render_calls=4, dynamic=True)
+        drop_in = side_leg(drop_in_numbers, eng, n_frames=6, n_render_calls=48)
+        dyn = side_leg(drop_in_numbers, eng, n_frames=6, n_render_calls=4, dynamic=True)
         if isinstance(drop_in, dict) and "error" not in drop_in:
             drop_in["dynamic"] = ({k: dyn[k] for k in ("mode", "frames_per_s", "ms_per_frame", "frames_per_s_all_data_points",
                                                        "ms_per_part")} if "error" not in dyn else dyn)
@@ -1065,7 +1075,8 @@ def drop_in_numbers(eng, n_frames=4, n_render_calls=48, dynamic=False):
         return scene
 
     with torch.no_grad():
-        scene = frame(cams[0])                                       # warm-up
+        for _ in range(3):                                           # warm-up: allocator blocks of every size, pinned host
+            scene = frame(cams[0])                                   # buffers, first-use costs of the pose path
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for c in cams[1:n_frames + 1]:
@@ -1110,7 +1121,8 @@ def run_cpu_only(args):
     run anything under oracle/)."""
     import oracle
     oracle.build()
-    cloud, views, label = build_workload(args.workload, args.scale, max(1, min(args.views, 8)), camera_set=args.camera_set)
+    cloud, views, label = build_workload(args.workload, args.scale, max(1, min(args.views, 8)), camera_set=args.camera_set,
+                                         width=args.width, height=args.height, objects=args.objects)
     act = cloud.activated()
     n_cpu = os.cpu_count() or 1
     rows = {}

@@ -560,210 +560,35 @@ __device__ __forceinline__ void merge_sort_tile(uint64_t* __restrict__ skeys, co
 // onto NB = capacity buckets puts about one key in each: one LDS atomic per key builds the histogram AND hands the
 // key its arrival slot inside the bucket, one scan turns counts into bucket starts, one LDS store parks the key, and
 // the exact order inside a bucket (same 64-bit key compare as the merge sort, so the result is the same permutation)
-// is a count of the smaller keys among the bucket's few members.  ~10 LDS operations per key instead of the merge
-// sort's ~35 (log2(n) merge-path rounds).  Lists whose depths pile up (sum of squared bucket counts > 8 n) are
-// rejected and take the merge sort; the result never depends on which path ran.
+// is a count of the smaller keys among the bucket's few members.  Lists whose depths pile up (sum of squared bucket
+// counts > 8 n) are rejected and take the merge sort; the result never depends on which path ran.
+//
+// Round 5 (position-owned ranking; rounds 1-4 ranked a key in the thread that had loaded it, stored the sorted
+// indices into an LDS image and read that back: eight workgroup barriers, C3 sort stage 0.0272 ms per view, C5 0.0817):
+//   * Once the keys are parked (bucket start + arrival slot) the image is sorted by bucket, and the exact place of a key
+//     is decided by the thread that owns its PARKED POSITION: position i is read back coalesced, its bucket recomputed
+//     from its depth bits (4 VALU), the bucket's extent read from the counter word (the lanes of a wave read consecutive
+//     or equal words), the members of a multi-key bucket are the position's own neighbours.  The random LDS reads of the
+//     ranking and the random store + read-back of an index image are gone (23 % of the sort's LDS-array cycles at a
+//     2.1 - 2.9-fold conflict factor: scripts/sim/sort_bank_conflicts.py); the sorted indices go straight to global
+//     memory from position order (a wave's 64 stores fall into the 64..130-entry window its positions map to: whole
+//     lines).  What stays random -- the histogram atomic, the start look-up and the 8-byte park -- is random by
+//     construction (a hash of the depth): no bucket swizzle or key-to-lane assignment changes its 2.7-fold conflict
+//     factor (same simulation).
+//   * Wave-level partial results (min, max, totals, squares) go to per-wave words instead of atomics on shared words,
+//     which need no zero-fill barrier in front: five workgroup barriers per list.
+//   Measured (A/B on one box, profiles/r05_sort_ab.txt): C3 sort stage 0.0272 -> 0.0240 ms per view, C5 0.0817 -> 0.0738.
 
 constexpr uint32_t BUCKET_SQ_LIMIT = 8;
-#ifndef PGR_SORT_POS
-#define PGR_SORT_POS 1          // 1: position-owned ranking (bucket_sort_tile_pos); 0: rounds 1-4 (bucket_sort_tile) -- A/B builds
-#endif
 
-
-// Sorts n <= THREADS*E keys of `bucket` into out[] (indices) -- same contract as merge_sort_tile without keys_out.
-// NB = number of buckets (multiple of THREADS; THREADS*E = one per key of capacity).  DIRECT: sorted indices go
-// straight to global memory (4-B scattered stores into an L2-resident list) instead of through an LDS image -- the
-// 16384-key tier has no LDS left for one.
-// lds: KEYS*8 + NB*4 + 128 bytes (NB >= THREADS*E unless DIRECT; KEYS = the most keys a call may hold, THREADS*E by default).  Returns false (LDS free for reuse, nothing
-// written) when the list is rejected.
-template <int THREADS, int E, int NB = THREADS * E, bool DIRECT = false, int KEYS = THREADS * E>
-__device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds, const uint2* __restrict__ bucket,
-                                                 uint32_t* __restrict__ out, int n, int n_env,
-                                                 uint32_t* __restrict__ obj_last, uint32_t pos_offset = 0,
-                                                 const int32_t* __restrict__ tie = nullptr) {
-    constexpr int CAP = THREADS * E, WAVES = THREADS / WAVE, CH = NB / (WAVES * WAVE);   // 64-bucket chunks per wave
-    static_assert(NB % (WAVES * WAVE) == 0 && (DIRECT || NB >= CAP), "bucket count");
-    static_assert((4 + WAVES) * 4 <= 128, "s_misc must fit the 128 bytes the callers reserve behind the counters");
-    static_assert(KEYS <= CAP, "key image");
-    uint64_t* s_keys = reinterpret_cast<uint64_t*>(lds);                       // [KEYS] (n <= KEYS <= CAP)
-    uint32_t* s_hist = reinterpret_cast<uint32_t*>(lds + (size_t)KEYS * 8);    // [NB], later the sorted indices
-    uint32_t* s_misc = s_hist + NB;                                            // [0] min [1] max [2] sum k^2 [4..] wave totals
-    const int t = threadIdx.x, lane = t & (WAVE - 1), wave = t / WAVE;
-
-    // All E loads of a thread are issued back to back (index clamped into the list, n >= 1) and waited for once: a
-    // load inside `if (i < n)` is not hoisted by the compiler, and E branches each ending in s_waitcnt vmcnt(0) made
-    // the key load E serial round trips (20 k of the 46 k cycles of a 5 k-key list, s_memtime stamps).
-    uint32_t d[E], id[E];
-    uint32_t dmin = 0xffffffffu, dmax = 0u;
-    {
-        uint2 v[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) v[e] = gload(bucket + min(e * THREADS + t, n - 1));
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const bool in = e * THREADS + t < n;
-            d[e] = in ? v[e].x : 0xffffffffu; id[e] = in ? v[e].y : 0xffffffffu;
-            dmin = min(dmin, d[e]); dmax = max(dmax, in ? v[e].x : 0u);
-        }
-    }
-    for (int i = t; i < NB; i += THREADS) s_hist[i] = 0u;
-    if (t < 4 + WAVES) s_misc[t] = t == 0 ? 0xffffffffu : 0u;
-    __syncthreads();
-    // -- key load + zero fill done
-    // block min / max of the depth bits: DPP prefix inside the wave (VALU only: a ds_bpermute butterfly pays six LDS
-    // round trips), one LDS atomic per wave.  min as max of the complement (0 is the prefix-max identity).
-    dmin = ~wave_inclusive_max(~dmin);
-    dmax = wave_inclusive_max(dmax);
-    if (lane == WAVE - 1) { atomicMin(&s_misc[0], dmin); atomicMax(&s_misc[1], dmax); }
-    __syncthreads();
-    // -- min / max done
-    const uint32_t mn = s_misc[0];
-    const float scale = (float)NB / ((float)(s_misc[1] - mn) + 1.0f);
-    // monotone in d: uint->float conversion, multiplication by a positive constant, truncation and clamp all are
-    uint32_t br[E];      // bucket << 16 | arrival slot inside the bucket
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        br[e] = 0u;
-        if (e * THREADS + t < n) {
-            const uint32_t b = min((uint32_t)((float)(d[e] - mn) * scale), (uint32_t)(NB - 1));
-            br[e] = (b << 16) | atomicAdd(&s_hist[b], 1u);
-        }
-    }
-    __syncthreads();
-    // -- histogram atomics done
-    // pass A: every wave owns NB / WAVES consecutive buckets (CH chunks of 64): totals and sum of squares
-    const int wbase = wave * (WAVE * CH);
-    uint32_t tot = 0, sq = 0;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const uint32_t h = s_hist[wbase + c * WAVE + lane];
-        tot += h; sq += h * h;
-    }
-    tot = wave_inclusive_scan(tot);
-    sq = wave_inclusive_scan(sq);
-    if (lane == WAVE - 1) { s_misc[4 + wave] = tot; atomicAdd(&s_misc[2], sq); }
-    __syncthreads();
-    // -- totals + squares done
-    // average occupancy is n / NB by construction: reject when the squares exceed what an even spread would cost
-    const bool reject = s_misc[2] > BUCKET_SQ_LIMIT * (uint32_t)n * (uint32_t)((CAP + NB - 1) / NB);
-    if (reject) { __syncthreads(); return false; }
-    // pass B: exclusive scan of the counts -> bucket starts
-    uint32_t carry = 0;
-    for (int w = 0; w < wave; ++w) carry += s_misc[4 + w];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const uint32_t h = s_hist[wbase + c * WAVE + lane];
-        const uint32_t incl = wave_inclusive_scan(h);
-        // bucket start | members << 16 (both < 2^16: n <= 16384): the key scatter below then knows its bucket's
-        // extent from the one word it reads anyway, and the ranking needs no further look-up
-        s_hist[wbase + c * WAVE + lane] = (carry + incl - h) | (h << 16);
-        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
-    }
-    __syncthreads();
-    // -- scan done
-    uint32_t fin[E];     // here: bucket start | members << 16
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        fin[e] = 0u;
-        if (e * THREADS + t < n) {
-            fin[e] = s_hist[br[e] >> 16];
-            s_keys[(fin[e] & 0xffffu) + (br[e] & 0xffffu)] = ((uint64_t)d[e] << 32) | id[e];
-        }
-    }
-    __syncthreads();
-    // -- keys to their buckets done
-    // exact place inside the bucket: number of smaller keys among its members.  A key alone in its bucket (about half
-    // of them at one bucket per key) is in place already: no LDS access at all.  (Tried and measured slower: advancing
-    // the keys of a thread in lockstep, member m of every key's bucket per round -- the predicated reads did not
-    // overlap and the bookkeeping cost more than the round trips it saved.)
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        if (e * THREADS + t < n) {
-            const uint32_t s0 = fin[e] & 0xffffu, cnt = fin[e] >> 16;
-            uint32_t rank = 0;
-            if (cnt > 1u) {
-                const uint64_t key = ((uint64_t)d[e] << 32) | id[e];
-                uint32_t same = 0;                       // members with this key's depth bits (itself included)
-                // the first RANK_BATCH members in ONE LDS round trip (independent reads, index clamped into the bucket);
-                // a serial read-compare loop pays the LDS latency per member, and most buckets hold 2..4 keys
-                constexpr uint32_t RANK_BATCH = 4;
-                uint64_t kb[RANK_BATCH];
-#pragma unroll
-                for (uint32_t m = 0; m < RANK_BATCH; ++m) kb[m] = s_keys[s0 + min(m, cnt - 1u)];
-#pragma unroll
-                for (uint32_t m = 0; m < RANK_BATCH; ++m) {
-                    const bool in = m < cnt;
-                    rank += (in && kb[m] < key) ? 1u : 0u;
-                    same += (in && (uint32_t)(kb[m] >> 32) == d[e]) ? 1u : 0u;
-                }
-                for (uint32_t j = s0 + RANK_BATCH; j < s0 + cnt; ++j) {
-                    const uint64_t kj = s_keys[j];
-                    rank += kj < key ? 1u : 0u;
-                    same += (uint32_t)(kj >> 32) == d[e] ? 1u : 0u;
-                }
-                if (tie && same > 1u) {
-                    // exact depth tie between different Gaussians: the CALLER's index decides (a few keys per list;
-                    // measured: cheaper than carrying the tie index in the bucket entries or in the LDS keys)
-                    const int32_t mine = gload(tie + id[e]);
-                    rank = 0;
-                    for (uint32_t j = s0; j < s0 + cnt; ++j) {
-                        const uint64_t kj = s_keys[j];
-                        const uint32_t dj = (uint32_t)(kj >> 32);
-                        rank += (dj < d[e] || (dj == d[e] && (uint32_t)kj != id[e] && gload(tie + (uint32_t)kj) < mine)) ? 1u : 0u;
-                    }
-                }
-            }
-            fin[e] = s0 + rank;
-        }
-    }
-    // -- rank inside the bucket done
-    if (DIRECT) {
-        uint32_t best = 0;
-#pragma unroll
-        for (int e = 0; e < E; ++e)
-            if (e * THREADS + t < n) {
-                gstore(out + fin[e], id[e]);
-                if (n_env >= 0 && (int)id[e] >= n_env) best = max(best, pos_offset + fin[e] + 1u);
-            }
-        if (n_env >= 0) {
-#pragma unroll
-            for (int m = 1; m < WAVE; m <<= 1) best = max(best, (uint32_t)__shfl_xor((int)best, m));
-            if (lane == 0 && best) gatomic_max(obj_last, best);
-        }
-        // -- direct output done
-        return true;
-    }
-    __syncthreads();
-    uint32_t* s_idx = s_hist;
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-        if (e * THREADS + t < n) s_idx[fin[e]] = id[e];
-    __syncthreads();
-    for (int i = t; i < n; i += THREADS) gstore(out + i, s_idx[i]);
-    // -- index image + output done
-    if (n_env >= 0) mark_last_object<THREADS>([&](int i) { return s_idx[i]; }, n, n_env, obj_last, pos_offset);
-    // -- last object marker done
-    return true;
-}
-
-// ---- bucket sort, position-owned ranking (round 5) -----------------------------------------------------------------
-// Same map, same buckets, same result as bucket_sort_tile above; what changes is WHO ranks a key and how often the
-// workgroup meets at a barrier.
-//   * Once the keys are parked (bucket start + arrival slot) the image is sorted by bucket; the exact place of a key is
-//     decided by the thread that owns its PARKED POSITION, not by the thread that loaded it: position i is read back
-//     coalesced, its bucket recomputed from its depth bits (4 VALU), the bucket's extent read from the counter word (lanes
-//     of a wave read consecutive or equal words), the members of a multi-key bucket are the position's own neighbours.
-//     The random LDS reads of the ranking and the random store + read-back of an index image (rounds 1-4: 23 % of the
-//     sort's LDS-array cycles at a 2.1 - 2.9-fold conflict factor, scripts/sim/sort_bank_conflicts.py) are gone; the
-//     sorted indices go straight to global memory from position order (a wave's 64 stores fall into the 64..130-entry
-//     window its positions map to: whole lines).
-//   * Wave-level partial results (min, max, totals, squares) go to per-wave words instead of atomics on shared words,
-//     which need no zero-fill barrier in front: five workgroup barriers per list instead of eight.
-// lds: KEYS*8 + NB*4 + 256 bytes.
+// Sorts n <= THREADS*E keys of `bucket` (global, (depth,idx) pairs) into out[] (indices) -- same contract as
+// merge_sort_tile without keys_out.  NB = number of buckets (a multiple of THREADS; THREADS*E = one per key of
+// capacity); KEYS = the most keys a call may hold (THREADS*E by default).  lds: KEYS*8 + NB*4 + SORT_MISC_BYTES.
+// Returns false (LDS free for reuse, nothing written) when the list is rejected.
 constexpr int SORT_MISC_BYTES = 256;
 
 template <int THREADS, int E, int NB = THREADS * E, int KEYS = THREADS * E>
-__device__ __forceinline__ bool bucket_sort_tile_pos(unsigned char* __restrict__ lds, const uint2* __restrict__ bucket,
+__device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds, const uint2* __restrict__ bucket,
                                                      uint32_t* __restrict__ out, int n, int n_env,
                                                      uint32_t* __restrict__ obj_last, uint32_t pos_offset = 0,
                                                      const int32_t* __restrict__ tie = nullptr) {
@@ -914,17 +739,6 @@ __device__ __forceinline__ bool bucket_sort_tile_pos(unsigned char* __restrict__
     return true;
 }
 
-template <int THREADS, int E, int NB = THREADS * E, bool DIRECT = false, int KEYS = THREADS * E>
-__device__ __forceinline__ bool sort_list_in_lds(unsigned char* __restrict__ lds, const uint2* __restrict__ bucket,
-                                                 uint32_t* __restrict__ out, int n, int n_env, uint32_t* __restrict__ obj_last,
-                                                 uint32_t pos_offset = 0, const int32_t* __restrict__ tie = nullptr) {
-#if PGR_SORT_POS
-    return bucket_sort_tile_pos<THREADS, E, NB, KEYS>(lds, bucket, out, n, n_env, obj_last, pos_offset, tie);
-#else
-    return bucket_sort_tile<THREADS, E, NB, DIRECT, KEYS>(lds, bucket, out, n, n_env, obj_last, pos_offset, tie);
-#endif
-}
-
 // Lists beyond one LDS sort (> CAP keys): ONE counting-sort pass by coarse depth bucket through the alt buffer
 // (L2-resident), cut at the first bucket start at or after every multiple of CAP / 2 -- with no bucket larger than
 // CAP / 2 every segment holds < CAP keys, and all of its depths precede the next segment's -- then each segment is
@@ -1017,7 +831,7 @@ __device__ __forceinline__ bool partition_sort_long(unsigned char* __restrict__ 
         const uint32_t a = s_cut[g];
         if (a >= (uint32_t)n) break;
         const int n_seg = (int)(s_cut[g + 1] - a);
-        if (!sort_list_in_lds<THREADS, E, SORT_LARGE_BUCKETS, true, SORT_LARGE_KEYS>(lds, alt + a, out + a, n_seg, n_env, obj_last, a, tie))
+        if (!bucket_sort_tile<THREADS, E, SORT_LARGE_BUCKETS, SORT_LARGE_KEYS>(lds, alt + a, out + a, n_seg, n_env, obj_last, a, tie))
             merge_sort_tile<THREADS, E>(reinterpret_cast<uint64_t*>(lds), alt + a, out + a, n_seg, nullptr, n_env, obj_last, a,
                                         tie, inv);
         __syncthreads();
@@ -1082,13 +896,13 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* 
     const uint2* bucket; uint32_t* out; int n; ObjOut oo;
     sort_item(views, tiles, queue[blockIdx.x], bucket, out, n, oo);
     if (n <= SORT_THREADS * 2) {
-        if (!sort_list_in_lds<SORT_THREADS, 2>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+        if (!bucket_sort_tile<SORT_THREADS, 2>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
             merge_sort_tile<SORT_THREADS, 2>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
     } else if (n <= SORT_THREADS * 4) {
-        if (!sort_list_in_lds<SORT_THREADS, 4>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+        if (!bucket_sort_tile<SORT_THREADS, 4>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
             merge_sort_tile<SORT_THREADS, 4>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
     } else {
-        if (!sort_list_in_lds<SORT_THREADS, 8>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+        if (!bucket_sort_tile<SORT_THREADS, 8>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
             merge_sort_tile<SORT_THREADS, 8>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
     }
 }
@@ -1122,10 +936,10 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? PGR_T1_WAVES : 4)) void 
         sort_item(views, tiles, queue[k], bucket, out, n, oo, &alt);
         {
             if constexpr (!LAST) {
-                if (!sort_list_in_lds<THREADS, E>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+                if (!bucket_sort_tile<THREADS, E>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
                     merge_sort_tile<THREADS, E>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
             } else if (n <= SORT_LARGE_KEYS) {
-                if (!sort_list_in_lds<THREADS, E, SORT_LARGE_BUCKETS, true, SORT_LARGE_KEYS>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+                if (!bucket_sort_tile<THREADS, E, SORT_LARGE_BUCKETS, SORT_LARGE_KEYS>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
                     merge_sort_tile<THREADS, E>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
             } else if (partition_sort_long<THREADS, E>(lds, s_cut, bucket, reinterpret_cast<uint2*>(alt), out, n, oo.n_env,
                                                        oo.last, oo.tie, oo.inv)) {
