@@ -765,7 +765,10 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
     P = W * H
     with_masks = eng.with_masks
     stats = []
-    for i in range(args.profile_steps if args.profile_steps > 0 else min(4, args.steps)):   # N, V, I, evaluations
+    # N, V, I, evaluations: four batches spread EVENLY over the timed steps (the camera set is ordered by elevation: the first
+    # batches alone are the grazing views)
+    n_stat = args.profile_steps if args.profile_steps > 0 else min(4, args.steps)
+    for i in [(j * args.steps) // n_stat for j in range(n_stat)]:
         res = rasterizer.forward_views(fr.means3d, fr.opacities, eng.batch_views(args.warmup + i), shs=fr.shs, scales=fr.scales,
                                        rotations=fr.rotations, sh_degree=3, want_radii=True, want_aux=True)
         info = rasterizer.last_forward_info()

@@ -386,7 +386,9 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     tile_sort_long_kernel<1024, 16, true><<<std::min(items, 512), 1024, 0, stream>>>(
         bin_table, L.tiles, sort_queue + 3 * qs, n_queue + 3);
     if (!merge_long) {
-        tile_sort_long_kernel<1024, 8, false><<<std::min(items, 1024), 1024, 0, stream>>>(
+        // 4097..8192 keys: 512 threads x 16 keys over 3584 buckets = 80 KiB, TWO workgroups per CU (round 5: the position-owned
+        // ranking needs no index image, so the bucket count is free; 1024 x 8 over 8192 buckets = 96 KiB held a CU alone)
+        tile_sort_long_kernel<512, 16, false, SORT_T2_BUCKETS, 4><<<std::min(items, 2048), 512, 0, stream>>>(
             bin_table, L.tiles, sort_queue + 2 * qs, n_queue + 2);
         tile_sort_long_kernel<512, 8, false><<<std::min(items, 2048), 512, 0, stream>>>(
             bin_table, L.tiles, sort_queue + qs, n_queue + 1);

@@ -868,6 +868,10 @@ __device__ __forceinline__ void merge_round_global(const uint64_t* __restrict__ 
     }
 }
 
+// short tier (<= 2048 keys): at most 1024 buckets under the 2048-key image = 20.7 KiB, SEVEN workgroups per CU (one bucket
+// per key: 24.8 KiB, six per CU; C3 sort stage 0.0231 -> 0.0223 ms per view, profiles/r05_sort_tier_shapes_ab.txt)
+constexpr int SORT_SHORT_BUCKETS = 1024;
+constexpr int SORT_T2_BUCKETS = 3584;                   // 4097..8192-key tier: 7 x 512 buckets (8192 x 8 + 3584 x 4 + 256 B = 80 128 B)
 constexpr int SORT_SMALL_MAX = SORT_THREADS * 8;       // 2048 keys, 24 KiB of LDS: six workgroups per CU
 
 struct ObjOut { int n_env; uint32_t* last; const int32_t* tie; const uint32_t* inv; };
@@ -890,19 +894,23 @@ __device__ __forceinline__ void sort_item(const BinView* __restrict__ views, int
 __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* __restrict__ views, int tiles,
                                                                  const uint4* __restrict__ queue,
                                                                  const uint32_t* __restrict__ n_queue) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[SORT_THREADS * 8 * 12 + SORT_MISC_BYTES];
-    uint64_t* skeys = reinterpret_cast<uint64_t*>(lds);     // merge sort: SORT_THREADS * 9 keys fit as well
+    constexpr int NBS = SORT_SHORT_BUCKETS;     // at most one bucket per key of capacity
+    constexpr int NB2 = NBS < SORT_THREADS * 2 ? NBS : SORT_THREADS * 2, NB4 = NBS < SORT_THREADS * 4 ? NBS : SORT_THREADS * 4;
+    constexpr int NB8 = NBS < SORT_THREADS * 8 ? NBS : SORT_THREADS * 8;
+    static_assert(SORT_THREADS * 9 * 8 <= SORT_THREADS * 8 * 8 + NB8 * 4 + SORT_MISC_BYTES, "the merge sort's padded keys must fit");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[SORT_THREADS * 8 * 8 + NB8 * 4 + SORT_MISC_BYTES];
+    uint64_t* skeys = reinterpret_cast<uint64_t*>(lds);
     if (blockIdx.x >= *n_queue) return;
     const uint2* bucket; uint32_t* out; int n; ObjOut oo;
     sort_item(views, tiles, queue[blockIdx.x], bucket, out, n, oo);
     if (n <= SORT_THREADS * 2) {
-        if (!bucket_sort_tile<SORT_THREADS, 2>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+        if (!bucket_sort_tile<SORT_THREADS, 2, NB2>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
             merge_sort_tile<SORT_THREADS, 2>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
     } else if (n <= SORT_THREADS * 4) {
-        if (!bucket_sort_tile<SORT_THREADS, 4>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+        if (!bucket_sort_tile<SORT_THREADS, 4, NB4>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
             merge_sort_tile<SORT_THREADS, 4>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
     } else {
-        if (!bucket_sort_tile<SORT_THREADS, 8>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+        if (!bucket_sort_tile<SORT_THREADS, 8, NB8>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
             merge_sort_tile<SORT_THREADS, 8>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
     }
 }
@@ -911,21 +919,23 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* 
 #define PGR_T1_WAVES 6      // the 512-thread tier: three workgroups per CU (48 KiB of LDS each) need six waves per SIMD
 #endif
 // Lists longer than 2048: workgroups stride over the queue of their tier.  One launch per tier (THREADS, E):
-//   (512, 8)    2049..4096 keys, 48 KiB of LDS: three workgroups per CU;
-//   (1024, 8)   4097..8192 keys, one bucket per key (96 KiB image): one per CU;
-//   (1024, 16)  LAST, open-ended: 8193..16384 keys with 4096 buckets (144 KiB, sorted indices stored straight to global
-//               memory), anything longer depth-partitioned into LDS-sized segments or, failing that, merge-sorted
-//               16384-key chunks merged through L2 between the list and its alt buffer.
+//   (512, 8)    2049..4096 keys, one bucket per key, 48 KiB of LDS: three workgroups per CU;
+//   (512, 16)   4097..8192 keys over SORT_T2_BUCKETS = 3584 buckets, 80 KiB: two per CU (round 5; rounds 2-4 used 1024 x 8
+//               with one bucket per key, 96 KiB, one per CU: C3 sort stage 0.0237 -> 0.0229 ms per view, C5 0.0744 ->
+//               0.0708, profiles/r05_sort_tier_shapes_ab.txt; the same treatment of the 2049..4096 tier returned nothing);
+//   (1024, 16)  LAST, open-ended: 8193..16000 keys over 8192 buckets (157 KiB), anything longer depth-partitioned into
+//               LDS-sized segments or, failing that, merge-sorted 16384-key chunks merged through L2 between the list
+//               and its alt buffer.
 // A kernel per tier keeps each one's register budget its own: with the open-ended tier's code in the same kernel the
 // 4097..8192 path (a quarter of C3's keys) ran out of the 128 VGPRs a 1024-thread workgroup gets and spilled.
-template <int THREADS, int E, bool LAST>
-__global__ __launch_bounds__(THREADS, (THREADS == 512 ? PGR_T1_WAVES : 4)) void tile_sort_long_kernel(const BinView* __restrict__ views, int tiles,
+template <int THREADS, int E, bool LAST, int NB = THREADS * E, int MIN_WAVES = (THREADS == 512 ? PGR_T1_WAVES : 4)>
+__global__ __launch_bounds__(THREADS, MIN_WAVES) void tile_sort_long_kernel(const BinView* __restrict__ views, int tiles,
                                                                  const uint4* __restrict__ queue,
                                                                  const uint32_t* __restrict__ n_queue) {
     constexpr int CAP = THREADS * E;
     static_assert(!LAST || CAP == SORT_LARGE_MAX, "the open-ended tier");
-    // bucket sort image: 12 B per key, or (last tier) keys + 4096 counters = 144 KiB; the merge sort's padded keys fit
-    constexpr size_t LDS_BYTES = LAST ? (size_t)SORT_LARGE_KEYS * 8 + SORT_LARGE_BUCKETS * 4 + SORT_MISC_BYTES : (size_t)CAP * 12 + SORT_MISC_BYTES;
+    // bucket sort image: 8 B per key + 4 B per bucket, or (last tier) keys + 8192 counters = 157 KiB; the merge sort's padded keys fit
+    constexpr size_t LDS_BYTES = LAST ? (size_t)SORT_LARGE_KEYS * 8 + SORT_LARGE_BUCKETS * 4 + SORT_MISC_BYTES : (size_t)CAP * 8 + (size_t)NB * 4 + SORT_MISC_BYTES;
     static_assert((size_t)THREADS * (E + 1) * 8 <= LDS_BYTES && LDS_BYTES <= 160 * 1024, "lds");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     __shared__ uint32_t s_cut[LAST ? PART_MAX_SEGMENTS + 3 : 1];
@@ -936,7 +946,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? PGR_T1_WAVES : 4)) void 
         sort_item(views, tiles, queue[k], bucket, out, n, oo, &alt);
         {
             if constexpr (!LAST) {
-                if (!bucket_sort_tile<THREADS, E>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
+                if (!bucket_sort_tile<THREADS, E, NB>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))
                     merge_sort_tile<THREADS, E>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, 0u, oo.tie, oo.inv);
             } else if (n <= SORT_LARGE_KEYS) {
                 if (!bucket_sort_tile<THREADS, E, SORT_LARGE_BUCKETS, SORT_LARGE_KEYS>(lds, bucket, out, n, oo.n_env, oo.last, 0u, oo.tie))

@@ -16,7 +16,8 @@ for a in "$@"; do
 done
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-BENCH_FLAGS="--steps 3 --warmup 1 --no-cpu-baseline --no-drop-in --profile-steps 1 --sync-steps $*"
+# (all 16 batches of the 512 cameras: the set is ordered by elevation, three batches would be the grazing views only)
+BENCH_FLAGS="--steps 16 --warmup 1 --repeats 1 --no-cpu-baseline --no-drop-in --profile-steps 1 --sync-steps $*"
 GROUPS_=("FETCH_SIZE" "WRITE_SIZE" "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"
          "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE")
 dbs=()
