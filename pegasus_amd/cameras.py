@@ -48,12 +48,15 @@ class Camera(nn.Module):
         self.trans = trans
         self.scale = scale
         dev = self.data_device
-        self.world_view_transform = torch.tensor(G.getWorld2View2(R, T, trans, scale)).transpose(0, 1).to(dev)
+        # Same values as upstream's Camera; the transposes are made CONTIGUOUS here, once, on the host: upstream keeps
+        # `.transpose(0, 1)` views, whose inverse is column-major too, so every render() of a camera paid two device copy
+        # kernels (view matrix, camera centre) to hand the rasterizer contiguous memory.
+        self.world_view_transform = torch.tensor(G.getWorld2View2(R, T, trans, scale)).transpose(0, 1).contiguous().to(dev)
         self.projection_matrix = torch.tensor(
-            G.getProjectionMatrix(self.znear, self.zfar, self.FoVx, self.FoVy)).transpose(0, 1).to(dev)
+            G.getProjectionMatrix(self.znear, self.zfar, self.FoVx, self.FoVy)).transpose(0, 1).contiguous().to(dev)
         self.full_proj_transform = (self.world_view_transform.unsqueeze(0).bmm(
             self.projection_matrix.unsqueeze(0))).squeeze(0)
-        self.camera_center = self.world_view_transform.inverse()[3, :3]
+        self.camera_center = self.world_view_transform.inverse()[3, :3].contiguous()
 
 
 class MiniCam:

@@ -17,10 +17,13 @@ oracle.build()
 n3 = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n5 = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 bad = 0
-for name, maker, nv in (("C3", lambda n: scenes.scene_c3(n_views=n), n3), ("C5", lambda n: scenes.scene_c5(n_views=n), n5)):
+# cameras spread over each config's own set (512 / 200 Fibonacci hemisphere views, ordered by elevation: the first ones alone
+# would be the grazing views), the lowest one included
+for name, maker, total, nv in (("C3", lambda n: scenes.scene_c3(n_views=n), 512, n3), ("C5", lambda n: scenes.scene_c5(n_views=n), 200, n5)):
     if nv <= 0:
         continue
-    cloud, views = maker(max(nv, 4))
+    cloud, all_views = maker(total)
+    views = [all_views[(k * (total - 1)) // max(nv - 1, 1)] for k in range(nv)]
     act = cloud.activated()
     fr = FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"], cloud.object_id, device="cuda:0")
     act_r = {k: np.ascontiguousarray(a[fr.order]) for k, a in act.items()}

@@ -1,0 +1,41 @@
+#!/bin/bash
+# Round-5 evidence run (GPU box): tests, counter passes, bench lines, kernel traces -> gpurun_out/r05_*
+cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set}"
+mkdir -p gpurun_out
+P=gpurun_out/r05
+python -m pytest tests -m gpu -q 2>&1 | tail -5 > ${P}_pytest_gpu.txt
+# counters first: bench.py reads profiles/pmc.json, so the lines below carry THIS code's traffic / issue numbers
+bash scripts/pmc_profile.sh r05_pmc > ${P}_pmc.log 2>&1
+cp gpurun_out/r05_pmc.json profiles/pmc.json
+python bench.py > ${P}_bench_default.json 2> ${P}_bench_default.err
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > ${P}_bench_steps20_warmup5.json 2>/dev/null
+python bench.py --data-points all --no-cpu-baseline --no-drop-in > ${P}_bench_all_data_points.json 2>/dev/null
+python bench.py --workload c5 --dynamic --views 200 --no-drop-in > ${P}_bench_c5_dynamic.json 2>/dev/null
+python bench.py --workload c5 --views 200 --no-drop-in --no-cpu-baseline > ${P}_bench_c5_static.json 2>/dev/null
+python bench.py --dynamic --no-drop-in --no-cpu-baseline > ${P}_bench_c3_dynamic.json 2>/dev/null
+python bench.py --workload c2 --views 64 --no-drop-in --no-cpu-baseline > ${P}_bench_c2.json 2>/dev/null
+python bench.py --views 4096 --steps 128 --repeats 3 --no-drop-in --no-cpu-baseline > ${P}_bench_c4_4096views_1gpu.json 2>/dev/null
+python bench.py --workload c5 --dynamic --views 200 --batch 40 --steps 5 --no-drop-in --no-cpu-baseline > ${P}_bench_c5_dynamic_200steps_1gpu.json 2>/dev/null
+python bench.py --facade > ${P}_bench_facade.json 2>/dev/null
+python bench.py --width 640 --height 480 --objects 6 --data-points all --no-cpu-baseline > ${P}_bench_ref_default_640x480.json 2>/dev/null
+python bench.py --gpus 2 --share-devices --backend gloo --steps 6 --warmup 2 --no-drop-in > ${P}_bench_rehearsal_2ranks_1gpu.json 2>/dev/null
+python bench.py --force-dist --backend nccl --no-drop-in --no-cpu-baseline > ${P}_bench_rccl_1rank_forced.json 2>/dev/null
+python bench.py --force-dist --backend nccl --records pack --no-drop-in --no-cpu-baseline > ${P}_bench_rccl_1rank_forced_pack.json 2>/dev/null
+bash scripts/trace_run.sh r05 --no-drop-in > /dev/null 2>&1
+bash scripts/trace_run.sh r05_sync --no-drop-in --sync-steps > /dev/null 2>&1
+bash scripts/trace_run.sh r05_c5_sync --no-drop-in --sync-steps --workload c5 --views 200 > /dev/null 2>&1
+bash scripts/single_view_trace.sh r05 40 c3 > /dev/null 2>&1
+python scripts/silhouette_time.py 2>&1 | grep -v amdgpu.ids > ${P}_silhouette_time.txt
+( python scripts/fuzz_parity.py 90000 1500 2>&1 | tail -1; python scripts/fuzz_fused.py 5000 200 2>&1 | tail -1; python scripts/fuzz_layered.py 3000 100 2>&1 | tail -1
+  python scripts/soak_determinism.py 4 c3 2>&1 | tail -1; python scripts/full_size_parity.py 2>&1 | tail -1 ) | grep -v amdgpu.ids > ${P}_verification.txt
+for f in ${P}_bench_*.json; do python - "$f" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    r = d.get("roofline") or {}
+    print(sys.argv[1], d.get("value"), d.get("value_min"), d.get("value_max"), r.get("stage_ms_per_view"), r.get("bound"), r.get("frac"), r.get("hbm_frac"))
+except Exception as e:
+    print(sys.argv[1], "unreadable:", e)
+PY
+done
+cat ${P}_pytest_gpu.txt ${P}_silhouette_time.txt ${P}_verification.txt
