@@ -129,7 +129,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                        ws.numel(), max_inst, C.byref(need), stream)
                 if status != _lib.PGR_ERR_INSTANCE_OVERFLOW:
                     break
-                max_inst = rasterizer._grown_capacity(need.value, 1.25)
+                max_inst = rasterizer.grown_capacity(need.value, 1.25)
             _lib.check(status, "pgr_forward")
         ctx.rs, ctx.max_inst, ctx.n = rs, max_inst, n
         # non-tensor state stays on ctx; tensors (inputs as the kernels read them + the forward's own buffers) are saved

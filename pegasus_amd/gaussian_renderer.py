@@ -44,7 +44,9 @@ def invalidate_activations(pc=None) -> None:
         _SLOTS.pop(pc, None)
 
 
-def _kept(pc, getter: str):
+def kept_activation(pc, getter: str):
+    """``getattr(pc, getter)`` (get_opacity / get_scaling / get_rotation / get_features), kept between calls while the raw
+    tensors behind it are unchanged (inference only; see the comment above)."""
     sources = [getattr(pc, name, None) for name in _SOURCES[getter]]
     if torch.is_grad_enabled() or not all(isinstance(t, torch.Tensor) for t in sources):
         return getattr(pc, getter)
@@ -93,7 +95,7 @@ def _geometry(pc, pipe, scaling_modifier) -> dict:
     """Either the model's own 3D covariances (pipe.compute_cov3D_python) or scale + rotation for the kernel to combine."""
     if getattr(pipe, "compute_cov3D_python", False):
         return dict(cov3D_precomp=pc.get_covariance(scaling_modifier))
-    return dict(scales=_kept(pc, "get_scaling"), rotations=_kept(pc, "get_rotation"))
+    return dict(scales=kept_activation(pc, "get_scaling"), rotations=kept_activation(pc, "get_rotation"))
 
 
 def _colour(pc, pipe, cam, override_color) -> dict:
@@ -102,7 +104,7 @@ def _colour(pc, pipe, cam, override_color) -> dict:
     if override_color is not None:
         return dict(colors_precomp=override_color)
     if not getattr(pipe, "convert_SHs_python", False):
-        return dict(shs=_kept(pc, "get_features"))
+        return dict(shs=kept_activation(pc, "get_features"))
     coeff = pc.get_features                                        # [N, (max_deg+1)^2, 3]
     towards = torch.nn.functional.normalize(pc.get_xyz - cam.camera_center.reshape(1, 3), dim=1)
     basis = sh_basis(pc.active_sh_degree, towards)                 # [N, (deg+1)^2]
@@ -126,7 +128,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
             _ZERO_PROBES.clear()                                   # (one scene shape at a time: a merged scene grows per object)
             probe = _ZERO_PROBES[pkey] = torch.zeros_like(xyz)
     settings = _view(viewpoint_camera, pc, pipe, bg_color, scaling_modifier)
-    inputs = dict(means3D=xyz, means2D=probe, opacities=_kept(pc, "get_opacity"),
+    inputs = dict(means3D=xyz, means2D=probe, opacities=kept_activation(pc, "get_opacity"),
                   **_colour(pc, pipe, viewpoint_camera, override_color), **_geometry(pc, pipe, scaling_modifier))
     if torch.is_grad_enabled():
         image, radii, depth = GaussianRasterizer(raster_settings=settings)(**inputs)

@@ -62,7 +62,7 @@ _LAST_INFO: dict = {}
 MAX_INSTANCES = 0x7FFFFFFF      # per view: list positions are 32-bit (include/pegasus_raster.h)
 
 
-def _grown_capacity(need: int, factor: float) -> int:
+def grown_capacity(need: int, factor: float) -> int:
     """Instance capacity for a retry after PGR_ERR_INSTANCE_OVERFLOW.  The device reports the count saturated at
     2^32 - 1; a view that needs more than MAX_INSTANCES list entries cannot be rendered and the retry gives up."""
     if need > MAX_INSTANCES:
@@ -144,7 +144,7 @@ class PendingBatch:
             self.num_instances = [int(x) for x in need]
             peak = max(self.num_instances)
             if peak > 0.8 * self._max_inst and peak <= MAX_INSTANCES:
-                _WS.capacity_hint[self._key] = max(_WS.capacity_hint.get(self._key, 0), _grown_capacity(peak, 1.6))   # few, large steps:
+                _WS.capacity_hint[self._key] = max(_WS.capacity_hint.get(self._key, 0), grown_capacity(peak, 1.6))   # few, large steps:
                 # every growth reallocates the multi-GB workspace (tens of ms)
             self._event = None
             if self.record_info and status != _lib.PGR_ERR_INSTANCE_OVERFLOW:
@@ -155,7 +155,7 @@ class PendingBatch:
                                   height=int(self._key[3]), n_views=self._nv, workspace=ws, workspace_bytes=int(ws.numel()))
             if status == _lib.PGR_ERR_INSTANCE_OVERFLOW:
                 self._was_redone = True
-                _WS.capacity_hint[self._key] = max(_WS.capacity_hint.get(self._key, 0), _grown_capacity(peak, 1.6))   # raises beyond MAX_INSTANCES
+                _WS.capacity_hint[self._key] = max(_WS.capacity_hint.get(self._key, 0), grown_capacity(peak, 1.6))   # raises beyond MAX_INSTANCES
                 self.results = self._redo()          # synchronous path grows the workspace and retries
             else:
                 _lib.check(status, "pgr_forward_batch_async")
@@ -295,7 +295,7 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
                                       used_max_instances=int(pb._max_inst), n=n, width=W, height=H, n_views=nv,
                                       workspace=pb._keep[1], workspace_bytes=int(pb._keep[1].numel()))
                     return results
-                _WS.capacity_hint[key] = _grown_capacity(max(need), 1.6)
+                _WS.capacity_hint[key] = grown_capacity(max(need), 1.6)
             raise RuntimeError("instance capacity did not converge")
     if async_slot is not None:
         with torch.cuda.device(device):
@@ -327,7 +327,7 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
         if layers is not None:          # a layered call is asynchronous only: the retry after an overflow is one too
             def redo():
                 # bounded like the fused path: every attempt runs at the capacity the device asked for (a view that needs
-                # more than MAX_INSTANCES raises from _grown_capacity instead of overflowing for ever)
+                # more than MAX_INSTANCES raises from grown_capacity instead of overflowing for ever)
                 for _attempt in range(3):
                     pb2 = forward_views(means3D_in, opacities_in, views, async_slot=async_slot, layers=layers, **kw)
                     pb2._redo = None
@@ -337,7 +337,7 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
                     if status2 != _lib.PGR_ERR_INSTANCE_OVERFLOW:
                         _lib.check(status2, "pgr_forward_layers_async")
                         return pb2.results
-                    _WS.capacity_hint[key] = _grown_capacity(max(need2), 1.6)
+                    _WS.capacity_hint[key] = grown_capacity(max(need2), 1.6)
                 raise RuntimeError("instance capacity did not converge")
         else:
             redo = lambda: forward_views(means3D_in, opacities_in, views, **kw)
@@ -361,12 +361,12 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
                                              max_inst, need, stream)
             if status != _lib.PGR_ERR_INSTANCE_OVERFLOW:
                 break
-            max_inst = _grown_capacity(max(need), 1.25)   # grow to what the largest view needs, then retry
+            max_inst = grown_capacity(max(need), 1.25)   # grow to what the largest view needs, then retry
         _lib.check(status, "pgr_forward_batch")
     used_max_inst = max_inst
     peak = max(need) if nv else 0
     if peak > 0.8 * max_inst:
-        max_inst = _grown_capacity(peak, 1.6)
+        max_inst = grown_capacity(peak, 1.6)
     _WS.capacity_hint[key] = max_inst
     if stage_ms is not None:
         stage_ms[:] = list(ms)

@@ -57,7 +57,7 @@ def render_silhouette_mask(cam, gs_object_list, gs_env, width, height, color_set
         return _render_silhouette_mask_per_object(cam, gs_object_list, gs_env, width, height, color_set, pipe_settings, bg)
     import math
     from . import rasterizer as R
-    from .gaussian_renderer import _kept
+    from .gaussian_renderer import kept_activation as _kept
     scene, key = _semantic_scene(gs_env, gs_object_list)
     dev = scene._xyz.device
     K = int(color_set.shape[0])

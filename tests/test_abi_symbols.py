@@ -140,3 +140,25 @@ def test_new_entry_points_validate_before_any_launch():
     assert lib.pgr_scene_prepare(C.byref(sc), None, fake, 1 << 20, None, C.byref(p2), None) == _lib.PGR_ERR_INVALID_ARGUMENT
     empty = _lib.PgrScene(n=0)
     assert lib.pgr_scene_prepare(C.byref(empty), None, None, 0, C.byref(p1), C.byref(p2), None) == 0 and not p1.value and not p2.value
+
+
+def test_stale_or_foreign_library_is_named_not_crashed_on(tmp_path):
+    """PGR_LIB pointing at a library of another ABI version (a stale build, a variant built from old sources) or at a
+    library that is not this one at all: the loader checks pgr_abi_version FIRST and raises RasterizerLibraryError naming
+    the file, instead of an AttributeError on whichever newer entry point the file lacks (round-4 advisor finding)."""
+    import subprocess
+    import sys
+    old = tmp_path / "old.c"
+    old.write_text("int pgr_abi_version(void) { return 1; }\nconst char* pgr_version(void) { return \"old\"; }\n")
+    foreign = tmp_path / "foreign.c"
+    foreign.write_text("int something_else(void) { return 0; }\n")
+    for src, needle in ((old, "ABI version 1"), (foreign, "pgr_abi_version")):
+        so = src.with_suffix(".so")
+        subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+        code = ("import sys; sys.path.insert(0, %r)\n"
+                "from pegasus_amd import _lib\n"
+                "try:\n    _lib.lib()\nexcept _lib.RasterizerLibraryError as e:\n    print('RLE:', e)\n" % str(ROOT))
+        out = subprocess.run([sys.executable, "-c", code], env={**__import__("os").environ, "PGR_LIB": str(so)},
+                             capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert "RLE:" in out.stdout and needle in out.stdout and str(so) in out.stdout, out.stdout + out.stderr

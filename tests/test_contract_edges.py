@@ -10,12 +10,12 @@ from pegasus_amd import scenes
 
 def test_capacity_growth_gives_up_beyond_the_per_view_limit():
     from pegasus_amd import rasterizer as R
-    assert R._grown_capacity(1_000_000, 1.25) == 1_251_024
-    assert R._grown_capacity(R.MAX_INSTANCES, 1.6) == R.MAX_INSTANCES           # clamped, still renderable
+    assert R.grown_capacity(1_000_000, 1.25) == 1_251_024
+    assert R.grown_capacity(R.MAX_INSTANCES, 1.6) == R.MAX_INSTANCES           # clamped, still renderable
     with pytest.raises(RuntimeError, match="per-view limit"):
-        R._grown_capacity(R.MAX_INSTANCES + 1, 1.25)
+        R.grown_capacity(R.MAX_INSTANCES + 1, 1.25)
     with pytest.raises(RuntimeError, match=">= 4294967295"):                       # the device's saturated count
-        R._grown_capacity(0xFFFFFFFF, 1.25)
+        R.grown_capacity(0xFFFFFFFF, 1.25)
 
 
 @pytest.mark.gpu
