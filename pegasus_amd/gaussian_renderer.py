@@ -125,7 +125,8 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         pkey = (tuple(xyz.shape), xyz.dtype, xyz.device)
         probe = _ZERO_PROBES.get(pkey)
         if probe is None:
-            _ZERO_PROBES.clear()                                   # (one scene shape at a time: a merged scene grows per object)
+            if len(_ZERO_PROBES) >= 4:                             # PEGASUS alternates between the merged scene and the objects-only
+                _ZERO_PROBES.pop(next(iter(_ZERO_PROBES)))         # scene: a few shapes stay, the oldest goes
             probe = _ZERO_PROBES[pkey] = torch.zeros_like(xyz)
     settings = _view(viewpoint_camera, pc, pipe, bg_color, scaling_modifier)
     inputs = dict(means3D=xyz, means2D=probe, opacities=kept_activation(pc, "get_opacity"),

@@ -894,3 +894,39 @@ def test_tiny_and_ragged_images_through_the_round4_outputs(gpu_device, size):
         got_v, want_v = M.record_views(f["records"], H, W, fr.K), M.record_views(want, H, W, fr.K)
         assert all(torch.equal(got_v[k], want_v[k]) for k in ("rgb", "depth_mm", "mask_bits"))
         assert all(torch.equal(f[k], ref[k]) for k in ("color", "depth", "seg", "masks"))
+
+
+@pytest.mark.parametrize("n", [1, 2, 512, 513, 1024, 1025, 2048, 2049, 4096, 4097, 8192, 8193, 16000, 16001, 16384, 16385])
+def test_sort_tier_boundaries(oracle, gpu_device, n):
+    """ONE tile list of exactly n keys, n on both sides of every capacity edge of the per-tile sort (256 x 2 / 4 / 8 keys,
+    512 x 8, 512 x 16 over 3584 buckets, the 16 000-key LDS image of the open-ended tier, 16 384 = its register capacity):
+    n pinpoint splats inside one tile, a third of them at exactly equal depth.  As a one-view call (every long list goes to
+    the open-ended tier's kernel) and as a three-view batch (one kernel per tier): the list bit-exact against the oracle."""
+    import torch
+    from helpers import fetch_workspace
+    from pegasus_amd import rasterizer as R
+    rng = np.random.default_rng(n)
+    cloud, views = scenes.scene_c1(seed=9, n=n)
+    cloud.xyz[:, 0] = np.float32(0.0929) + rng.normal(0, 5e-4, n).astype(np.float32)       # 8.5 px off the image centre:
+    cloud.xyz[:, 1] = np.float32(0.0929) + rng.normal(0, 5e-4, n).astype(np.float32)       # the middle of a tile
+    cloud.xyz[:, 2] = rng.normal(0, 0.2, n).astype(np.float32)
+    cloud.xyz[: n // 3, 2] = np.float32(0.125)                                             # exact depth ties
+    cloud.scaling[:] = np.log(0.0005).astype(np.float32)
+    cloud.opacity[:] = rng.normal(-3.0, 0.5, size=(n, 1)).astype(np.float32)
+    act, v = cloud.activated(), views[0]
+    o = oracle.forward(**act, sh_degree=3, **v.raster_kwargs(), num_threads=8, cull_mode=1)
+    lens = o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]
+    assert lens.max() == n and (lens > 0).sum() == 1, (lens.max(), (lens > 0).sum())
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(gpu_device)
+    spec = R.ViewSpec(v.height, v.width, v.tanfovx, v.tanfovy, t(np.zeros(3)), t(v.world_view_transform),
+                      t(v.full_proj_transform), t(v.camera_center))
+    T = {k: t(a) for k, a in act.items()}
+    for n_views in (1, 3):
+        res = R.forward_views(T["means3d"], T["opacities"], [spec] * n_views, shs=T["shs"], scales=T["scales"],
+                              rotations=T["rotations"], sh_degree=3, want_radii=True, want_aux=True)
+        torch.cuda.synchronize()
+        for k in range(n_views):
+            w = fetch_workspace(k, n, v.width, v.height)
+            np.testing.assert_array_equal(w["gauss_sorted"], o["gauss_sorted"], err_msg=f"{n_views} views, view {k}")
+            np.testing.assert_array_equal(res[k]["n_contrib"].cpu().numpy().astype(np.uint32)[~o["ambig"].astype(bool)],
+                                          o["n_contrib"][~o["ambig"].astype(bool)])
