@@ -162,3 +162,53 @@ def test_stale_or_foreign_library_is_named_not_crashed_on(tmp_path):
                              capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stderr
         assert "RLE:" in out.stdout and needle in out.stdout and str(so) in out.stdout, out.stdout + out.stderr
+
+
+def test_header_is_plain_c_and_the_library_links_from_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/pegasus_raster.h compiles as C11 (gcc -std=c11 -Wall -Werror -pedantic) and
+    a C program linked against libpegasus_raster.so calls the host-only entry points -- version, status strings, workspace
+    sizes, the frame-record layout, and an argument check that returns before any device is touched -- and agrees with the
+    ctypes binding.  (The struct sizes it prints are the ones pegasus_amd/_lib.py declares.)"""
+    import subprocess
+    from pegasus_amd import _lib, build
+    build.build()
+    src = tmp_path / "abi_probe.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "pegasus_raster.h"
+int main(void) {
+    PgrRecordLayout lay;
+    PgrScene scene = {0};
+    PgrCamera cam = {0};
+    PgrOutputs out = {0};
+    int64_t need = -1;
+    scene.n = 10;                               /* no pointers: must be rejected on the host */
+    cam.image_width = 64; cam.image_height = 64; cam.tanfovx = 0.5f; cam.tanfovy = 0.5f;
+    printf("abi %d\n", (int)pgr_abi_version());
+    printf("version %s\n", pgr_version());
+    printf("status %s\n", pgr_status_string(PGR_ERR_INSTANCE_OVERFLOW));
+    printf("ws %zu\n", pgr_batch_workspace_bytes(100000, 800, 800, 1 << 20, 8));
+    printf("layout_rc %d\n", (int)pgr_frame_record_layout(800, 800, 8, &lay));
+    printf("record %lld %lld %lld\n", (long long)lay.off_depth, (long long)lay.off_masks, (long long)lay.bytes);
+    printf("forward_rc %d\n", (int)pgr_forward(&scene, &cam, &out, NULL, 0, 100, &need, NULL));
+    printf("sizes %zu %zu %zu %zu %zu %zu\n", sizeof(PgrScene), sizeof(PgrCamera), sizeof(PgrOutputs), sizeof(PgrSemantic),
+           sizeof(PgrLayers), sizeof(PgrPosedObjects));
+    return 0;
+}
+''')
+    exe = tmp_path / "abi_probe"
+    lib_dir = str(_lib.LIB_PATH.parent)
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-pedantic", f"-I{ROOT / 'include'}", str(src), "-o", str(exe),
+                    f"-L{lib_dir}", "-lpegasus_raster", f"-Wl,-rpath,{lib_dir}"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120, check=True).stdout.splitlines()
+    got = dict(l.split(" ", 1) for l in out)
+    lib = _lib.lib()
+    assert got["abi"] == str(_lib.PGR_ABI_VERSION) and got["version"] == lib.pgr_version().decode()
+    assert got["status"] == "instance buffer overflow"
+    assert int(got["ws"]) == lib.pgr_batch_workspace_bytes(100000, 800, 800, 1 << 20, 8)
+    assert got["layout_rc"] == "0" and got["record"] == "1920000 3200000 3840000"
+    assert int(got["forward_rc"]) == _lib.PGR_ERR_INVALID_ARGUMENT
+    sizes = [int(x) for x in got["sizes"].split()]
+    assert sizes == [C.sizeof(t) for t in (_lib.PgrScene, _lib.PgrCamera, _lib.PgrOutputs, _lib.PgrSemantic, _lib.PgrLayers,
+                                           _lib.PgrPosedObjects)]
