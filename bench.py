@@ -835,12 +835,14 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
     # scripts/pmc_profile.sh -> scripts/pmc_report.py as ONE file, so the numbers here and the committed text summary
     # cannot diverge
     try:
-        pmc = json.loads((ROOT / "profiles" / "pmc.json").read_text())
+        # (profiles/pmc.json = the C3 profile; other workloads: profiles/pmc_<workload>.json when one is on file)
+        pmc_file = ROOT / "profiles" / ("pmc.json" if args.workload == "c3" else f"pmc_{args.workload}.json")
+        pmc = json.loads(pmc_file.read_text())
         kern = pmc["stage_kernel"].get(dom_name)
         k = pmc["kernels"].get(kern) if kern else None
         fused_default = with_masks and not args.separate_semantic
         if (k and pmc.get("workload") == args.workload and pmc.get("batch") == B and pmc.get("fused") == fused_default
-                and (W, H) == (800, 800) and not args.objects and args.scale == 1.0):
+                and (W, H) == (800, 800) and not args.objects and args.scale == 1.0 and not args.dynamic):
             roofline["traffic"] = int(k["traffic_bytes_per_launch"])
             roofline["traffic_detail"] = {kk: k[kk] for kk in ("kernel", "dispatches", "fetch_size_kib_per_launch",
                                                                "write_size_kib_per_launch") if kk in k}
@@ -886,6 +888,9 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
                                   "x frames/s = vector wave-instructions issued per second, against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"}
     except (OSError, ValueError, KeyError):
         pass
+    if "bound_by_counters" not in roofline:
+        roofline["bound_note"] = ("no counter profile on file for this workload / shape: `bound` is the formula's HBM figure only; on the "
+                                  "profiled configs (profiles/pmc*.json) this kernel is vector-issue bound, not bandwidth bound")
 
     # the two side legs must not be able to lose the headline: a failure in one of them is recorded in its place
     def side_leg(fn, *a, **kw):
