@@ -252,6 +252,19 @@ def test_c5_view_matches_oracle(oracle, gpu_device):
     g = dict(color=res[0]["color"].cpu().numpy(), out_depth=res[0]["depth"].cpu().numpy(),
              final_T=res[0]["final_T"].cpu().numpy(), n_contrib=res[0]["n_contrib"].cpu().numpy())
     assert_images_match(g, o)
+    # ... and against the oracle's REFERENCE-STYLE lists (every tile of the 3-sigma rectangle, what the reference's rasterizer
+    # emits): radii, images and every pixel's last blended Gaussian
+    from test_gpu_parity import _last_blended
+    o0 = oracle.forward(**act_r, sh_degree=3, **v.raster_kwargs(), num_threads=8, cull_mode=0, tie_index=fr.order)
+    assert o0["num_instances"] > 1.3 * o["num_instances"]
+    np.testing.assert_array_equal(res[0]["radii"].cpu().numpy(), o0["radii"])
+    amb = o0["ambig"].astype(bool)
+    assert amb.mean() <= 5e-4
+    assert np.abs(g["color"] - o0["color"])[:, ~amb].max() <= 1e-4
+    assert np.abs(g["out_depth"] - o0["out_depth"])[:, ~amb].max() <= 1e-4
+    lg = _last_blended(w["gauss_sorted"], w["ranges"], g["n_contrib"], v.width, v.height)
+    lo = _last_blended(o0["gauss_sorted"], o0["ranges"], o0["n_contrib"], v.width, v.height)
+    np.testing.assert_array_equal(lg[~amb], lo[~amb])
     del fr
     torch.cuda.empty_cache()
 
