@@ -448,7 +448,7 @@ using namespace pgr;
 extern "C" {
 
 int32_t pgr_abi_version(void) { return PGR_ABI_VERSION; }
-const char* pgr_version(void) { return "pegasus_raster 0.7 (gfx950)"; }
+const char* pgr_version(void) { return "pegasus_raster 0.8 (gfx950)"; }
 
 const char* pgr_status_string(int32_t status) {
     switch (status) {
