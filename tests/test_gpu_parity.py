@@ -896,12 +896,15 @@ def test_tiny_and_ragged_images_through_the_round4_outputs(gpu_device, size):
         assert all(torch.equal(f[k], ref[k]) for k in ("color", "depth", "seg", "masks"))
 
 
+@pytest.mark.parametrize("ties", [True, False])
 @pytest.mark.parametrize("n", [1, 2, 512, 513, 1024, 1025, 2048, 2049, 4096, 4097, 8192, 8193, 16000, 16001, 16384, 16385])
-def test_sort_tier_boundaries(oracle, gpu_device, n):
+def test_sort_tier_boundaries(oracle, gpu_device, n, ties):
     """ONE tile list of exactly n keys, n on both sides of every capacity edge of the per-tile sort (256 x 2 / 4 / 8 keys,
     512 x 8, 512 x 16 over 3584 buckets, the 16 000-key LDS image of the open-ended tier, 16 384 = its register capacity):
-    n pinpoint splats inside one tile, a third of them at exactly equal depth.  As a one-view call (every long list goes to
-    the open-ended tier's kernel) and as a three-view batch (one kernel per tier): the list bit-exact against the oracle."""
+    n pinpoint splats inside one tile -- with a third of them at exactly equal depth (`ties`: the pile-up rejects the bucket
+    sort, so every tier's merge-sort fallback and the index tie-break run) or all depths distinct (the bucket sort itself at
+    exactly its capacity).  As a one-view call (every long list goes to the open-ended tier's kernel) and as a three-view
+    batch (one kernel per tier): the list bit-exact against the oracle."""
     import torch
     from helpers import fetch_workspace
     from pegasus_amd import rasterizer as R
@@ -910,7 +913,8 @@ def test_sort_tier_boundaries(oracle, gpu_device, n):
     cloud.xyz[:, 0] = np.float32(0.0929) + rng.normal(0, 5e-4, n).astype(np.float32)       # 8.5 px off the image centre:
     cloud.xyz[:, 1] = np.float32(0.0929) + rng.normal(0, 5e-4, n).astype(np.float32)       # the middle of a tile
     cloud.xyz[:, 2] = rng.normal(0, 0.2, n).astype(np.float32)
-    cloud.xyz[: n // 3, 2] = np.float32(0.125)                                             # exact depth ties
+    if ties:
+        cloud.xyz[: n // 3, 2] = np.float32(0.125)                                         # exact depth ties
     cloud.scaling[:] = np.log(0.0005).astype(np.float32)
     cloud.opacity[:] = rng.normal(-3.0, 0.5, size=(n, 1)).astype(np.float32)
     act, v = cloud.activated(), views[0]
