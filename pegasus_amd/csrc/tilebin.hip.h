@@ -769,7 +769,17 @@ __device__ __forceinline__ bool partition_sort_long(unsigned char* __restrict__ 
     const int t = threadIdx.x, lane = t & (WAVE - 1), wave = t / WAVE;
     if ((n + HALF - 1) / HALF > PART_MAX_SEGMENTS) return false;
     uint32_t dmin = 0xffffffffu, dmax = 0u;
-    for (int i = t; i < n; i += THREADS) { const uint32_t d = gload(bucket + i).x; dmin = min(dmin, d); dmax = max(dmax, d); }
+    // The three passes over the list read it from global memory (L2) with PB loads of a thread in flight at once, index
+    // clamped into the list: a `for (i < n) gload` loop waits for every load before it issues the next one (20..100 serial
+    // round trips per pass and thread on a 20..100 k-key list, with one workgroup per CU to cover them).
+    constexpr int PB = 8;
+    for (int i0 = t; i0 < n; i0 += PB * THREADS) {
+        uint32_t dv[PB];
+#pragma unroll
+        for (int k = 0; k < PB; ++k) dv[k] = gload(bucket + min(i0 + k * THREADS, n - 1)).x;     // (a clamped repeat changes no min / max)
+#pragma unroll
+        for (int k = 0; k < PB; ++k) { dmin = min(dmin, dv[k]); dmax = max(dmax, dv[k]); }
+    }
     for (int i = t; i < PART_BUCKETS; i += THREADS) s_hist[i] = 0u;
     if (t < 4 + WAVES) s_misc[t] = t == 0 ? 0xffffffffu : 0u;
     if (t < PART_MAX_SEGMENTS + 2) s_cut[t] = (uint32_t)n;      // segment g starts at s_cut[g]; n = not opened
@@ -784,7 +794,14 @@ __device__ __forceinline__ bool partition_sort_long(unsigned char* __restrict__ 
     const uint32_t mn = s_misc[0];
     const float scale = (float)PART_BUCKETS / ((float)(s_misc[1] - mn) + 1.0f);
     auto coarse = [&](uint32_t d) { return min((uint32_t)((float)(d - mn) * scale), (uint32_t)(PART_BUCKETS - 1)); };
-    for (int i = t; i < n; i += THREADS) atomicAdd(&s_hist[coarse(gload(bucket + i).x)], 1u);
+    for (int i0 = t; i0 < n; i0 += PB * THREADS) {
+        uint32_t dv[PB];
+#pragma unroll
+        for (int k = 0; k < PB; ++k) dv[k] = gload(bucket + min(i0 + k * THREADS, n - 1)).x;
+#pragma unroll
+        for (int k = 0; k < PB; ++k)
+            if (i0 + k * THREADS < n) atomicAdd(&s_hist[coarse(dv[k])], 1u);
+    }
     __syncthreads();
     const int wbase = wave * (WAVE * CH);
     uint32_t tot = 0, big = 0;
@@ -821,9 +838,13 @@ __device__ __forceinline__ bool partition_sort_long(unsigned char* __restrict__ 
     }
     __syncthreads();
     // counting-sort scatter through the alt buffer (the starts become the cursors)
-    for (int i = t; i < n; i += THREADS) {
-        const uint2 v = gload(bucket + i);
-        gstore(alt + atomicAdd(&s_hist[coarse(v.x)], 1u), v);
+    for (int i0 = t; i0 < n; i0 += PB * THREADS) {
+        uint2 kv[PB];
+#pragma unroll
+        for (int k = 0; k < PB; ++k) kv[k] = gload(bucket + min(i0 + k * THREADS, n - 1));
+#pragma unroll
+        for (int k = 0; k < PB; ++k)
+            if (i0 + k * THREADS < n) gstore(alt + atomicAdd(&s_hist[coarse(kv[k].x)], 1u), kv[k]);
     }
     __threadfence_block();
     __syncthreads();
