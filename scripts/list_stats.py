@@ -8,13 +8,14 @@ from helpers import fetch_workspace
 from pegasus_amd import frames as F, rasterizer as R
 
 workload = sys.argv[1] if len(sys.argv) > 1 else "c3"
-cloud, views, label = bench.build_workload(workload, 1.0, 64)
+n_total = 512 if workload == "c3" else (200 if workload == "c5" else 64)
+cloud, views, label = bench.build_workload(workload, 1.0, n_total)
 act = cloud.activated()
 fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"], cloud.object_id, sh_degree=3, device="cuda:0")
 edges = [0, 256, 512, 1024, 2048, 4096, 8192, 16384, 1 << 30]
 tot_l = np.zeros(len(edges) - 1); tot_k = np.zeros(len(edges) - 1)
-nv = 8
-for v in views[:nv]:
+nv = 16
+for v in [views[(k * (len(views) - 1)) // (nv - 1)] for k in range(nv)]:      # spread over the camera set (ordered by elevation)
     R.forward_views(fr.means3d, fr.opacities, [fr.view_spec(v)], shs=fr.shs, scales=fr.scales, rotations=fr.rotations, sh_degree=3, want_radii=True)
     torch.cuda.synchronize()
     w = fetch_workspace(0, cloud.n, v.width, v.height)
