@@ -359,3 +359,68 @@ def test_generate_view_sharded_over_two_ranks_writes_the_same_dataset(gpu_device
             assert (one / f).read_bytes() == (two / f).read_bytes(), f
         else:
             assert json.loads((one / f).read_text()) == json.loads((two / f).read_text()), f
+
+
+@pytest.mark.gpu
+def test_render_follows_cameras_with_transposed_matrices_and_in_place_edits(gpu_device):
+    """render() keeps contiguous copies of a camera's matrices while the camera's tensors are unchanged (upstream's Camera
+    hands out `.transpose(0, 1)` VIEWS, whose contiguous copy cost two kernels per call).  The copies must follow the
+    camera: an upstream-style camera (transposed views) renders like this build's own Camera, an in-place edit of its matrices
+    (through the view or through its base tensor) or a re-assignment is seen by the next call, and the shared zero
+    `viewspace_points` stays zero."""
+    import types
+    import torch
+    from argparse import ArgumentParser
+    sys.path.insert(0, str(ROOT / "compat"))
+    from arguments import PipelineParams
+    from pegasus_amd import gaussian_renderer as GR, graphics as G, scenes
+    from pegasus_amd.cameras import Camera
+    from pegasus_amd.gaussian_model import GaussianModel
+    dev = gpu_device
+    cloud, views = scenes.scene_c3(scale=0.01, n_views=3, width=320, height=240, camera_set="fibonacci_above_9deg")
+    pc = GaussianModel.from_arrays(cloud.xyz, cloud.features_dc, cloud.features_rest, cloud.opacity, cloud.scaling, cloud.rotation,
+                                   device=dev)
+    pipe = PipelineParams(ArgumentParser())
+    bg = torch.zeros(3, device=dev)
+
+    def ours(v):
+        return Camera(colmap_id=0, R=v.R_c2w, T=v.t_w2c, FoVx=v.fovx, FoVy=v.fovy, image=None, image_width=v.width,
+                      image_height=v.height, gt_alpha_mask=None, image_name="0", uid=0, data_device=str(dev))
+
+    def upstream_style(v):
+        """What the reference's scene.cameras.Camera computes (/root/reference/src/gs/pegasus_setup.py:130-140 builds it):
+        transposed VIEWS on the device, full_proj by bmm, the centre as a row of the (column-major) inverse."""
+        c = types.SimpleNamespace(image_width=v.width, image_height=v.height, FoVx=v.fovx, FoVy=v.fovy)
+        c.base_view = torch.tensor(G.getWorld2View2(v.R_c2w, v.t_w2c)).to(dev)
+        c.world_view_transform = c.base_view.transpose(0, 1)
+        c.projection_matrix = torch.tensor(G.getProjectionMatrix(G.ZNEAR, G.ZFAR, v.fovx, v.fovy)).to(dev).transpose(0, 1)
+        c.full_proj_transform = (c.world_view_transform.unsqueeze(0).bmm(c.projection_matrix.unsqueeze(0))).squeeze(0)
+        c.camera_center = c.world_view_transform.inverse()[3, :3]
+        return c
+
+    with torch.no_grad():
+        ref = [GR.render(upstream_style(v), pc, pipe, bg) for v in views]                    # fresh cameras: cold copies
+        own = GR.render(ours(views[0]), pc, pipe, bg)
+        # (this build's Camera multiplies the same matrices in contiguous layout: the products may differ in the last bit)
+        assert float((own["render"] - ref[0]["render"]).abs().max()) < 1e-4 and int((own["radii"] != ref[0]["radii"]).sum()) <= 2
+        cam = upstream_style(views[0])
+        assert not cam.world_view_transform.is_contiguous()
+        a = GR.render(cam, pc, pipe, bg)
+        assert torch.equal(a["render"], ref[0]["render"]) and torch.equal(a["radii"], ref[0]["radii"])
+        assert torch.equal(GR.render(cam, pc, pipe, bg)["render"], ref[0]["render"])           # warm: the kept copies
+        # the camera moves IN PLACE: through the base tensor of the view, through the views themselves
+        other = upstream_style(views[1])
+        cam.base_view.copy_(other.base_view)
+        cam.full_proj_transform.copy_(other.full_proj_transform)
+        cam.camera_center.copy_(other.camera_center)
+        b = GR.render(cam, pc, pipe, bg)
+        assert torch.equal(b["render"], ref[1]["render"]) and not torch.equal(b["render"], ref[0]["render"])
+        # ... and by re-assignment
+        third = upstream_style(views[2])
+        cam.world_view_transform, cam.full_proj_transform, cam.camera_center = (third.world_view_transform, third.full_proj_transform,
+                                                                                third.camera_center)
+        c = GR.render(cam, pc, pipe, bg)
+        assert torch.equal(c["render"], ref[2]["render"])
+        assert torch.equal(c["visibility_filter"], c["radii"] > 0) and int(c["visibility_filter"].sum()) > 100
+        assert float(c["viewspace_points"].abs().max()) == 0.0 and c["viewspace_points"].shape == pc.get_xyz.shape
+        assert c["viewspace_points"] is a["viewspace_points"]                                   # the shared zero probe
