@@ -141,21 +141,25 @@ class GaussianModel:
         self.apply_translation_on_xyz(t=T[:3, 3])
 
     @staticmethod
-    def _host_matrix(M) -> np.ndarray:
-        """A pose matrix on the host, float64.  PEGASUS hands the SAME device tensor R to apply_rotation_on_splats and
-        apply_rotation_on_sh (pegasus_setup.py:195-208): its host copy (one device round trip) is kept for the next call."""
+    def _host_matrix(M):
+        """(key, 3x3.. float64 host copy) of a pose matrix.  PEGASUS hands the SAME device tensor R to
+        apply_rotation_on_splats and apply_rotation_on_sh (pegasus_setup.py:195-208): for a tensor the key is (object,
+        version counter, storage) and its host copy (one device round trip) is kept for the next call.  Host inputs
+        (ndarray, lists) are COPIED and keyed on their 72 value bytes: object identity says nothing about an array the
+        caller may edit in place (round-5 advisor finding)."""
         if not torch.is_tensor(M):
-            return np.asarray(M, dtype=np.float64)
+            host = np.array(M, dtype=np.float64, copy=True)
+            return ("host", host.tobytes()), host
         try:
-            key = (id(M), M._version, M.data_ptr())
+            key = ("tensor", id(M), M._version, M.data_ptr())
         except RuntimeError:
             key = None
         hit = GaussianModel._host_matrix_slot
         if key is not None and hit is not None and hit[0] == key:
-            return hit[1]
+            return key, hit[1]
         host = np.asarray(M.detach().cpu().numpy(), dtype=np.float64)
         GaussianModel._host_matrix_slot = (key, host, M)       # (keeps M alive: its id cannot be recycled under the key)
-        return host
+        return key, host
 
     _host_matrix_slot = None
 
@@ -163,13 +167,13 @@ class GaussianModel:
     def _rotation_pose(cls, R):
         """PgrObjectPose of a pure rotation about the origin (quaternion + SH band matrices), built once per R: the
         reference's update calls apply_rotation_on_splats(R) and apply_rotation_on_sh(R) with the same tensor."""
-        host = cls._host_matrix(R)
+        key, host = cls._host_matrix(R)
         hit = cls._rotation_pose_slot
-        if hit is not None and hit[0] is host:
+        if key is not None and hit is not None and hit[0] == key:
             return hit[1]
-        T = np.eye(4); T[:3, :3] = host
+        T = np.eye(4); T[:3, :3] = host[:3, :3]
         pose = compose.make_pose(T, np.zeros(3))
-        cls._rotation_pose_slot = (host, pose)
+        cls._rotation_pose_slot = (key, pose)
         return pose
 
     _rotation_pose_slot = None
