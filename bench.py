@@ -118,6 +118,9 @@ def parse(argv=None):
                     help="BASELINE.json configs[0] (plumbing, no GPU): time ONLY the CPU oracle on the chosen workload's cameras "
                          "(default there: --workload c1, the 10 k-Gaussian cube at 256x256) and print a line flagged cpu_only; "
                          "the product path is not involved and needs no HIP device")
+    ap.add_argument("--full-outputs", action="store_true",
+                    help="N > 1 with --records epilogue: keep writing the fp32 images and mask planes beside the records "
+                         "(rounds 4-5; default since round 6: records-only frame sets, PgrOutputs color = NULL)")
     ap.add_argument("--records", default="epilogue", choices=["epilogue", "pack"],
                     help="N > 1: where the gathered frame records come from -- epilogue (default on RCCL): the compositor writes "
                          "them straight into the gather's send buffers (PgrOutputs::record); pack: pgr_pack_records after the "
@@ -325,6 +328,17 @@ class RealEngine:
     def record_bytes(self):
         from pegasus_amd import masks as M
         return M.record_layout(self.H, self.W, self.fr.K if self.with_masks else 0)["bytes"]
+
+    def set_records_only(self):
+        """N > 1 with direct records: a rank's only product is the frame record in the gather's send buffer, so its frame
+        sets name no image (PgrOutputs color = depth = sem_* = NULL): the compositor writes 3.84 MB per 800x800 frame, not
+        29.4 MB of fp32 / mask planes that nothing reads."""
+        self.frame_sets = [dict() for _ in range(self.n_slots)]
+        self.frames = None
+        self.records_only = True
+
+    def full_frame_set(self):
+        return self.fr.alloc_frames(self.B, self.H, self.W, masks=self.with_masks)
 
     def pack(self, fr_set, out):
         """What leaves the GPU for a finished batch: ONE uint8 record per frame, written straight into `out` (a
@@ -536,6 +550,8 @@ def run_worker(args):
                   and not args.separate_semantic)
         fg = VS.FrameGather(cap=B, record_bytes=eng.record_bytes(), device="cpu" if host_wire else dev, dst=0,
                             depth=n_slots + 2 if direct else 2, pin_memory=host_wire and not eng.stub)
+        if direct and not args.full_outputs and not eng.with_sil:
+            eng.set_records_only()
         if host_wire and not eng.stub:             # device-side staging of the rehearsal: pack on the GPU, copy to pinned
             stage = [torch.empty((B, eng.record_bytes()), dtype=torch.uint8, device=dev) for _ in range(2)]
 
@@ -659,6 +675,9 @@ def run_worker(args):
             fg.finish_all()
             seq["enq"] = 0
             token = enqueue(i_chk, 0).wait()
+            if getattr(eng, "records_only", False):   # the same batch once more with every image, for the pack kernel to read
+                token = eng.fr.render_frames(eng.batch_views(i_chk), eng.full_frame_set(), masks=eng.with_masks,
+                                             poses=eng.batch_poses(i_chk))
             eng.sync()
             # the compositor's records against the pack kernel's on the same frames (sender side, every rank)
             # (section by section: neither writer touches the 16-byte alignment padding between the sections)
@@ -724,7 +743,9 @@ def run_worker(args):
                     "g = i * world + r); two buffer slots, one gather in flight; nothing allocated or reordered per batch",
             "payload": "one record per frame: uint8 RGB [H,W,3] | uint16 depth mm [H,W] | K masks as bit planes (ceil(K/8) bytes per pixel)",
             "records": ("written by the compositor's epilogue straight into the gather's send buffers (PgrOutputs::record; a ring of "
-                        f"{fg.depth} buffers), no pack pass" if direct else "pgr_pack_records into the send buffer after the batch"),
+                        f"{fg.depth} buffers), no pack pass" + ("; RECORDS-ONLY views: no fp32 image or mask plane is written"
+                                                                if getattr(eng, "records_only", False) else "")
+                        if direct else "pgr_pack_records into the send buffer after the batch"),
             "bytes_per_rank_and_batch": fg.bytes_per_rank_and_batch,
             "views_per_s_with_gather": round(value, 3),
             "views_per_s_render_only": round(total_views / elapsed_render_only, 3),

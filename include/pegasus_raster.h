@@ -98,14 +98,19 @@ typedef struct PgrCamera {
 } PgrCamera;
 
 typedef struct PgrOutputs {
-    float *color;                /* [3,H,W]  required (except in a layered call, which writes no image) */
-    float *depth;                /* [1,H,W]  required (same exception): sum_i T_i alpha_i z_i, no bg term; PgrCamera::depth_mode
-                                    selects the normalised form */
+    float *color;                /* [3,H,W]  required, except: a layered call writes no image; a RECORDS-ONLY view passes
+                                    color = depth = NULL with `record` set and receives the frame record alone (round 6:
+                                    a rank of a view-sharded job ships 3.84 MB per 800x800 frame and has no reader for the
+                                    25.6 MB of fp32 / mask planes beside it) */
+    float *depth;                /* [1,H,W]  required (same exceptions; NULL exactly when color is): sum_i T_i alpha_i z_i, no
+                                    bg term; PgrCamera::depth_mode selects the normalised form */
     int32_t *radii;              /* [n]      required */
     float *final_T;              /* [H,W]    optional (NULL) */
     uint32_t *n_contrib;         /* [H,W]    optional (NULL) */
     float *sem_color;            /* [3,H,W]  the objects-only semantic render: REQUIRED on every view of a call that
-                                    passes a PgrSemantic (PGR_ERR_INVALID_ARGUMENT otherwise), ignored without one */
+                                    passes a PgrSemantic (PGR_ERR_INVALID_ARGUMENT otherwise), ignored without one.  A
+                                    records-only view (color == NULL, record set) may pass NULL when the descriptor carries
+                                    mask_colors: the semantic image then exists only as the record's mask planes */
     float *sem_depth;            /* [1,H,W]  optional, only with sem_color */
     uint8_t *sem_masks;          /* [K,H,W]  optional: the K colour-distance masks of the semantic image
                                     (pgr_color_masks of sem_color against PgrSemantic::mask_colors, bit for bit), written by

@@ -415,9 +415,11 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
     if (inside) {
         const float cr = fmaf(T, cam.bg[0], Crg.x), cg = fmaf(T, cam.bg[1], Crg.y), cb = fmaf(T, cam.bg[2], Cbd.x);
         const float dd = depth_out(Cbd.y, T);
-        gstore(o.color + 0 * P + pix, cr);
-        gstore(o.color + 1 * P + pix, cg);
-        gstore(o.color + 2 * P + pix, cb);
+        if (o.color) {                   // (NULL: a records-only view -- the record below is its whole product)
+            gstore(o.color + 0 * P + pix, cr);
+            gstore(o.color + 1 * P + pix, cg);
+            gstore(o.color + 2 * P + pix, cb);
+        }
         if (o.depth) gstore(o.depth + pix, dd);
         if (AUX) {
             if (o.final_T) gstore(o.final_T + pix, T);
@@ -437,9 +439,11 @@ __device__ __forceinline__ void composite_quarter(const ViewEntry& ve, uint32_t 
         const float sg = want_sem ? fmaf(Ts, cam.bg[1], Srg.y) : cam.bg[1];
         const float sb = want_sem ? fmaf(Ts, cam.bg[2], Sbd.x) : cam.bg[2];
         if (inside) {
-            gstore(ve.sem_color + 0 * P + pix, sr);
-            gstore(ve.sem_color + 1 * P + pix, sg);
-            gstore(ve.sem_color + 2 * P + pix, sb);
+            if (ve.sem_color) {          // (NULL: records only -- the semantic image lives on as the record's mask planes)
+                gstore(ve.sem_color + 0 * P + pix, sr);
+                gstore(ve.sem_color + 1 * P + pix, sg);
+                gstore(ve.sem_color + 2 * P + pix, sb);
+            }
             if (ve.sem_depth) gstore(ve.sem_depth + pix, want_sem ? depth_out(Sbd.y, Ts) : 0.0f);
         }
         // the K masks of that pixel, from the registers that hold it (round 3: a separate pass re-read 12 P bytes per view)
@@ -489,9 +493,10 @@ __global__ __launch_bounds__(WAVE) PGR_COMP_OCC void composite_quarter_kernel(co
     const uint32_t view = item / items_per_view;
     item -= view * items_per_view;
     const ViewEntry& ve = views[view];
-    if (ve.counters[1] || !ve.out.color) return;
+    if (ve.counters[1] || !(ve.out.color || ve.record)) return;
     if constexpr (FUSED) {
-        const bool want_sem = ve.sem_color != nullptr;
+        // the objects-only image is wanted as an image, or (records-only view) as the mask planes of the frame record
+        const bool want_sem = ve.sem_color != nullptr || (ve.record != nullptr && sem.mask_colors != nullptr);
         // object entries live in [0, n_sem).  readfirstlane: the value arrives through a vector load; everything derived
         // from it (the semantic masks, the loop exits) must stay on the scalar unit
         const int n_sem = want_sem ? __builtin_amdgcn_readfirstlane((int)ve.obj_last[item >> 2]) : 0;
@@ -585,14 +590,28 @@ constexpr int ORDER_BINS = NUM_XCD * ORDER_CLASSES_USED;
 // order_state layout (uint32): [ORDER_BINS] counters -> cursors, then [SORT_TIERS] lengths of the sort queues, then the
 // ticket of tile_scan_kernel's workgroups (the last one turns the counters into cursors)
 // Sort queues: every non-empty list of a view that did not overflow is one uint4 (item, first instance, keys, 0) in the
-// queue of its tier -- 1..2048 keys, 2049..4096, 4097..8192, longer: one queue and one sort launch each.  A sort
+// queue of its tier -- 1..2048 keys, 2049..4096, 4097..8192, 8193..SORT_WINDOW_MAX (round 6: the windowed sort), longer
+// (round 6: the split pre-pass, whose depth segments join the SEGMENT queue of the 4097..8192 tier's kernel), and the open-ended
+// kernel's queue, which order_scatter fills only in one- and two-view calls and which otherwise receives what the windowed
+// sort and the split pre-pass reject: one queue and one sort launch each.  A sort
 // workgroup learns its list from that one word (the view's table entry arrives beside it through the scalar cache)
 // instead of chasing item -> view table -> ranges -> keys; and a launch has no workgroups for empty tiles.
-constexpr int SORT_TIERS = 4;
+constexpr int SORT_TIERS = 6;
+constexpr int SORT_WINDOW_MAX = 2 * (8192 - 256);   // tilebin.hip.h: two windows of the windowed sort's 8192-key image
 constexpr int ORDER_DONE_WORD = ORDER_BINS + SORT_TIERS;
-constexpr int ORDER_STATE_WORDS = ORDER_BINS + SORT_TIERS + 1;
+constexpr int ORDER_SEG_WORD = ORDER_DONE_WORD + 1; // entries of the segment queue
+constexpr int ORDER_STATE_WORDS = ORDER_BINS + SORT_TIERS + 2;
 
-__device__ __forceinline__ int sort_tier(uint32_t len) { return len > 8192u ? 3 : (len > 4096u ? 2 : (len > 2048u ? 1 : 0)); }
+#ifndef PGR_WINDOW_TIER
+#define PGR_WINDOW_TIER 1        // 0: no windowed sort (A/B builds): lists of 8193..15872 keys take the next tier's path
+#endif
+#ifndef PGR_SPLIT_TIER
+#define PGR_SPLIT_TIER 1         // 0: no split pre-pass (A/B builds): lists beyond the windowed sort go to the open-ended kernel
+#endif
+__device__ __forceinline__ int sort_tier(uint32_t len) {
+    const int beyond = PGR_SPLIT_TIER ? 4 : 5;
+    return len > (uint32_t)SORT_WINDOW_MAX ? beyond : (len > 8192u ? (PGR_WINDOW_TIER ? 3 : beyond) : (len > 4096u ? 2 : (len > 2048u ? 1 : 0)));
+}
 
 __device__ __forceinline__ int xcd_of_tile(int tile, int grid_x) { return (tile / grid_x / ORDER_BAND_ROWS) % NUM_XCD; }
 

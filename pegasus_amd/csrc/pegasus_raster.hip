@@ -75,6 +75,7 @@ static Layout make_layout(int32_t n, int32_t width, int32_t height, int64_t max_
     L.alt = take(I * 8);
     L.gauss_sorted = take(I * 4);
     L.total = off;
+    L.max_instances = (int64_t)I;
     return L;
 }
 
@@ -129,6 +130,7 @@ struct BatchLayout {
     int n_groups, vis_words;
     size_t view_table_off, bin_table_off, pre_table_off, tables_bytes;   // inside `tables` (one H2D copy)
     size_t order_slots;
+    size_t seg_cap;              // entries of the segment queue (behind the SORT_TIERS tier queues)
     size_t per_view;
 };
 
@@ -154,7 +156,10 @@ static BatchLayout make_batch_layout(const Layout& L, int n_views, size_t n_scen
     // NUM_XCD interleaved streams; each holds the items of its band of tile rows for every view
     B.order_slots = (size_t)NUM_XCD * max_band_rows(L.grid_y) * L.grid_x * ITEMS_PER_TILE * n_views;
     B.work_order = take(B.order_slots * 4);
-    B.long_list = take((size_t)n_views * L.tiles * sizeof(uint4) * SORT_TIERS);   // the sort queues
+    // the sort queues: one per tier, and the segment queue of the split pre-pass -- a list of n > SORT_WINDOW_MAX keys yields
+    // at most n / SEG_HALF + 2 <= n (1 / 4096 + 2 / 15872) = n / 2702 segments, and a view's lists hold max_instances keys
+    B.seg_cap = (size_t)n_views * ((size_t)(L.max_instances > 0 ? L.max_instances : 0) / 2702 + 2);
+    B.long_list = take(((size_t)n_views * L.tiles * SORT_TIERS + B.seg_cap) * sizeof(uint4));
     B.tie_inv = take((size_t)n_scene * 4);     // inverse of PgrScene::tie_index (filled only when one is given)
     B.n_groups = (int)((n_scene + WAVE - 1) / WAVE);
     B.vis_words = (n_views + 31) / 32;
@@ -169,7 +174,8 @@ static BatchLayout make_batch_layout(const Layout& L, int n_views, size_t n_scen
 static int check_camera(const PgrCamera* cam, const PgrOutputs* out, bool layered = false) {
     if (!cam || !out || cam->image_width <= 0 || cam->image_height <= 0 || !(cam->tanfovx > 0.f) ||
         !(cam->tanfovy > 0.f) || !cam->viewmatrix || !cam->projmatrix || !cam->campos || !cam->bg ||
-        (layered ? !out->sem_masks : (!out->color || !out->depth)) ||
+        // color + depth, or (records-only view) the frame record alone; a layered call writes mask planes only
+        (layered ? !out->sem_masks : !((out->color && out->depth) || (out->record && !out->color && !out->depth))) ||
         (cam->depth_mode != PGR_DEPTH_EXPECTED && cam->depth_mode != PGR_DEPTH_NORMALIZED))
         return PGR_ERR_INVALID_ARGUMENT;
     // tile coordinates are packed into 16 bits
@@ -230,7 +236,10 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         if (int rc = check_camera(&cams[v], &outs[v], layers != nullptr)) return rc;
         if (cams[v].image_width != W || cams[v].image_height != H) return PGR_ERR_INVALID_ARGUMENT;
         // a semantic descriptor asks for the objects-only image of EVERY view of the batch
-        if (semantic && !outs[v].sem_color) return PGR_ERR_INVALID_ARGUMENT;
+        // (a records-only view takes it as the mask planes of its record instead: no image, but then the colours to
+        // threshold against must be there)
+        if (semantic && !outs[v].sem_color && !(outs[v].record && !outs[v].color && semantic->mask_colors && !outs[v].sem_depth))
+            return PGR_ERR_INVALID_ARGUMENT;
         // masks in the compositor's epilogue need the colours to threshold against
         if (!layers && outs[v].sem_masks && !(semantic && semantic->mask_colors)) return PGR_ERR_INVALID_ARGUMENT;
     }
@@ -298,7 +307,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         e.obj_last = vw[v].obj_last;
         e.sem_masks = (semantic || layers) ? outs[v].sem_masks : nullptr;
         e.record = layers ? nullptr : outs[v].record;
-        want_sem = want_sem || e.sem_color;
+        want_sem = want_sem || e.sem_color || (semantic && e.record);
         want_aux = want_aux || outs[v].final_T || outs[v].n_contrib;
         bins[v] = BinView{vw[v].crects, vw[v].splats, vw[v].tile_count, vw[v].rel, vw[v].ranges,
                           vw[v].counters, vw[v].bucket, vw[v].gauss_sorted, vw[v].alt, vw[v].obj_last,
@@ -383,8 +392,21 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     order_scatter_kernel<<<og, 256, 0, stream>>>(view_table, L.tiles, L.grid_x, order_state, work_order, sort_queue,
                                                  (uint32_t)items, merge_long ? 1 : 0, layers ? 1 : 0);
     const uint32_t* n_queue = order_state + ORDER_BINS;
+    uint32_t* const n_open = order_state + ORDER_BINS + 5;
+    if (!merge_long) {
+        // 8193..15872 keys: the windowed sort (two workgroups per CU); longer: the split pre-pass, whose depth segments the
+        // 512 x 16 tier's kernel sorts from the segment queue; what either rejects joins the open-ended kernel's queue
+        tile_sort_window_kernel<<<std::min(items, 2048), SORT_WINDOW_THREADS, 0, stream>>>(
+            bin_table, L.tiles, sort_queue + 3 * qs, n_queue + 3, sort_queue + 5 * qs, n_open);
+        tile_partition_kernel<<<std::min(items, 1024), PART_THREADS, 0, stream>>>(
+            bin_table, L.tiles, sort_queue + 4 * qs, n_queue + 4, sort_queue + SORT_TIERS * qs, order_state + ORDER_SEG_WORD,
+            (uint32_t)B.seg_cap, sort_queue + 5 * qs, n_open);
+    }
     tile_sort_long_kernel<1024, 16, true><<<std::min(items, 512), 1024, 0, stream>>>(
-        bin_table, L.tiles, sort_queue + 3 * qs, n_queue + 3);
+        bin_table, L.tiles, sort_queue + 5 * qs, n_queue + 5);
+    if (!merge_long)
+        tile_sort_long_kernel<512, 16, false, SORT_T2_BUCKETS, 4, true><<<std::min(items, 2048), 512, 0, stream>>>(
+            bin_table, L.tiles, sort_queue + SORT_TIERS * qs, order_state + ORDER_SEG_WORD, (uint32_t)B.seg_cap);
     if (!merge_long) {
         // 4097..8192 keys: 512 threads x 16 keys over 3584 buckets = 80 KiB, TWO workgroups per CU (round 5: the position-owned
         // ranking needs no index image, so the bucket count is free; 1024 x 8 over 8192 buckets = 96 KiB held a CU alone)

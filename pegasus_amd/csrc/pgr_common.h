@@ -76,6 +76,7 @@ struct Layout {
     int32_t tiles, grid_x, grid_y;
     int32_t n_blocks;
     int32_t n_chunks;
+    int64_t max_instances;
 };
 
 // Work ordering: list-length classes (256, log-spaced); see composite.hip.h "work order".

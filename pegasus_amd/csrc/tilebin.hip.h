@@ -739,6 +739,242 @@ __device__ __forceinline__ bool bucket_sort_tile(unsigned char* __restrict__ lds
     return true;
 }
 
+// ---- windowed bucket sort: lists of 8193 .. SORT_WINDOW_MAX keys in an 80 KiB workgroup (round 6) -------------------
+// Until round 5 every list beyond 8192 keys went to the open-ended tier: 1024 threads over a 157 KiB image, ONE workgroup
+// per CU, whose phases (loads, histogram atomics, scan, park, ranking) nothing overlaps -- VALU 0.35, LDS 0.16, 76 keys/ns
+// on C5 against 135 for the two-per-CU 512 x 16 tier, with 30 % of C5's keys.  The LDS image is what holds a CU alone,
+// and it only has to hold the keys being RANKED: here a thread keeps the depth bits of its E = 32 keys in registers, the
+// histogram (one arrival slot per key, eight bits, four per register) and the scan run once over the whole list, and the
+// image is filled and ranked one WINDOW of bucket-aligned positions at a time: window w = the buckets whose start lies in
+// [w WK, (w + 1) WK), WK = KEYS - 256, parked at (position - w WK).  A bucket holds at most 255 keys (else the list is
+// rejected), so a window's positions end below w WK + KEYS.
+//   Counters are HALF WORDS, two buckets per LDS word (a 32-bit atomic adds 1 << 16 (b & 1) to word b >> 1 and returns both
+//   halves; no half can overflow into its neighbour below 65 536 keys): 7168 buckets in the 14 KiB that 3584 word counters
+//   take -- 1.1 .. 2.2 keys per bucket instead of 2.3 .. 4.4, which is what the in-bucket ranking loops cost (first build,
+//   word counters over 3584 buckets: sort stage +6 % on C5 against the open-ended tier, profiles/r06_sort_window_ab.txt).
+//   After the scan a half word is its bucket's first position; a bucket's extent = its half and the next one (two
+//   consecutive words, one ds_read2_b32).
+// Same position-owned ranking and direct stores as bucket_sort_tile: the result is THE order; two workgroups per CU as in
+// the 512 x 16 tier, the list's depths read once (the indices again when a key is parked).  Rejected lists (piled-up
+// depths) are appended to the open-ended tier's queue, which is launched afterwards.
+#ifndef PGR_WINDOW_EB
+#define PGR_WINDOW_EB 4
+#endif
+constexpr int SORT_WINDOW_THREADS = 512;
+constexpr int SORT_WINDOW_E = 32;
+constexpr int SORT_WINDOW_KEYS = 8192;                      // image: 64 KiB
+#ifndef PGR_WINDOW_NB
+#define PGR_WINDOW_NB 7168
+#endif
+constexpr int SORT_WINDOW_BUCKETS = PGR_WINDOW_NB;          // half-word counters: + 14 KiB (+ SORT_MISC_BYTES + window words): 2 per CU
+constexpr int SORT_WINDOW_WK = SORT_WINDOW_KEYS - 256;
+static_assert(SORT_WINDOW_MAX == 2 * SORT_WINDOW_WK, "composite.hip.h's tier bound: 15 872 keys, two windows");
+constexpr int SORT_WINDOW_ROUNDS = (SORT_WINDOW_THREADS * SORT_WINDOW_E + SORT_WINDOW_WK - 1) / SORT_WINDOW_WK;   // by capacity: 3
+constexpr size_t SORT_WINDOW_LDS = (size_t)SORT_WINDOW_KEYS * 8 + ((size_t)SORT_WINDOW_BUCKETS / 2 + 2) * 4 + SORT_MISC_BYTES;
+
+template <int THREADS, int E, int NB, int KEYS>
+__device__ __forceinline__ bool window_sort_tile(unsigned char* __restrict__ lds, uint32_t* __restrict__ s_win,
+                                                 const uint2* __restrict__ bucket, uint32_t* __restrict__ out, int n,
+                                                 int n_env, uint32_t* __restrict__ obj_last,
+                                                 const int32_t* __restrict__ tie = nullptr) {
+    constexpr int WAVES = THREADS / WAVE, NW = NB / 2, CH = NW / (WAVES * WAVE), WK = KEYS - 256, ROUNDS = (THREADS * E + WK - 1) / WK;
+    static_assert(NB % (2 * WAVES * WAVE) == 0 && E % 8 == 0 && KEYS % THREADS == 0, "shape");
+    static_assert(5 * WAVES * 4 <= SORT_MISC_BYTES, "per-wave words");
+    uint64_t* s_keys = reinterpret_cast<uint64_t*>(lds);                       // [KEYS]
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(lds + (size_t)KEYS * 8);    // [NW + 2] two counters per word -> two starts
+    uint32_t* s_wmin = s_hist + NW + 2;
+    uint32_t* s_wmax = s_wmin + WAVES;
+    uint32_t* s_wtot = s_wmax + WAVES;
+    uint32_t* s_wsq = s_wtot + WAVES;
+    uint32_t* s_wbig = s_wsq + WAVES;                                          // [WAVES] largest bucket of the wave's share
+    // s_win[w] = first bucket of window w, s_win[ROUNDS + 1 + w] = its first position; entry ROUNDS closes the last window
+    // (opaque per call: the kernel's loop over its lists would otherwise hoist every thread-dependent address and bucket
+    // index of this function out of it and keep them on the stack)
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const int lane = t & (WAVE - 1), wave = t / WAVE;
+    const int e_used = (n + THREADS - 1) / THREADS;                            // (uniform) key slots of a thread that hold keys
+
+    // the depth bits stay in registers (E per thread); the indices are fetched again when a key is parked (the list is
+    // in the cache hierarchy, and 2 E more live registers spill)
+    uint32_t d[E];
+    uint32_t dmin = 0xffffffffu, dmax = 0u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) d[e] = gload(&bucket[min(e * THREADS + t, n - 1)].x);
+    for (int i = t; i < NW + 2; i += THREADS) s_hist[i] = 0u;
+    // window table: no window opened = (bucket NB, position n); window 0 opens at (bucket 0, position 0)
+    if (t < 2 * (ROUNDS + 1)) s_win[t] = (t == 0 || t == ROUNDS + 1) ? 0u : (t <= ROUNDS ? (uint32_t)NB : (uint32_t)n);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool in = e * THREADS + t < n;
+        dmin = min(dmin, in ? d[e] : 0xffffffffu); dmax = max(dmax, in ? d[e] : 0u);
+    }
+    dmin = ~wave_inclusive_max(~dmin);
+    dmax = wave_inclusive_max(dmax);
+    if (lane == WAVE - 1) { s_wmin[wave] = dmin; s_wmax[wave] = dmax; }
+    __syncthreads();                            // 1: counters zero, per-wave extremes visible
+    uint32_t mn = 0xffffffffu, mx = 0u;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { mn = min(mn, s_wmin[w]); mx = max(mx, s_wmax[w]); }
+    const float scale = (float)NB / ((float)(mx - mn) + 1.0f);
+    auto bucket_of = [&](uint32_t depth) { return min((uint32_t)((float)(depth - mn) * scale), (uint32_t)(NB - 1)); };
+    // Eight atomics of a thread in flight at a time: a key slot beyond the list adds 0 to a word of the thread's own
+    // (no exec-masked round trip per key, no pile of same-address atomics from the padding)
+    uint32_t sl[E / 4];                         // arrival slot inside the bucket, 8 bits per key (a bucket of > 255 keys rejects the list)
+#pragma unroll
+    for (int e0 = 0; e0 < E; e0 += 8) {
+        sl[e0 / 4] = 0u; sl[e0 / 4 + 1] = 0u;
+        if (e0 < e_used) {
+            uint32_t old[8], sh[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool in = (e0 + e) * THREADS + t < n;
+                const uint32_t b = bucket_of(d[e0 + e]);
+                sh[e] = (b & 1u) << 4;
+                old[e] = atomicAdd(&s_hist[in ? (b >> 1) : (uint32_t)t], in ? (1u << sh[e]) : 0u);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sl[(e0 + e) >> 2] |= ((old[e] >> sh[e]) & 0xffu) << (8 * (e & 3));
+        }
+    }
+    __syncthreads();                            // 2: histogram complete
+    const int wbase = wave * (WAVE * CH);
+    uint32_t tot = 0, sq = 0, big = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const uint32_t hc = s_hist[wbase + c * WAVE + lane], lo = hc & 0xffffu, hi = hc >> 16;
+        tot += lo + hi; sq += lo * lo + hi * hi; big = max(big, max(lo, hi));
+    }
+    tot = wave_inclusive_scan(tot);
+    sq = wave_inclusive_scan(sq);
+    big = wave_inclusive_max(big);
+    if (lane == WAVE - 1) { s_wtot[wave] = tot; s_wsq[wave] = sq; s_wbig[wave] = big; }
+    __syncthreads();                            // 3: per-wave totals visible
+    uint32_t carry = 0, sqsum = 0, biggest = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        const uint32_t tw = s_wtot[w];
+        carry += w < wave ? tw : 0u;
+        sqsum += s_wsq[w];
+        biggest = max(biggest, s_wbig[w]);
+    }
+    if (biggest > 255u || sqsum > BUCKET_SQ_LIMIT * (uint32_t)n * (uint32_t)((THREADS * E + NB - 1) / NB)) { __syncthreads(); return false; }
+    // exclusive scan of the counts -> every half word = its bucket's first position; the bucket whose start is the first at
+    // or beyond w WK opens window w (exactly one bucket per window that exists)
+    auto opens = [&](uint32_t b, uint32_t start, uint32_t next) {
+        // w WK in (start, next]: the NEXT bucket's start is the first at or beyond w WK (a bucket holds < WK keys: one w)
+        const uint32_t w = start / (uint32_t)WK + 1u;
+        if (w * (uint32_t)WK <= next && w <= (uint32_t)ROUNDS) { s_win[w] = b + 1u; s_win[ROUNDS + 1 + w] = next; }
+    };
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const uint32_t word = (uint32_t)(wbase + c * WAVE + lane);
+        const uint32_t hc = s_hist[word], lo = hc & 0xffffu, hi = hc >> 16;
+        const uint32_t incl = wave_inclusive_scan(lo + hi);
+        const uint32_t s_lo = carry + incl - (lo + hi), s_hi = s_lo + lo;
+        s_hist[word] = s_lo | (s_hi << 16);
+        opens(2u * word, s_lo, s_hi);
+        opens(2u * word + 1u, s_hi, s_hi + hi);
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+    }
+    if (t == THREADS - 1) s_hist[NW] = (uint32_t)n | ((uint32_t)n << 16);      // closes the last bucket
+    __syncthreads();                            // 4: bucket starts and window table
+    uint32_t best = 0;
+    for (int w = 0; w < ROUNDS; ++w) {
+        const uint32_t b_lo = s_win[w], b_hi = s_win[w + 1];
+        const uint32_t p_lo = s_win[ROUNDS + 1 + w], p_hi = min(s_win[ROUNDS + 2 + w], (uint32_t)n);
+        if (b_lo >= (uint32_t)NB || p_lo >= (uint32_t)n) break;
+        const uint32_t shift = (uint32_t)w * (uint32_t)WK;
+        // (opaque copies per round: everything below that depends only on d[] and t is loop-invariant, and the compiler
+        // would keep the 32 buckets and 32 load addresses of a thread live across the rounds -- 100 registers to the stack)
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        constexpr int PBATCH = 8;               // index loads and bucket-start look-ups in flight at a time
+#pragma unroll
+        for (int e0 = 0; e0 < E; e0 += PBATCH) {
+            if (e0 >= e_used) break;
+            uint32_t idv[PBATCH], st[PBATCH];
+            bool mine[PBATCH];
+#pragma unroll
+            for (int e = 0; e < PBATCH; ++e) {
+                asm volatile("" : "+v"(d[e0 + e]));
+                const uint32_t b = bucket_of(d[e0 + e]);
+                mine[e] = (e0 + e) * THREADS + tt < n && b >= b_lo && b < b_hi;
+                idv[e] = 0u; st[e] = 0u;
+                if (mine[e]) { idv[e] = gload(&bucket[(e0 + e) * THREADS + tt].y); st[e] = (s_hist[b >> 1] >> ((b & 1u) << 4)) & 0xffffu; }
+            }
+#pragma unroll
+            for (int e = 0; e < PBATCH; ++e)
+                if (mine[e])
+                    s_keys[st[e] + ((sl[(e0 + e) >> 2] >> (8 * ((e0 + e) & 3))) & 0xffu) - shift] = ((uint64_t)d[e0 + e] << 32) | idv[e];
+        }
+        __syncthreads();                        // the window's keys parked in their buckets
+        constexpr int EB = PGR_WINDOW_EB, PER = KEYS / THREADS;
+#pragma unroll
+        for (int e0 = 0; e0 < PER; e0 += EB) {
+            uint64_t key[EB];
+            uint32_t x0[EB], x1[EB];
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                const uint32_t i = shift + (uint32_t)((e0 + e) * THREADS + t);
+                key[e] = s_keys[min(max(i, p_lo), p_hi - 1u) - shift];
+            }
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                const uint32_t b = bucket_of((uint32_t)(key[e] >> 32));
+                x0[e] = s_hist[b >> 1]; x1[e] = s_hist[(b >> 1) + 1];
+            }
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                const uint32_t i = shift + (uint32_t)((e0 + e) * THREADS + t);
+                if (i >= p_lo && i < p_hi) {
+                    const uint32_t kd = (uint32_t)(key[e] >> 32), kid = (uint32_t)key[e];
+                    const bool odd = bucket_of(kd) & 1u;
+                    const uint32_t s0 = odd ? x0[e] >> 16 : x0[e] & 0xffffu, cnt = (odd ? x1[e] & 0xffffu : x0[e] >> 16) - s0;
+                    uint32_t rank = i - s0;
+                    if (cnt > 1u) {
+                        rank = 0;
+                        uint32_t same = 0;
+                        constexpr uint32_t RANK_BATCH = 4;
+                        uint64_t kb[RANK_BATCH];
+#pragma unroll
+                        for (uint32_t m = 0; m < RANK_BATCH; ++m) kb[m] = s_keys[s0 - shift + min(m, cnt - 1u)];
+#pragma unroll
+                        for (uint32_t m = 0; m < RANK_BATCH; ++m) {
+                            const bool in = m < cnt;
+                            rank += (in && kb[m] < key[e]) ? 1u : 0u;
+                            same += (in && (uint32_t)(kb[m] >> 32) == kd) ? 1u : 0u;
+                        }
+                        for (uint32_t j = s0 + RANK_BATCH; j < s0 + cnt; ++j) {
+                            const uint64_t kj = s_keys[j - shift];
+                            rank += kj < key[e] ? 1u : 0u;
+                            same += (uint32_t)(kj >> 32) == kd ? 1u : 0u;
+                        }
+                        if (tie && same > 1u) {
+                            const int32_t mine = gload(tie + kid);
+                            rank = 0;
+                            for (uint32_t j = s0; j < s0 + cnt; ++j) {
+                                const uint64_t kj = s_keys[j - shift];
+                                const uint32_t dj = (uint32_t)(kj >> 32);
+                                rank += (dj < kd || (dj == kd && (uint32_t)kj != kid && gload(tie + (uint32_t)kj) < mine)) ? 1u : 0u;
+                            }
+                        }
+                    }
+                    const uint32_t f = s0 + rank;
+                    gstore(out + f, kid);
+                    if (n_env >= 0 && (int)kid >= n_env) best = max(best, f + 1u);
+                }
+            }
+        }
+        __syncthreads();                        // the image is free for the next window
+    }
+    if (n_env >= 0) {
+        best = wave_inclusive_max(best);
+        if (lane == WAVE - 1 && best) gatomic_max(obj_last, best);
+    }
+    return true;
+}
+
 // Lists beyond one LDS sort (> CAP keys): ONE counting-sort pass by coarse depth bucket through the alt buffer
 // (L2-resident), cut at the first bucket start at or after every multiple of CAP / 2 -- with no bucket larger than
 // CAP / 2 every segment holds < CAP keys, and all of its depths precede the next segment's -- then each segment is
@@ -911,6 +1147,21 @@ __device__ __forceinline__ void sort_item(const BinView* __restrict__ views, int
     if (alt) *alt = bv.alt + q.y;
 }
 
+// q = SEGMENT queue entry (view * tiles + tile, first instance of the list, keys of the segment, first position of the
+// segment inside the list): tile_partition_kernel.  The segment's keys sit in the list's alt buffer, depth-partitioned; its
+// sorted indices go to the same positions of gauss_sorted.  `pos` = the offset the object marker is counted from.
+__device__ __forceinline__ void sort_segment(const BinView* __restrict__ views, int tiles, const uint4 q,
+                                             const uint2*& bucket, uint32_t*& out, int& n, ObjOut& oo, uint32_t& pos) {
+    const uint32_t view = q.x / (uint32_t)tiles;
+    const uint32_t tile = q.x - view * (uint32_t)tiles;
+    const BinView& bv = views[view];
+    n = (int)q.z;
+    pos = q.w;
+    bucket = reinterpret_cast<const uint2*>(bv.alt) + q.y + q.w;
+    out = bv.gauss_sorted + q.y + q.w;
+    oo = ObjOut{bv.n_env, bv.obj_last + tile, bv.tie_index, bv.tie_inv};
+}
+
 // grid = n_views * tiles workgroups of 256 (upper bound of the queue's length); lists of 1..2048 entries
 __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* __restrict__ views, int tiles,
                                                                  const uint4* __restrict__ queue,
@@ -949,10 +1200,11 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* 
 //               and its alt buffer.
 // A kernel per tier keeps each one's register budget its own: with the open-ended tier's code in the same kernel the
 // 4097..8192 path (a quarter of C3's keys) ran out of the 128 VGPRs a 1024-thread workgroup gets and spilled.
-template <int THREADS, int E, bool LAST, int NB = THREADS * E, int MIN_WAVES = (THREADS == 512 ? PGR_T1_WAVES : 4)>
+// SEG: the queue holds depth SEGMENTS of longer lists (tile_partition_kernel) instead of whole lists; seg_cap = its capacity
+template <int THREADS, int E, bool LAST, int NB = THREADS * E, int MIN_WAVES = (THREADS == 512 ? PGR_T1_WAVES : 4), bool SEG = false>
 __global__ __launch_bounds__(THREADS, MIN_WAVES) void tile_sort_long_kernel(const BinView* __restrict__ views, int tiles,
                                                                  const uint4* __restrict__ queue,
-                                                                 const uint32_t* __restrict__ n_queue) {
+                                                                 const uint32_t* __restrict__ n_queue, uint32_t seg_cap = 0) {
     constexpr int CAP = THREADS * E;
     static_assert(!LAST || CAP == SORT_LARGE_MAX, "the open-ended tier");
     // bucket sort image: 8 B per key + 4 B per bucket, or (last tier) keys + 8192 counters = 157 KiB; the merge sort's padded keys fit
@@ -961,9 +1213,20 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES) void tile_sort_long_kernel(cons
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     __shared__ uint32_t s_cut[LAST ? PART_MAX_SEGMENTS + 3 : 1];
     uint64_t* skeys = reinterpret_cast<uint64_t*>(lds);
-    const uint32_t cand = *n_queue;
+    const uint32_t cand = SEG ? min(*n_queue, seg_cap) : *n_queue;
     for (uint32_t k = blockIdx.x; k < cand; k += gridDim.x) {
         const uint2* bucket; uint32_t* out; int n; uint64_t* alt; ObjOut oo;
+        if constexpr (SEG) {
+            static_assert(!SEG || !LAST, "segments fit the tier");
+            uint32_t pos;
+            sort_segment(views, tiles, queue[k], bucket, out, n, oo, pos);
+            if (n > 0) {                         // (n == 0: a reservation that did not fit the queue, see tile_partition_kernel)
+                if (!bucket_sort_tile<THREADS, E, NB>(lds, bucket, out, n, oo.n_env, oo.last, pos, oo.tie))
+                    merge_sort_tile<THREADS, E>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, pos, oo.tie, oo.inv);
+            }
+            __syncthreads();
+            continue;
+        }
         sort_item(views, tiles, queue[k], bucket, out, n, oo, &alt);
         {
             if constexpr (!LAST) {
@@ -993,6 +1256,145 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES) void tile_sort_long_kernel(cons
             }
         }
         __syncthreads();   // LDS reuse across loop iterations
+    }
+}
+
+// ---- split pre-pass (round 6): lists beyond the windowed sort -> depth segments for the 512 x 16 tier ----------------------
+// Rounds 1-5 sorted such a list inside the open-ended kernel: three passes over it (extremes, coarse histogram, counting-sort
+// scatter through the alt buffer) and then every segment one after the other in the same 1024-thread workgroup that holds
+// its CU alone (partition_sort_long).  The passes need 16 KiB of LDS, not 157: here they run four workgroups to a CU, cut
+// the list into segments of < 8192 keys (first bucket start at or beyond every multiple of 4096; no coarse bucket larger
+// than that) and hand every segment to the SEGMENT queue of the 512 x 16 tier's kernel (tile_sort_long_kernel<.., SEG>), two
+// workgroups per CU, all segments of all lists side by side.  What cannot be split (a piled-up coarse bucket, more than
+// PART_MAX_SEGMENTS segments, no room in the queue) goes to the open-ended kernel's queue as before.
+constexpr int PART_THREADS = 512;
+constexpr int SEG_HALF = 4096;                       // segments hold < 2 * SEG_HALF keys: the 512 x 16 tier's capacity
+
+__global__ __launch_bounds__(PART_THREADS) void tile_partition_kernel(const BinView* __restrict__ views, int tiles,
+                                                                       const uint4* __restrict__ queue,
+                                                                       const uint32_t* __restrict__ n_queue,
+                                                                       uint4* __restrict__ seg_queue, uint32_t* __restrict__ n_seg,
+                                                                       uint32_t seg_cap, uint4* __restrict__ open_queue,
+                                                                       uint32_t* __restrict__ n_open) {
+    constexpr int THREADS = PART_THREADS, WAVES = THREADS / WAVE, CH = PART_BUCKETS / (WAVES * WAVE), HALF = SEG_HALF, PB = 8;
+    static_assert(PART_BUCKETS % (WAVES * WAVE) == 0, "bucket count");
+    __shared__ uint32_t s_hist[PART_BUCKETS];             // counts -> starts -> cursors
+    __shared__ uint32_t s_misc[4 + WAVES];                // [0] min [1] max [2] largest bucket [3] queue slot [4..] wave totals
+    __shared__ uint32_t s_cut[PART_MAX_SEGMENTS + 3];     // segment g starts at s_cut[g]; n = not opened
+    const int t = threadIdx.x, lane = t & (WAVE - 1), wave = t / WAVE;
+    const uint32_t cand = *n_queue;
+    for (uint32_t k = blockIdx.x; k < cand; k += gridDim.x) {
+        const uint4 q = queue[k];
+        const uint2* bucket; uint32_t* out; int n; uint64_t* alt64; ObjOut oo;
+        sort_item(views, tiles, q, bucket, out, n, oo, &alt64);
+        uint2* const alt = reinterpret_cast<uint2*>(alt64);
+        bool ok = (n + HALF - 1) / HALF <= PART_MAX_SEGMENTS;        // (uniform)
+        if (ok) {
+            uint32_t dmin = 0xffffffffu, dmax = 0u;
+            for (int i0 = t; i0 < n; i0 += PB * THREADS) {
+                uint32_t dv[PB];
+#pragma unroll
+                for (int j = 0; j < PB; ++j) dv[j] = gload(&bucket[min(i0 + j * THREADS, n - 1)].x);   // (a clamped repeat changes no extreme)
+#pragma unroll
+                for (int j = 0; j < PB; ++j) { dmin = min(dmin, dv[j]); dmax = max(dmax, dv[j]); }
+            }
+            for (int i = t; i < PART_BUCKETS; i += THREADS) s_hist[i] = 0u;
+            if (t < 4 + WAVES) s_misc[t] = t == 0 ? 0xffffffffu : 0u;
+            if (t < PART_MAX_SEGMENTS + 3) s_cut[t] = (uint32_t)n;
+            __syncthreads();
+            dmin = ~wave_inclusive_max(~dmin);
+            dmax = wave_inclusive_max(dmax);
+            if (lane == WAVE - 1) { atomicMin(&s_misc[0], dmin); atomicMax(&s_misc[1], dmax); }
+            __syncthreads();
+            const uint32_t mn = s_misc[0];
+            const float scale = (float)PART_BUCKETS / ((float)(s_misc[1] - mn) + 1.0f);
+            auto coarse = [&](uint32_t d) { return min((uint32_t)((float)(d - mn) * scale), (uint32_t)(PART_BUCKETS - 1)); };
+            for (int i0 = t; i0 < n; i0 += PB * THREADS) {
+                uint32_t dv[PB];
+#pragma unroll
+                for (int j = 0; j < PB; ++j) dv[j] = gload(&bucket[min(i0 + j * THREADS, n - 1)].x);
+#pragma unroll
+                for (int j = 0; j < PB; ++j)
+                    if (i0 + j * THREADS < n) atomicAdd(&s_hist[coarse(dv[j])], 1u);
+            }
+            __syncthreads();
+            const int wbase = wave * (WAVE * CH);
+            uint32_t tot = 0, big = 0;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const uint32_t h = s_hist[wbase + c * WAVE + lane];
+                tot += h; big = max(big, h);
+            }
+            tot = wave_inclusive_scan(tot);
+            big = wave_inclusive_max(big);
+            if (lane == WAVE - 1) { s_misc[4 + wave] = tot; atomicMax(&s_misc[2], big); }
+            __syncthreads();
+            ok = s_misc[2] <= (uint32_t)HALF;
+            if (ok) {
+                uint32_t carry = 0;
+                for (int w = 0; w < wave; ++w) carry += s_misc[4 + w];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const uint32_t h = s_hist[wbase + c * WAVE + lane];
+                    const uint32_t incl = wave_inclusive_scan(h);
+                    const uint32_t s0 = carry + incl - h;
+                    s_hist[wbase + c * WAVE + lane] = s0;
+                    // segment g begins at the smallest bucket start >= g * HALF: bucket sizes <= HALF, so every g up to the
+                    // last one is hit and consecutive cuts are < 2 * HALF apart (empty buckets share their successor's start)
+                    const uint32_t g = (s0 + (uint32_t)HALF - 1u) / (uint32_t)HALF;
+                    if (s0 < (uint32_t)n) atomicMin(&s_cut[g], s0);
+                    carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+                }
+                __syncthreads();
+                // counting-sort scatter through the alt buffer (the starts become the cursors)
+                for (int i0 = t; i0 < n; i0 += PB * THREADS) {
+                    uint2 kv[PB];
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) kv[j] = gload(bucket + min(i0 + j * THREADS, n - 1));
+#pragma unroll
+                    for (int j = 0; j < PB; ++j)
+                        if (i0 + j * THREADS < n) gstore(alt + atomicAdd(&s_hist[coarse(kv[j].x)], 1u), kv[j]);
+                }
+                // the segments: g = 0 .. ceil(last start / HALF), without gaps (starts advance by <= HALF): that is
+                // ceil(n / HALF) of them, or one more; entry g = [s_cut[g], s_cut[g + 1]) (s_cut = n beyond the last one)
+                const uint32_t g_top = (uint32_t)((n + HALF - 1) / HALF);
+                const uint32_t n_segs = g_top + (s_cut[g_top] < (uint32_t)n ? 1u : 0u);
+                if (t == 0) s_misc[3] = gatomic_add(n_seg, n_segs);
+                __syncthreads();
+                const uint32_t slot = s_misc[3];
+                ok = slot + n_segs <= seg_cap;
+                if ((uint32_t)t < n_segs && slot + (uint32_t)t < seg_cap) {
+                    const uint32_t a = s_cut[t], b = s_cut[t + 1];
+                    // (no room for all of them: empty entries, and the whole list goes to the open-ended kernel)
+                    seg_queue[slot + (uint32_t)t] = make_uint4(q.x, q.y, ok && b > a ? b - a : 0u, a);
+                }
+            }
+        }
+        if (!ok && t == 0) open_queue[gatomic_add(n_open, 1u)] = q;
+        __syncthreads();                           // LDS reuse across the lists
+    }
+}
+
+// 8193 .. SORT_WINDOW_MAX keys: the windowed sort; a rejected list joins the open-ended tier's queue (launched afterwards)
+__global__ __launch_bounds__(SORT_WINDOW_THREADS, 4) void tile_sort_window_kernel(const BinView* __restrict__ views, int tiles,
+                                                                                   const uint4* __restrict__ queue,
+                                                                                   const uint32_t* __restrict__ n_queue,
+                                                                                   uint4* __restrict__ open_queue,
+                                                                                   uint32_t* __restrict__ n_open) {
+    constexpr size_t LDS_BYTES = SORT_WINDOW_LDS;
+    static_assert(2 * (LDS_BYTES + 64) <= 160 * 1024, "two workgroups per CU");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    __shared__ uint32_t s_win[2 * (SORT_WINDOW_ROUNDS + 1) + 2];
+    const uint32_t cand = *n_queue;
+    for (uint32_t k = blockIdx.x; k < cand; k += gridDim.x) {
+        const uint4 q = queue[k];
+        const uint2* bucket; uint32_t* out; int n; ObjOut oo;
+        sort_item(views, tiles, q, bucket, out, n, oo);
+        if (!window_sort_tile<SORT_WINDOW_THREADS, SORT_WINDOW_E, SORT_WINDOW_BUCKETS, SORT_WINDOW_KEYS>(
+                lds, s_win, bucket, out, n, oo.n_env, oo.last, oo.tie)) {
+            if (threadIdx.x == 0) open_queue[gatomic_add(n_open, 1u)] = q;
+        }
+        __syncthreads();
     }
 }
 

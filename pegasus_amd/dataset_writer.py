@@ -101,27 +101,43 @@ class BopSceneWriter:
         else:
             batch_futures.append(self._pool.submit(self._write, path, image))
 
-    def add_batch(self, frames: dict, scene_gt: dict, scene_camera: dict, n: int = None, silhouettes=None, frame_ids=None):
+    def add_batch(self, frames: dict, scene_gt: dict, scene_camera: dict, n: int = None, silhouettes=None, frame_ids=None,
+                  record_shape=None):
         """``frames``: FrameRenderer output (color, depth, and with masks: seg, masks); ``silhouettes``: uint8 [B,K,H,W]
         of FrameRenderer.render_silhouettes (or frames["sil"]) -> the mask/ directory.  ``frame_ids``: the frames' numbers in
         the dataset (default: consecutive) -- a view-sharded run gives every rank's writer the GLOBAL ids of its frames."""
         from . import masks as M
-        n = frames["color"].shape[0] if n is None else n
-        # GPU: uint8 HWC / uint16 millimetres for the whole batch in one launch (pgr_pack_frames), then ONE device->host copy
-        # per kind and batch
-        packed = M.pack_frames(color=frames["color"][:n], depth=frames["depth"][:n])
-        rgb8 = packed["rgb"].cpu().numpy()
-        mm = packed["depth_mm"].cpu().numpy().view(np.uint16)
-        mk = (frames["masks"][:n] * 255).cpu().numpy() if "masks" in frames else None
+        masks_dev = frames.get("masks")
+        if "color" in frames:
+            n = frames["color"].shape[0] if n is None else n
+            # GPU: uint8 HWC / uint16 millimetres for the whole batch in one launch (pgr_pack_frames), then ONE
+            # device->host copy per kind and batch
+            packed = M.pack_frames(color=frames["color"][:n], depth=frames["depth"][:n])
+            depth_mm_dev = packed["depth_mm"]
+            rgb8 = packed["rgb"].cpu().numpy()
+            mm = depth_mm_dev.cpu().numpy().view(np.uint16)
+        else:
+            # a records-only frame set (FrameRenderer.alloc_frames(images=False | "seg")): the compositor's epilogue wrote the
+            # casts already -- the record IS what the writers take
+            if record_shape is None:
+                raise ValueError("a frame set without images needs record_shape=(H, W, K)")
+            n = frames["records"].shape[0] if n is None else n
+            H, W, K = (int(v) for v in record_shape)
+            rv = M.record_views(frames["records"][:n], H, W, K)
+            depth_mm_dev = rv["depth_mm"]
+            rgb8 = rv["rgb"].cpu().numpy()
+            mm = depth_mm_dev.cpu().numpy().view(np.uint16)
+            masks_dev = M.unpack_mask_bits(rv["mask_bits"], K) if K else None
+        mk = (masks_dev[:n] * 255).cpu().numpy() if masks_dev is not None else None
         sem8 = M.pack_frames(color=frames["seg"][:n])["rgb"].cpu().numpy() if "seg" in frames else None
         if silhouettes is None:
             silhouettes = frames.get("sil")
         sil = (silhouettes[:n] * 255).cpu().numpy() if silhouettes is not None else None
         info = None
-        if silhouettes is not None and "masks" in frames:
+        if silhouettes is not None and masks_dev is not None:
             # BOP's scene_gt_info from the masks the batch already holds, counted on the GPU (a few hundred numbers per batch)
             from . import bop_pose
-            info = bop_pose.gt_info_from_masks(frames["masks"][:n], silhouettes[:n], packed["depth_mm"] != 0)
+            info = bop_pose.gt_info_from_masks(masks_dev[:n], silhouettes[:n], depth_mm_dev != 0)
         futures = []
         for i in range(n):
             fid = self.n_frames if frame_ids is None else int(frame_ids[i])

@@ -99,11 +99,22 @@ class FrameRenderer:
                           t(view.world_view_transform), t(view.full_proj_transform), t(view.camera_center),
                           depth_mode=int(depth_mode))
 
-    def alloc_frames(self, batch: int, height: int, width: int, masks: bool = True, records: bool = False):
+    def alloc_frames(self, batch: int, height: int, width: int, masks: bool = True, records: bool = False,
+                     images: bool = True):
         """``records``: also a uint8 [batch, record bytes] tensor the compositor's epilogue fills with every frame's RECORD
         (uint8 RGB | uint16 depth mm | the K masks as bit planes: masks.record_layout / record_views) -- what leaves the GPU
-        for a finished frame, without a pass that re-reads the images."""
+        for a finished frame, without a pass that re-reads the images.  ``images=False`` (with records): a RECORDS-ONLY frame
+        set -- no fp32 images, no mask planes; the compositor writes 3.84 MB per 800x800 frame instead of 29.4 MB (a rank of
+        a view-sharded job: nothing there reads the planes).  ``images="seg"``: the records plus the semantic image (a
+        dataset writer: its sem_mask PNG is the one product the record does not carry)."""
         dev = self.device
+        if images is not True:               # False, or "seg": the record + the semantic image (the writers' sem_mask PNG)
+            if not records:
+                raise ValueError("a frame set without images needs records")
+            f = dict(records=torch.empty((batch, self.record_bytes(height, width, masks)), dtype=torch.uint8, device=dev))
+            if images == "seg" and masks and self.K:
+                f["seg"] = torch.empty((batch, 3, height, width), device=dev)
+            return f
         f = dict(color=torch.empty((batch, 3, height, width), device=dev),
                  depth=torch.empty((batch, 1, height, width), device=dev))
         if masks and self.K:
@@ -113,6 +124,18 @@ class FrameRenderer:
         if records:
             f["records"] = torch.empty((batch, self.record_bytes(height, width, masks)), dtype=torch.uint8, device=dev)
         return f
+
+    @staticmethod
+    def _outs(frames: dict, B: int, fused: bool):
+        """Per-view output dicts of a frame set; a records-only set (alloc_frames(images=False)) names no image."""
+        if "color" not in frames:
+            return [dict(radii=None, **({"sem_color": frames["seg"][i]} if fused and "seg" in frames else {})) for i in range(B)]
+        outs = [dict(color=frames["color"][i], depth=frames["depth"][i], radii=None) for i in range(B)]
+        if fused:
+            for i in range(B):
+                outs[i]["sem_color"], outs[i]["sem_depth"] = frames["seg"][i], frames["seg_depth"][i]
+                outs[i]["sem_masks"] = frames["masks"][i]
+        return outs
 
     def record_bytes(self, height: int, width: int, masks: bool = True) -> int:
         return M.record_layout(height, width, self.K if masks else 0)["bytes"]
@@ -154,11 +177,7 @@ class FrameRenderer:
         if st is None:
             st = self._slot_streams[skey] = torch.cuda.Stream(dev)
         fused = masks and self.K > 0
-        outs = [dict(color=frames["color"][i], depth=frames["depth"][i], radii=None) for i in range(B)]
-        if fused:
-            for i in range(B):
-                outs[i]["sem_color"], outs[i]["sem_depth"] = frames["seg"][i], frames["seg_depth"][i]
-                outs[i]["sem_masks"] = frames["masks"][i]
+        outs = self._outs(frames, B, fused)
         if records is not None:
             if records.shape[1] < self.record_bytes(int(specs[0].image_height), int(specs[0].image_width), fused) or records.stride(0) % 16:
                 raise ValueError("records: rows of at least record_bytes(H, W, masks) bytes with a 16-byte-aligned stride")
@@ -248,11 +267,7 @@ class FrameRenderer:
         if frames is None:
             frames = self.alloc_frames(B, H, W, masks)
         fused = masks and self.K > 0
-        outs = [dict(color=frames["color"][i], depth=frames["depth"][i], radii=None) for i in range(B)]
-        if fused:
-            for i in range(B):
-                outs[i]["sem_color"], outs[i]["sem_depth"] = frames["seg"][i], frames["seg_depth"][i]
-                outs[i]["sem_masks"] = frames["masks"][i]
+        outs = self._outs(frames, B, fused)
         if "records" in frames:
             for i in range(B):
                 outs[i]["record"] = frames["records"][i]

@@ -67,7 +67,7 @@ def main():
     t0 = time.perf_counter()
     t_gpu = 0.0
     mine = list(range(rank, args.frames, world))          # frame f -> rank f mod world
-    seq_tables = seq_motion = None
+    seq_tables = seq_motion = frame_set = None
     for b0 in range(0, len(mine), args.batch):
         ids = mine[b0:b0 + args.batch]
         vs = [views[f] for f in ids]
@@ -81,12 +81,17 @@ def main():
             poses, m2w = seq_tables[idx], [seq_motion[i] for i in idx]
         t1 = time.perf_counter()
         specs = [fr.view_spec(v) for v in vs]
-        frames = fr.render_frames(specs, poses=poses)
+        # records-only frames: the compositor's epilogue writes what the writers take (uint8 RGB, uint16 mm, mask bits) and
+        # the semantic image; no fp32 colour / depth image, no mask plane (3.84 + 7.68 MB per frame instead of 29.4)
+        H, W = int(specs[0].image_height), int(specs[0].image_width)
+        if frame_set is None or frame_set["records"].shape[0] != len(vs):
+            frame_set = fr.alloc_frames(len(vs), H, W, records=True, images="seg")
+        frames = fr.render_frames(specs, frames=frame_set, poses=poses)
         sil = fr.render_silhouettes(specs, poses=poses) if fr.K else None          # 'seg_sil': one layered pass for all objects
         torch.cuda.synchronize(device)
         t_gpu += time.perf_counter() - t1
         gt, cam = bop_pose.batch_pose_records(vs, m2w, boxes=boxes)
-        w.add_batch(frames, gt, cam, n=len(vs), silhouettes=sil, frame_ids=ids)
+        w.add_batch(frames, gt, cam, n=len(vs), silhouettes=sil, frame_ids=ids, record_shape=(H, W, fr.K))
     scene = w.close(write_json=False)
     if world > 1:
         import torch.distributed as dist

@@ -78,7 +78,26 @@ def test_semantic_descriptor_is_checked_before_any_enqueue(gpu_device):
                  radii=None)]                                   # no sem_color target
     with pytest.raises(ValueError, match="invalid argument"):
         R.forward_views(act["means3d"], act["opacities"], [spec], semantic=good, outputs=outs, **kw)
+    # records-only views (round 6): no image at all is fine WITH a record -- but the semantic image can only be left out when
+    # the descriptor names the colours its mask planes are thresholded against; depth without colour is no shape at all
+    from pegasus_amd import masks as M
+    rec = lambda k: torch.empty((M.record_layout(v.height, v.width, k)["bytes"],), dtype=torch.uint8, device=dev)
+    with pytest.raises(ValueError, match="invalid argument"):
+        R.forward_views(act["means3d"], act["opacities"], [spec], outputs=[dict(radii=None)], **kw)                # nothing to write
+    with pytest.raises(ValueError, match="invalid argument"):
+        R.forward_views(act["means3d"], act["opacities"], [spec], semantic=good, outputs=[dict(radii=None, record=rec(0))], **kw)
+    with pytest.raises(ValueError, match="invalid argument"):
+        R.forward_views(act["means3d"], act["opacities"], [spec],
+                        outputs=[dict(radii=None, record=rec(0), depth=torch.empty((1, v.height, v.width), device=dev))], **kw)
+    r0 = dict(radii=None, record=rec(0))
+    R.forward_views(act["means3d"], act["opacities"], [spec], outputs=[r0], **kw)                                  # raster-only record
+    withm = dict(good, mask_colors=torch.tensor([[0.2, 0.7, 0.4]], device=dev), mask_threshold=0.1)
+    r1 = dict(radii=None, record=rec(1))
+    R.forward_views(act["means3d"], act["opacities"], [spec], semantic=withm, outputs=[r1], **kw)
     torch.cuda.synchronize()
+    want = M.pack_records(ok["color"][None], ok["depth"][None])
+    assert torch.equal(M.record_views(r0["record"], v.height, v.width, 0)["rgb"], M.record_views(want[0], v.height, v.width, 0)["rgb"])
+    assert torch.equal(M.record_views(r1["record"], v.height, v.width, 1)["rgb"], M.record_views(want[0], v.height, v.width, 0)["rgb"])
     again = R.forward_views(act["means3d"], act["opacities"], [spec], semantic=good, **kw)[0]
     torch.cuda.synchronize()
     assert torch.equal(again["sem_color"], ok["sem_color"])

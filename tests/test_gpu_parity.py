@@ -464,6 +464,44 @@ def test_tie_index_order_on_long_lists(oracle, gpu_device, n, spread, equal):
     assert np.abs(res[0]["color"].cpu().numpy() - o["color"])[:, ~amb].max() <= 1e-4
 
 
+@pytest.mark.parametrize("n,pairs", [(9000, 300), (12000, 40), (15800, 1500)])
+def test_windowed_sort_with_scattered_depth_ties(oracle, gpu_device, n, pairs):
+    """The windowed sort (8193..15 872 keys, tilebin.hip.h window_sort_tile) in a three-view batch with `pairs` groups of two
+    or three Gaussians at exactly equal depth spread over the list (a few keys per bucket share their depth: the in-bucket
+    tie-break by the caller's tie_index runs, the list is NOT rejected) -- positions and tie indices both shuffled."""
+    import torch
+    from helpers import fetch_workspace
+    from pegasus_amd import rasterizer as R
+    rng = np.random.default_rng(n + pairs)
+    cloud, views = scenes.scene_c1(seed=9, n=n)
+    cloud.xyz[:, 0] = np.float32(0.0929) + rng.normal(0, 5e-4, n).astype(np.float32)
+    cloud.xyz[:, 1] = np.float32(0.0929) + rng.normal(0, 5e-4, n).astype(np.float32)
+    cloud.xyz[:, 2] = rng.normal(0, 0.2, n).astype(np.float32)
+    src = rng.choice(n, 3 * pairs, replace=False)
+    cloud.xyz[src[pairs:2 * pairs], 2] = cloud.xyz[src[:pairs], 2]
+    cloud.xyz[src[2 * pairs::2], 2] = cloud.xyz[src[:pairs:2][: len(src[2 * pairs::2])], 2]
+    cloud.xyz[src, 0] = np.float32(0.0929); cloud.xyz[src, 1] = np.float32(0.0929)            # same ray: same view depth
+    cloud.scaling[:] = np.log(0.0005).astype(np.float32)
+    cloud.opacity[:] = rng.normal(-3.0, 0.5, size=(n, 1)).astype(np.float32)
+    tie = rng.permutation(n).astype(np.int32)
+    act, v = cloud.activated(), views[0]
+    o = oracle.forward(**act, sh_degree=3, **v.raster_kwargs(), num_threads=8, cull_mode=1, tie_index=tie)
+    o_pos = oracle.forward(**act, sh_degree=3, **v.raster_kwargs(), num_threads=8, cull_mode=1)
+    lens = o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]
+    assert lens.max() == n, lens.max()
+    assert not np.array_equal(o["gauss_sorted"], o_pos["gauss_sorted"])                      # the ties are real
+    t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(gpu_device, dt)
+    spec = R.ViewSpec(v.height, v.width, v.tanfovx, v.tanfovy, t(np.zeros(3, np.float32)), t(v.world_view_transform),
+                      t(v.full_proj_transform), t(v.camera_center))
+    for tie_arg, want in ((t(tie, torch.int32), o), (None, o_pos)):
+        R.forward_views(t(act["means3d"]), t(act["opacities"]), [spec] * 3, shs=t(act["shs"]), scales=t(act["scales"]),
+                        rotations=t(act["rotations"]), sh_degree=3, want_radii=True, want_aux=True, tie_index=tie_arg)
+        torch.cuda.synchronize()
+        for k in range(3):
+            w = fetch_workspace(k, n, v.width, v.height)
+            np.testing.assert_array_equal(w["gauss_sorted"], want["gauss_sorted"], err_msg=f"view {k}")
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_hostile_inputs_do_not_fault_and_match_oracle(oracle, gpu_device, seed):
     """NaN / Inf positions, huge and vanishing scales, opacity exactly 0 and 1, zero and unnormalised quaternions,
@@ -861,6 +899,19 @@ def test_frame_records_from_the_compositor_equal_pack_records(gpu_device, size):
             assert torch.equal(got[k], ref[k]), (masks, mode, k)
         g = fr.render_frames(specs, fr.alloc_frames(4, h, w, masks=masks, records=True), masks=masks)      # the blocking form too
         assert all(torch.equal(M.record_views(g["records"], h, w, fr.K if masks else 0)[k], ref[k]) for k in ref)
+        # RECORDS-ONLY views (round 6: PgrOutputs color = depth = sem_* = NULL, what a rank of a view-sharded job asks for): the
+        # same record, no image written; and records + the semantic image alone (the dataset writer's frame set)
+        for images in (False, "seg"):
+            ro = fr.alloc_frames(4, h, w, masks=masks, records=True, images=images)
+            assert "color" not in ro and "masks" not in ro and ("seg" in ro) == (images == "seg" and masks)
+            ro["records"].fill_(0xCD)
+            fr.render_frames_async(specs, ro, masks=masks, slot=0).wait()
+            torch.cuda.synchronize()
+            got = M.record_views(ro["records"], h, w, fr.K if masks else 0)
+            for k in ref:
+                assert torch.equal(got[k], ref[k]), ("records only", images, masks, mode, k)
+            if "seg" in ro:
+                assert torch.equal(ro["seg"], f["seg"])
     rasterizer.reset_capacity(1500)
     specs = [fr.view_spec(v) for v in views]
     f = fr.alloc_frames(4, h, w, records=True)
@@ -868,6 +919,12 @@ def test_frame_records_from_the_compositor_equal_pack_records(gpu_device, size):
     torch.cuda.synchronize()
     want = M.pack_records(f["color"], f["depth"], f["masks"])
     ref, got = M.record_views(want, h, w, fr.K), M.record_views(f["records"], h, w, fr.K)
+    assert all(torch.equal(got[k], ref[k]) for k in ref)
+    rasterizer.reset_capacity(1500)                        # the overflow re-render of a records-only batch
+    ro = fr.alloc_frames(4, h, w, records=True, images=False)
+    fr.render_frames_async(specs, ro, slot=1).wait()
+    torch.cuda.synchronize()
+    got = M.record_views(ro["records"], h, w, fr.K)
     assert all(torch.equal(got[k], ref[k]) for k in ref)
 
 
@@ -897,10 +954,14 @@ def test_tiny_and_ragged_images_through_the_round4_outputs(gpu_device, size):
 
 
 @pytest.mark.parametrize("ties", [True, False])
-@pytest.mark.parametrize("n", [1, 2, 512, 513, 1024, 1025, 2048, 2049, 4096, 4097, 8192, 8193, 16000, 16001, 16384, 16385])
+@pytest.mark.parametrize("n", [1, 2, 512, 513, 1024, 1025, 2048, 2049, 4096, 4097, 8192, 8193, 7936, 7937, 12000, 15872, 15873,
+                               16000, 16001, 16384, 16385, 20481, 33000, 70000])
 def test_sort_tier_boundaries(oracle, gpu_device, n, ties):
     """ONE tile list of exactly n keys, n on both sides of every capacity edge of the per-tile sort (256 x 2 / 4 / 8 keys,
-    512 x 8, 512 x 16 over 3584 buckets, the 16 000-key LDS image of the open-ended tier, 16 384 = its register capacity):
+    512 x 8, 512 x 16 over 3584 buckets, the windowed sort of 8193..15 872 keys -- one window up to 7936 positions, two
+    beyond; with `ties` its reject path into the open-ended kernel's queue --, beyond 15 872 keys the split pre-pass whose depth
+    segments the 512 x 16 kernel sorts from the segment queue (with `ties`: a piled-up coarse bucket, the list falls back to the
+    open-ended kernel), the 16 000-key LDS image of the open-ended kernel, 16 384 = its register capacity):
     n pinpoint splats inside one tile -- with a third of them at exactly equal depth (`ties`: the pile-up rejects the bucket
     sort, so every tier's merge-sort fallback and the index tie-break run) or all depths distinct (the bucket sort itself at
     exactly its capacity).  As a one-view call (every long list goes to the open-ended tier's kernel) and as a three-view

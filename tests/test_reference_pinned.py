@@ -198,7 +198,9 @@ def test_gpu_gaussian_model_equals_the_reference_class(gpu_device):
         np.testing.assert_array_equal(getattr(a, name).cpu().numpy(), g["a." + name])
     for name in ("get_scaling", "get_rotation", "get_opacity"):                      # device exp / sigmoid / rsqrt: 1 ulp
         np.testing.assert_allclose(getattr(a, name).cpu().numpy(), g["a." + name], rtol=3e-7, atol=1e-9, err_msg=name)
-    np.testing.assert_allclose(a.get_covariance(1.7).cpu().numpy(), g["a.get_covariance_1.7"], rtol=2e-6, atol=1e-10)
+    # (off-diagonal terms are differences of products: absolute error of the largest entry)
+    np.testing.assert_allclose(a.get_covariance(1.7).cpu().numpy(), g["a.get_covariance_1.7"], rtol=2e-6,
+                               atol=2e-6 * float(np.abs(g["a.get_covariance_1.7"]).max()))
     m = copy.deepcopy(a)
     m.merge_gaussians(b)
     for k in RAW:
