@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PGR_ABI_VERSION 2
+#define PGR_ABI_VERSION 3
 #define PGR_TILE_SIZE 16
 
 typedef enum PgrStatus {
@@ -311,6 +311,43 @@ typedef struct PgrObjectPose {
 int32_t pgr_compose_object(int32_t n, const float *xyz, const float *rot, const float *f_rest, int32_t n_rest,
                            int32_t in_rest_stride, const PgrObjectPose *pose, float *out_xyz, float *out_rot,
                            float *out_rest, int32_t out_rest_stride, void *stream);
+
+/* The pose calls of a whole frame (round 6).  PEGASUS re-poses every object between two frames of a dynamic sequence with
+ * three calls per object -- apply_transformation_on_xyz(T), apply_rotation_on_splats(R), apply_rotation_on_sh(R):
+ * /root/reference/src/gs/pegasus_setup.py:195-208 -> /root/reference/src/gs/gaussian_model.py:482-546 -- each handed a
+ * rotation / translation that already lives on the device.  One JOB per (object, array); R and t stay DEVICE pointers (no
+ * host round trip, unlike PgrObjectPose), the cloud's mean, the quaternion of R and the SH band matrices are derived on the
+ * device:
+ *   PGR_POSE_XYZ   dst[i] = R (src[i] - c) + c + t,  c = the mean of src (about_origin = 0) or 0      src, dst [n,3]
+ *   PGR_POSE_ROT   dst[i] = quat(R) (x) normalise(src[i])                              (w,x,y,z)       src, dst [n,4]
+ *   PGR_POSE_SH    dst[i] = band-wise D_l(R) src[i],  D_l = pinv(B_l) B_l(R^T d_k)                     src, dst [n,n_rest,3]
+ * R = NULL: identity; t = NULL: zero.  R and t may point INTO a 4x4 transform (strides below): PEGASUS builds T on the device and
+ * hands its corner and last column over.  src == dst is allowed.  Jobs of one call must not depend on each other.
+ * sh_dirs [61,3] / sh_pinv [15,61]: device fp64 tables of the SH sample directions and the three bands' pseudo-inverses
+ * (pegasus_amd/sh_rotation.py builds them for the rasterizer's basis; needed only if a job is PGR_POSE_SH).
+ * workspace: pgr_pose_objects_workspace_bytes(n_jobs) bytes of device memory. */
+typedef enum PgrPoseKind { PGR_POSE_XYZ = 0, PGR_POSE_ROT = 1, PGR_POSE_SH = 2 } PgrPoseKind;
+typedef struct PgrPoseJob {
+    const float *src;
+    float *dst;
+    const float *R;              /* device, row-major: R[r][c] at R[r * R_row_stride + c] */
+    const float *t;              /* device: t[c] at t[c * t_stride] */
+    int32_t n;
+    int32_t kind;                /* PgrPoseKind */
+    int32_t n_rest;              /* PGR_POSE_SH: coefficients per Gaussian, 3, 8 or 15 */
+    int32_t about_origin;        /* PGR_POSE_XYZ */
+    int32_t R_row_stride;        /* floats between the rows of R: 3 = a contiguous 3x3, 4 = the corner of a 4x4 */
+    int32_t t_stride;            /* floats between the components of t: 1 = contiguous, 4 = the last column of a 4x4 */
+} PgrPoseJob;
+size_t pgr_pose_objects_workspace_bytes(int32_t n_jobs);
+int32_t pgr_pose_objects(int32_t n_jobs, const PgrPoseJob *jobs, const double *sh_dirs, const double *sh_pinv,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* Measurement aid (bench.py's roofline.issue_model; replaces nothing of the reference): ONE wave that reads its two clocks
+ * around a sleep loop of spin_us microseconds -- ticks[0] = shader cycles (s_memtime), ticks[1] = 100 MHz ticks
+ * (s_memrealtime) -- so ticks[0] / ticks[1] x 100 MHz is the shader clock under whatever runs beside it on other streams.
+ * `ticks`: device uint64[2]. */
+int32_t pgr_clock_probe(uint64_t *ticks, uint32_t spin_us, void *stream);
 
 /* Mean squared distance to the 3 nearest neighbours of every point (replaces simple_knn._C.distCUDA2 of the reference's
  * second absent submodule: GaussianModel.create_from_pcd, /root/reference/src/gs/gaussian_model.py:25,147).  Exact

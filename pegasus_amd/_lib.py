@@ -14,7 +14,7 @@ import os
 # from build_variants/ instead of overwriting the product .so)
 LIB_PATH = Path(os.environ.get("PGR_LIB") or Path(__file__).resolve().parent / "csrc" / "libpegasus_raster.so")
 
-PGR_ABI_VERSION = 2          # include/pegasus_raster.h PGR_ABI_VERSION
+PGR_ABI_VERSION = 3          # include/pegasus_raster.h PGR_ABI_VERSION
 PGR_OK = 0
 PGR_ERR_INVALID_ARGUMENT = -1
 PGR_ERR_WORKSPACE_TOO_SMALL = -2
@@ -78,6 +78,15 @@ class PgrObjectPose(C.Structure):
                 ("D1", C.c_float * 9), ("D2", C.c_float * 25), ("D3", C.c_float * 49)]
 
 
+class PgrPoseJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("R", C.c_void_p), ("t", C.c_void_p), ("n", C.c_int32),
+                ("kind", C.c_int32), ("n_rest", C.c_int32), ("about_origin", C.c_int32), ("R_row_stride", C.c_int32),
+                ("t_stride", C.c_int32)]
+
+
+PGR_POSE_XYZ, PGR_POSE_ROT, PGR_POSE_SH = 0, 1, 2
+
+
 class PgrGradOutputs(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("means2d", "means3d", "opacities", "colors", "shs", "cov3d", "scales",
                                           "rotations")]
@@ -132,6 +141,10 @@ SYMBOLS = {
     "pgr_compose_object": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                        C.POINTER(PgrObjectPose), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                        C.c_void_p]),
+    "pgr_clock_probe": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "pgr_pose_objects_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "pgr_pose_objects": (C.c_int32, [C.c_int32, C.POINTER(PgrPoseJob), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p]),
     "pgr_block_visibility_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "pgr_block_visibility": (C.c_int32, [C.POINTER(PgrScene), C.c_int32, C.POINTER(PgrCamera), C.c_void_p, C.c_size_t,
                                          C.c_void_p, C.c_void_p]),

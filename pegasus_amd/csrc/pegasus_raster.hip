@@ -470,7 +470,7 @@ using namespace pgr;
 extern "C" {
 
 int32_t pgr_abi_version(void) { return PGR_ABI_VERSION; }
-const char* pgr_version(void) { return "pegasus_raster 0.8 (gfx950)"; }
+const char* pgr_version(void) { return "pegasus_raster 0.9 (gfx950)"; }
 
 const char* pgr_status_string(int32_t status) {
     switch (status) {
@@ -686,6 +686,70 @@ int32_t pgr_compose_object(int32_t n, const float* xyz, const float* rot, const 
     compose_object_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream_v)>>>(
         n, xyz, rot, f_rest, n_rest, in_rest_stride, P, out_xyz, out_rot, out_rest, out_rest_stride);
     return hip_ok(hipGetLastError(), "compose_object launch") ? PGR_OK : PGR_ERR_LAUNCH_FAILURE;
+}
+
+// one wave that watches both of its clocks for spin_us microseconds: s_memtime ticks once per SHADER cycle, s_memrealtime
+// at a constant 100 MHz (MI355X_MICROARCH.md "Per-instruction cycle constants"), so ticks[0] / ticks[1] x 100 MHz is the
+// clock the chip ran at while whatever else was resident ran beside it
+__global__ void clock_probe_kernel(unsigned long long* __restrict__ ticks, uint32_t spin_us) {
+    const unsigned long long r0 = wall_clock64();
+    const unsigned long long c0 = __builtin_readcyclecounter();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < (unsigned long long)spin_us * 100ull) {
+        __builtin_amdgcn_s_sleep(8);
+        r1 = wall_clock64();
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) { ticks[0] = c1 - c0; ticks[1] = r1 - r0; }
+}
+
+int32_t pgr_clock_probe(uint64_t* ticks, uint32_t spin_us, void* stream_v) {
+    if (!ticks || spin_us == 0 || spin_us > 1000000u) return PGR_ERR_INVALID_ARGUMENT;
+    clock_probe_kernel<<<1, WAVE, 0, static_cast<hipStream_t>(stream_v)>>>(reinterpret_cast<unsigned long long*>(ticks), spin_us);
+    return hip_ok(hipGetLastError(), "clock_probe launch") ? PGR_OK : PGR_ERR_LAUNCH_FAILURE;
+}
+
+size_t pgr_pose_objects_workspace_bytes(int32_t n_jobs) {
+    if (n_jobs <= 0) return 0;
+    const size_t launches = ((size_t)n_jobs + POSE_JOBS_PER_LAUNCH - 1) / POSE_JOBS_PER_LAUNCH;
+    return launches * (align_up((size_t)POSE_JOBS_PER_LAUNCH * POSE_REDUCE_BLOCKS * 3 * sizeof(double)) +
+                       align_up((size_t)POSE_JOBS_PER_LAUNCH * sizeof(ObjectPoseDev)));
+}
+
+int32_t pgr_pose_objects(int32_t n_jobs, const PgrPoseJob* jobs, const double* sh_dirs, const double* sh_pinv,
+                         void* workspace, size_t workspace_bytes, void* stream_v) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return PGR_ERR_INVALID_ARGUMENT;
+    if (n_jobs == 0) return PGR_OK;
+    for (int k = 0; k < n_jobs; ++k) {
+        const PgrPoseJob& j = jobs[k];
+        if (j.n < 0 || (j.n > 0 && (!j.src || !j.dst)) || j.kind < PGR_POSE_XYZ || j.kind > PGR_POSE_SH ||
+            (j.kind == PGR_POSE_SH && ((j.n_rest != 3 && j.n_rest != 8 && j.n_rest != 15) || !sh_dirs || !sh_pinv)))
+            return PGR_ERR_INVALID_ARGUMENT;
+    }
+    if (!workspace || workspace_bytes < pgr_pose_objects_workspace_bytes(n_jobs)) return PGR_ERR_WORKSPACE_TOO_SMALL;
+    char* ws = static_cast<char*>(workspace);
+    const size_t part_bytes = align_up((size_t)POSE_JOBS_PER_LAUNCH * POSE_REDUCE_BLOCKS * 3 * sizeof(double));
+    const size_t per_launch = part_bytes + align_up((size_t)POSE_JOBS_PER_LAUNCH * sizeof(ObjectPoseDev));
+    for (int k0 = 0, launch = 0; k0 < n_jobs; k0 += POSE_JOBS_PER_LAUNCH, ++launch) {
+        PoseJobTable T{};
+        T.count = std::min(POSE_JOBS_PER_LAUNCH, n_jobs - k0);
+        uint32_t blocks = 0;
+        bool reduce = false;
+        for (int k = 0; k < T.count; ++k) {
+            const PgrPoseJob& j = jobs[k0 + k];
+            T.job[k] = PoseJobDev{j.src, j.dst, j.R, j.t, j.n, j.kind, j.n_rest, j.about_origin,
+                                  j.R_row_stride > 0 ? j.R_row_stride : 3, j.t_stride > 0 ? j.t_stride : 1, blocks};
+            blocks += (uint32_t)((j.n + 255) / 256);
+            reduce = reduce || (j.kind == PGR_POSE_XYZ && !j.about_origin && j.R && j.n > 0);
+        }
+        auto* partial = reinterpret_cast<double*>(ws + (size_t)launch * per_launch);
+        auto* poses = reinterpret_cast<ObjectPoseDev*>(ws + (size_t)launch * per_launch + part_bytes);
+        if (reduce) pose_reduce_kernel<<<dim3(POSE_REDUCE_BLOCKS, T.count), 256, 0, stream>>>(T, partial);
+        pose_prepare_kernel<<<T.count, 128, 0, stream>>>(T, partial, sh_dirs, sh_pinv, poses);
+        if (blocks) pose_apply_kernel<<<blocks, 256, 0, stream>>>(T, poses);
+    }
+    return hip_ok(hipGetLastError(), "pose_objects launch") ? PGR_OK : PGR_ERR_LAUNCH_FAILURE;
 }
 
 size_t pgr_block_visibility_workspace_bytes(int32_t n, int32_t n_views) {

@@ -12,7 +12,7 @@ import copy
 import numpy as np
 import torch
 
-from . import compose
+from . import compose, pose_queue
 from .ply_io import read_ply_vertices, write_ply_vertices
 
 
@@ -40,7 +40,31 @@ def inverse_sigmoid(x):
     return torch.log(x / (1 - x))
 
 
+def _posed_attribute(name):
+    """_xyz / _rotation / _features_rest: what the pose calls change.  Reading or writing one applies the recorded pose
+    calls first (pegasus_amd/pose_queue.py); the tensor itself lives in the instance dictionary under the same name."""
+    def get(self):
+        d = self.__dict__
+        if d.get("_pose_ops"):
+            pose_queue.flush_all()
+        try:
+            return d[name]
+        except KeyError:
+            raise AttributeError(name) from None
+
+    def put(self, value):
+        d = self.__dict__
+        if d.get("_pose_ops"):
+            pose_queue.flush_all()
+        d[name] = value
+    return property(get, put)
+
+
 class GaussianModel:
+    _xyz = _posed_attribute("_xyz")
+    _rotation = _posed_attribute("_rotation")
+    _features_rest = _posed_attribute("_features_rest")
+
     def __init__(self, sh_degree: int, device="cuda"):
         self.active_sh_degree = 0
         self.max_sh_degree = sh_degree
@@ -125,10 +149,24 @@ class GaussianModel:
         write_ply_vertices(path, cols)
 
     # ---- scene composition (reference :482-623)
+    def _defers(self, *pose_tensors) -> bool:
+        """A pose call is RECORDED (pose_queue.py) when the model lives on a HIP device, nothing of it is tracked by autograd
+        and the pose arrives as a device tensor (what PEGASUS hands over); otherwise it is applied at once."""
+        x = self.__dict__.get("_xyz")
+        return (pose_queue.enabled() and isinstance(x, torch.Tensor) and x.is_cuda and not x.requires_grad
+                and not self.__dict__["_rotation"].requires_grad and not self.__dict__["_features_rest"].requires_grad
+                and all(torch.is_tensor(p) and p.is_cuda and not p.requires_grad for p in pose_tensors))
+
     def apply_translation_on_xyz(self, t):
+        if self.__dict__.get("_pose_ops") and self._defers(t) and t.numel() == 3:
+            pose_queue.record(self, pose_queue.TRANSLATE, t=pose_queue.private_copy(t))     # rides with the pending rotation
+            return
         self._xyz = self._xyz + torch.as_tensor(t).to(self._xyz.device).type(torch.float32)
 
     def apply_rotation_on_xyz(self, R, origin=False):
+        if self._defers(R) and tuple(R.shape) == (3, 3):
+            pose_queue.record(self, pose_queue.ROT_XYZ, R=pose_queue.private_copy(R), origin=origin)
+            return
         R = torch.as_tensor(R).to(self._xyz.device).type(torch.float32)
         if not origin:
             mean_xyz = torch.mean(self._xyz, 0)
@@ -137,6 +175,12 @@ class GaussianModel:
             self._xyz = (R @ self._xyz.T).T
 
     def apply_transformation_on_xyz(self, T):
+        if self._defers(T) and tuple(T.shape) == (4, 4):
+            # ONE private copy of T; its corner and last column are addressed in place (row stride 4)
+            Tc = pose_queue.private_copy(T)
+            pose_queue.record(self, pose_queue.ROT_XYZ, R=Tc, R_stride=4)
+            pose_queue.record(self, pose_queue.TRANSLATE, t=Tc[:3, 3], t_stride=4)
+            return
         self.apply_rotation_on_xyz(R=T[:3, :3])
         self.apply_translation_on_xyz(t=T[:3, 3])
 
@@ -181,6 +225,9 @@ class GaussianModel:
     def apply_rotation_on_splats(self, R):
         """q' = q_R (x) q for every splat (reference :496-505).  Orientation only: no rotation centre is needed, so the
         object's mean is not fetched to the host (rounds 1-4 did, a device round trip per call)."""
+        if self._defers(R) and tuple(R.shape) == (3, 3):
+            pose_queue.record(self, pose_queue.ROT_SPLATS, R=pose_queue.private_copy(R))
+            return
         out_rot = torch.empty_like(self._rotation)
         compose.compose_object(self._xyz.contiguous(), self._rotation.contiguous(), None, self._rotation_pose(R),
                                torch.empty_like(self._xyz), out_rot, None)
@@ -188,6 +235,9 @@ class GaussianModel:
 
     def apply_rotation_on_sh(self, R):
         """SH bands 1-3 rotated with the object (reference :507-546)."""
+        if self._defers(R) and tuple(R.shape) == (3, 3):
+            pose_queue.record(self, pose_queue.ROT_SH, R=pose_queue.private_copy(R))
+            return
         out_rest = torch.empty_like(self._features_rest)
         compose.compose_object(self._xyz.contiguous(), None, self._features_rest.contiguous(), self._rotation_pose(R),
                                torch.empty_like(self._xyz), None, out_rest)
@@ -195,6 +245,13 @@ class GaussianModel:
 
     def apply_transformation(self, T):
         """xyz, splat orientation and SH in ONE device pass (reference: three methods, two host round trips)."""
+        if self._defers(T) and tuple(T.shape) == (4, 4):
+            Tc = pose_queue.private_copy(T)
+            pose_queue.record(self, pose_queue.ROT_XYZ, R=Tc, R_stride=4)
+            pose_queue.record(self, pose_queue.TRANSLATE, t=Tc[:3, 3], t_stride=4)
+            pose_queue.record(self, pose_queue.ROT_SPLATS, R=Tc, R_stride=4)
+            pose_queue.record(self, pose_queue.ROT_SH, R=Tc, R_stride=4)
+            return
         Tn = np.asarray(torch.as_tensor(T).detach().cpu().numpy(), dtype=np.float64)
         pose = compose.make_pose(Tn, self._xyz.double().mean(0).cpu().numpy())
         xyz, rot, rest = torch.empty_like(self._xyz), torch.empty_like(self._rotation), torch.empty_like(self._features_rest)
@@ -253,6 +310,8 @@ class GaussianModel:
         """copy.deepcopy(model): what PEGASUS's frame loop does with the environment before merging the objects into the copy
         (pegasus.py:255-256).  Same result as the default -- every tensor cloned, everything else deep-copied -- with the row
         attributes cloned into buffers that leave room for the merges that follow."""
+        if self.__dict__.get("_pose_ops"):
+            pose_queue.flush_all()                   # (the copy below reads the instance dictionary, not the attributes)
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         rows, dst, src = {}, [], []
@@ -277,6 +336,19 @@ class GaussianModel:
                         d.copy_(a)
         new.__dict__["_rows"] = rows
         return new
+
+    def __copy__(self):
+        """copy.copy(model): a second model over the same tensors -- never over the same list of recorded pose calls."""
+        if self.__dict__.get("_pose_ops"):
+            pose_queue.flush_all()
+        new = self.__class__.__new__(self.__class__)
+        new.__dict__.update(self.__dict__)
+        return new
+
+    def __getstate__(self):
+        if self.__dict__.get("_pose_ops"):
+            pose_queue.flush_all()
+        return self.__dict__
 
     def mask_points(self, mask):
         if self.optimizer:

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_status_strings():
     from pegasus_amd import _lib
     lib = _lib.lib()
-    assert lib.pgr_abi_version() == 2
+    assert lib.pgr_abi_version() == 3 == _lib.PGR_ABI_VERSION
     assert b"gfx950" in lib.pgr_version()
     assert lib.pgr_status_string(0) == b"ok"
     assert lib.pgr_status_string(-3) == b"instance buffer overflow"
