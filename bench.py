@@ -45,12 +45,13 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_LANE_OPS = 78.6e12   # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (SURVEY.md section 8d "secondary ceiling")
-# Vector-issue ceiling: 1024 SIMDs x 2.4 GHz / CYCLES_PER_WAVE_INST.  A wave64 single-rate VALU instruction (v_fma_f32,
-# v_mul, v_add, v_mov, v_cndmask) occupies its SIMD's issue port for 4 cycles on gfx950 -- measured with the shader's own
-# cycle counter, profiles/r05_valu_rates.txt (scripts/microbench/valu_rates.hip); the guide's "v_fma_f32 2 cyc" is the
-# datasheet FP32 rate, which only the packed forms (v_pk_fma_f32: 2 FMAs per lane in the same 4 cycles) reach.
-CYCLES_PER_WAVE_INST = 4.0
-VALU_ISSUE_PEAK = 1024 * 2.4e9 / CYCLES_PER_WAVE_INST
+# Vector-issue ceiling of a kernel (round 6; rounds 3-5 divided by a flat 4 cycles per instruction, which is the SQ counter's
+# convention, not a measured cost): cycles_needed = sum over the SQ instruction classes of (instructions of the class per
+# launch, counters) x (mean issue cost of the class in the kernel's ISA, measured per instruction kind with 8 waves per SIMD:
+# scripts/microbench/valu_classes.hip) / 1024 SIMDs -- scripts/issue_model.py -> profiles/issue_model.json,
+# profiles/r06_issue_model.txt.  frac = cycles_needed / (live kernel duration x the shader clock read DURING the run by
+# pgr_clock_probe): 1.0 = the vector ports never idle.
+N_SIMD = 1024
 LANE_OPS_PER_EVAL = 20         # VALU lane-ops of one pixel-Gaussian evaluation (same section)
 SEQUENCE_STEPS = 200           # BASELINE.json configs[4]: "Dynamic 200-step physics sequence"
 
@@ -367,6 +368,33 @@ class RealEngine:
                 break
 
 
+class ClockProbe:
+    """The shader clock WHILE a measured run is resident: one wave on a side stream reads its s_memtime (shader cycles) and
+    s_memrealtime (100 MHz) counters around a sleep loop (pgr_clock_probe).  start() before the run, mhz() after it."""
+
+    def __init__(self, dev):
+        import torch
+        self.torch, self.dev = torch, dev
+        self.ticks = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.stream = torch.cuda.Stream(dev)
+        self.started = False
+
+    def start(self, spin_us):
+        import ctypes as C
+        from pegasus_amd import _lib
+        self.stream.wait_stream(self.torch.cuda.current_stream(self.dev))
+        rc = _lib.lib().pgr_clock_probe(C.c_void_p(self.ticks.data_ptr()), int(spin_us), C.c_void_p(self.stream.cuda_stream))
+        self.started = rc == 0
+
+    def mhz(self):
+        if not self.started:
+            return None
+        self.stream.synchronize()
+        self.started = False
+        c, r = (int(v) for v in self.ticks.tolist())
+        return round(c / r * 100.0, 1) if r > 0 else None
+
+
 class StubEngine:
     """TEST ONLY (--stub-renderer): a deterministic CPU frame source with the engine's interface, so that the launcher,
     the sharding, the asynchronous gather, its check and the timing protocol run on 2 gloo ranks without a GPU."""
@@ -630,10 +658,14 @@ def run_worker(args):
         if use_dist:
             dist.barrier()
         eng.sync()
+        if probe is not None:                      # (a sleeping wave on its own stream: 20 ms of the run's clock)
+            probe.start(20000)
         t0 = time.perf_counter()
         run_steps(first, count, gather)
         eng.sync()
         own = time.perf_counter() - t0             # this rank's own work, before it waits for the others
+        if probe is not None:
+            clock.setdefault("timed_all", []).append(probe.mhz())
         if use_dist:
             dist.barrier()
         eng.sync()
@@ -647,6 +679,8 @@ def run_worker(args):
             dist.all_gather_object(per_rank, own)
         return el, per_rank
 
+    probe = ClockProbe(dev) if (not eng.stub and world == 1) else None
+    clock = {}
     eng.settle(run_steps)
     run_steps(0, args.warmup, gather_on)
     # The scene, 512+ view specs and the workspaces are thousands of long-lived Python objects; the per-batch host work of a
@@ -799,11 +833,17 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
         del res
     rows, srows = [], []
     prof = (range(args.warmup, args.warmup + args.steps) if args.profile_steps <= 0 else range(max(1, args.profile_steps)))
+    if probe is not None:
+        vals = [v for v in clock.get("timed_all", []) if v]
+        clock["timed"] = sorted(vals)[len(vals) // 2] if vals else None
+        probe.start(min(900000, 6000 * len(prof)))       # over the stage-profile run below (about 6 ms per step)
     for i in prof:
         ms, sms = [], []
         eng.step_blocking(i, stage_ms=ms, sem_stage_ms=sms)
         rows.append(ms)
         srows.append(sms if sms else [0.0] * _lib.PGR_NUM_STAGES)
+    if probe is not None:
+        clock["stage_profile"] = probe.mhz()
     stage_ms = np.asarray(rows)
     # R: raster-only rate (one full-scene RGB+depth forward per view), for the record next to F
     torch.cuda.synchronize()
@@ -878,38 +918,49 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
             if "valu_busy" in k:
                 roofline["valu_issue"] = {"busy_frac": k["valu_busy"], "lds_busy_frac": k.get("lds_busy"), "kernel": kern,
                                           "definition": pmc.get("busy_definition")}
-                # What bounds the dominant kernel, by the counters: the larger of its VALU-issue occupancy, its LDS occupancy
-                # and its HBM fraction (counter traffic / live duration).  The kernel's wave-instruction count is a property of
-                # the workload (SQ_INSTS_VALU per launch, profiles/pmc.json); its duration is measured live, above.
                 hbm_live = k["traffic_bytes_per_launch"] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if dom_ms > 0 else 0.0
-                cand = {"valu_issue": float(k["valu_busy"]), "lds": float(k.get("lds_busy") or 0.0), "hbm": hbm_live}
-                bound = max(cand, key=cand.get)
-                roofline["bound_by_counters"] = {kk: round(v, 4) for kk, v in cand.items()}
-                if bound == "valu_issue" and "valu_insts_per_launch" in k and dom_ms > 0:
-                    inst_rate = k["valu_insts_per_launch"] / (dom_ms * 1e-3)
-                    roofline.update(bound="valu_issue", achieved=round(inst_rate / 1e9, 3), peak=round(VALU_ISSUE_PEAK / 1e9, 1),
-                                    unit="G wave-inst/s", frac=round(inst_rate / VALU_ISSUE_PEAK, 4),
-                                    frac_definition="vector wave-instructions of this kernel per launch (SQ_INSTS_VALU, "
-                                                    "profiles/pmc.json) / its live HIP-event duration, against 1024 SIMDs x 2.4 GHz / "
-                                                    f"{CYCLES_PER_WAVE_INST:g} cycles per wave64 instruction (profiles/r05_valu_rates.txt); "
-                                                    "busy_frac in valu_issue is the same quantity from SQ_ACTIVE_INST_VALU under the "
-                                                    "profiler's clock; the HBM figure of the same kernel is `hbm` / `hbm_frac`")
-                elif bound == "lds":
-                    roofline.update(bound="lds", frac=round(cand["lds"], 4), achieved=None, peak=None, unit="LDS-busy fraction")
-                # the whole path as an instruction budget: vector wave-instructions per view of every kernel one frames
-                # batch launches (the other two compositor variants in the file belong to the profiled / raster-only passes)
-                per_view = {name: kk["valu_insts_per_launch"] / B for name, kk in pmc["kernels"].items()
-                            if "valu_insts_per_launch" in kk and (not name.startswith("composite_quarter_kernel") or name == kern)}
-                total = sum(per_view.values())
-                roofline["valu_issue"]["path"] = {
-                    "wave_insts_per_view": round(total), "wave_insts_per_s": round(total * value / world, 1),
-                    "peak_wave_insts_per_s": VALU_ISSUE_PEAK, "frac": round(total * value / world / VALU_ISSUE_PEAK, 4),
-                    "share": {name: round(v / total, 3) for name, v in sorted(per_view.items(), key=lambda kv: -kv[1]) if v / total >= 0.005},
-                    "definition": "SQ_INSTS_VALU per 32-view launch / 32, summed over the kernels of one frames batch; "
-                                  "x frames/s = vector wave-instructions issued per second, against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"}
+                roofline["bound_by_counters"] = {"valu_issue_busy": round(float(k["valu_busy"]), 4),
+                                                 "lds_busy": round(float(k.get("lds_busy") or 0.0), 4), "hbm": round(hbm_live, 4)}
+                # The issue model (profiles/issue_model.json, scripts/issue_model.py): cycles this kernel's vector instructions
+                # NEED at the measured per-kind issue costs, against the cycles it TOOK = live duration x the shader clock read
+                # during the stage-profile run.  Only with counters of THIS build of the library (sha of the loaded .so).
+                import hashlib
+                lib_sha = hashlib.sha256(Path(_lib.LIB_PATH).read_bytes()).hexdigest()[:16]
+                im = json.loads((ROOT / "profiles" / "issue_model.json").read_text())
+                mk = im["kernels"].get(args.workload, {}).get(kern)
+                same_build = pmc.get("library_sha16") == lib_sha and im.get("library_sha16", {}).get(args.workload) == lib_sha
+                clock_mhz = clock.get("stage_profile") or clock.get("timed")
+                if mk and same_build and clock_mhz and dom_ms > 0 and float(k["valu_busy"]) >= max(float(k.get("lds_busy") or 0.0), hbm_live):
+                    taken = dom_ms * 1e-3 * clock_mhz * 1e6
+                    insts = float(mk["valu_insts"])
+                    roofline.update(
+                        bound="valu_issue", achieved=round(insts / (dom_ms * 1e-3) / 1e9, 3),
+                        peak=round(N_SIMD * clock_mhz * 1e6 / mk["cycles_per_inst"] / 1e9, 1), unit="G wave-inst/s",
+                        frac=round(mk["cycles_needed"] / taken, 4),
+                        frac_definition="SIMD cycles this kernel's vector instructions need (per SQ class: counter count x mean "
+                                        "measured issue cost of the class in the kernel's ISA; profiles/r06_issue_model.txt) / "
+                                        "cycles it took (live HIP-event duration x clock_mhz); peak = 1024 SIMDs x clock / "
+                                        "cycles_per_inst_model")
+                    roofline["issue_model"] = {
+                        "kernel": kern, "clock_mhz": round(clock_mhz, 1), "clock_mhz_timed_region": clock.get("timed"),
+                        "clock_source": "pgr_clock_probe: one wave's s_memtime / s_memrealtime ticks while the measured run is resident",
+                        "cycles_per_inst_model": mk["cycles_per_inst"], "valu_insts_per_launch": insts,
+                        "cycles_needed_per_simd": mk["cycles_needed"], "cycles_taken": round(taken),
+                        "frac_all_cheapest_kind": round(mk["frac_cheapest"] * mk["kernel_cycles"] / taken, 4),
+                        "frac_all_dearest_kind": round(mk["frac_dearest"] * mk["kernel_cycles"] / taken, 4),
+                        "frac_under_profiler": mk["frac"], "salu_per_cu_cycle": mk["salu_frac"], "class_cost_cycles": mk["class_cost"],
+                        # every kernel of the path by the same model, under the profiler's clock (its own cycles)
+                        "path_under_profiler": {name: kk["frac"] for name, kk in im["kernels"].get(args.workload, {}).items()
+                                                if not name.startswith("composite_quarter_kernel") or name == kern},
+                        "source": "scripts/issue_model.py: profiles/r06_valu_classes.txt (costs), r06_valu_classes_pmc.txt (classes), "
+                                  + pmc_file.name + " (class counters), hipcc --save-temps ISA (split inside a class)"}
+                elif not same_build:
+                    roofline["bound_note"] = (f"counter files on record describe another build of the library (pmc {pmc.get('library_sha16')}, "
+                                              f"issue model {im.get('library_sha16', {}).get(args.workload)}, loaded {lib_sha}): `bound` stays the "
+                                              "formula's HBM figure; re-run scripts/r06_issue_model.sh + scripts/issue_model.py")
     except (OSError, ValueError, KeyError):
         pass
-    if "bound_by_counters" not in roofline:
+    if "bound_by_counters" not in roofline and "bound_note" not in roofline:
         roofline["bound_note"] = ("no counter profile on file for this workload / shape: `bound` is the formula's HBM figure only; on the "
                                   "profiled configs (profiles/pmc*.json) this kernel is vector-issue bound, not bandwidth bound")
 

@@ -18,8 +18,13 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 # (all 16 batches of the 512 cameras: the set is ordered by elevation, three batches would be the grazing views only)
 BENCH_FLAGS="--steps 16 --warmup 1 --repeats 1 --no-cpu-baseline --no-drop-in --profile-steps 1 --sync-steps $*"
+# (round 6: three more passes with the SQ instruction-CLASS counters -- what the issue model of bench.py's roofline prices with
+#  the per-class costs of scripts/microbench/valu_classes.hip: profiles/r06_issue_model.txt)
 GROUPS_=("FETCH_SIZE" "WRITE_SIZE" "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"
-         "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE")
+         "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
+         "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32"
+         "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_SALU"
+         "SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_FLAT")
 dbs=()
 i=0
 for grp in "${GROUPS_[@]}"; do

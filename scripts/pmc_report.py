@@ -72,6 +72,12 @@ def main(out_json, out_txt, command, *dbs):
             if "SQ_LDS_IDX_ACTIVE" in c:
                 e["lds_busy"] = round(c["SQ_LDS_IDX_ACTIVE"] / 256 / cyc, 4)
                 e["lds_bank_conflict_share"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(c["SQ_LDS_IDX_ACTIVE"], 1.0), 4)
+        # the kernel's vector instructions by SQ class (per launch): what scripts/issue_model.py prices; "OTHER" = the rest of
+        # SQ_INSTS_VALU (moves, selects, compares, min / max, lane ops, bit ops the class counters do not name)
+        cls = {n[len("SQ_INSTS_VALU_"):]: c[n] for n in c if n.startswith("SQ_INSTS_VALU_") and "MFMA" not in n}
+        if cls and "SQ_INSTS_VALU" in c:
+            cls["OTHER"] = max(0.0, c["SQ_INSTS_VALU"] - sum(cls.values()))
+            e["valu_classes_per_launch"] = {n: round(v) for n, v in sorted(cls.items())}
         e["counters_per_launch"] = {cc: round(v, 1) for cc, v in sorted(c.items())}
         kernels[k] = e
     stage_kernel = {}
@@ -81,7 +87,17 @@ def main(out_json, out_txt, command, *dbs):
             stage_kernel[st] = max(cands, key=lambda k: (kernels[k]["dispatches"], kernels[k].get("traffic_bytes_per_launch", 0)))
     m = re.search(r"--batch (\d+)", command)
     w = re.search(r"--workload (\w+)", command)
-    out = {"workload": w.group(1) if w else "c3", "batch": int(m.group(1)) if m else 32,
+    # which build of the library the counters describe (bench.py compares it with the library it loaded: a counter file of
+    # older kernels must not price today's durations)
+    import hashlib
+    import os
+    lib_path = os.environ.get("PGR_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pegasus_amd", "csrc",
+                                                         "libpegasus_raster.so")
+    try:
+        lib_sha = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        lib_sha = None
+    out = {"workload": w.group(1) if w else "c3", "batch": int(m.group(1)) if m else 32, "library_sha16": lib_sha,
            "fused": "--raster-only" not in command and "--separate-semantic" not in command,
            "source": ("rocprofv3 --pmc, one counter group per pass (FETCH_SIZE | WRITE_SIZE | SQ VALU group | SQ LDS group) over `" + command +
                       "` (scripts/pmc_profile.sh -> scripts/pmc_report.py); per kernel: counter sum / that kernel's own dispatch count; "
