@@ -22,14 +22,13 @@ from . import _lib
 from .sh_rotation import sh_rotation_matrices
 
 
-def make_pose(T, center, with_sh: bool = True) -> _lib.PgrObjectPose:
-    """PgrObjectPose from a 4x4 rigid transform and the rotation centre (the object's cloud mean).  ``with_sh=False``
-    leaves the SH band matrices at identity (callers that rotate positions / orientations only)."""
+def make_pose(T, center) -> _lib.PgrObjectPose:
+    """PgrObjectPose from a 4x4 rigid transform and the rotation centre (the object's cloud mean)."""
     from scipy.spatial.transform import Rotation as Rot
     T = np.asarray(T, dtype=np.float64).reshape(4, 4)
     R = T[:3, :3]
     q_xyzw = Rot.from_matrix(R).as_quat()
-    D1, D2, D3 = sh_rotation_matrices(R) if with_sh else (np.eye(3), np.eye(5), np.eye(7))
+    D1, D2, D3 = sh_rotation_matrices(R)
     f = lambda a: np.asarray(a, dtype=np.float32).reshape(-1)
     p = _lib.PgrObjectPose()
     p.R[:] = f(R); p.t[:] = f(T[:3, 3]); p.center[:] = f(center)

@@ -396,11 +396,11 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     if (!merge_long) {
         // 8193..15872 keys: the windowed sort (two workgroups per CU); longer: the split pre-pass, whose depth segments the
         // 512 x 16 tier's kernel sorts from the segment queue; what either rejects joins the open-ended kernel's queue
-        tile_sort_window_kernel<<<std::min(items, 2048), SORT_WINDOW_THREADS, 0, stream>>>(
-            bin_table, L.tiles, sort_queue + 3 * qs, n_queue + 3, sort_queue + 5 * qs, n_open);
-        tile_partition_kernel<<<std::min(items, 1024), PART_THREADS, 0, stream>>>(
-            bin_table, L.tiles, sort_queue + 4 * qs, n_queue + 4, sort_queue + SORT_TIERS * qs, order_state + ORDER_SEG_WORD,
-            (uint32_t)B.seg_cap, sort_queue + 5 * qs, n_open);
+        // (one launch: its first workgroups run the split pre-pass, the windowed sort fills the chip beside them)
+        const int part_blocks = std::min(items, 1024);
+        tile_sort_window_kernel<<<part_blocks + std::min(items, 2048), SORT_WINDOW_THREADS, 0, stream>>>(
+            bin_table, L.tiles, sort_queue + 3 * qs, n_queue + 3, sort_queue + 5 * qs, n_open, (uint32_t)part_blocks,
+            sort_queue + 4 * qs, n_queue + 4, sort_queue + SORT_TIERS * qs, order_state + ORDER_SEG_WORD, (uint32_t)B.seg_cap);
     }
     tile_sort_long_kernel<1024, 16, true><<<std::min(items, 512), 1024, 0, stream>>>(
         bin_table, L.tiles, sort_queue + 5 * qs, n_queue + 5);

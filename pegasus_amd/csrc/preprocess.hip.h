@@ -169,7 +169,6 @@ __device__ __forceinline__ CandRect candidate_rect(const TileRect& r, float mx, 
 // (0.1 % + 1 px), plus the box's own clipping.
 // Code: rows 0..3 of the rectangle, 4 bits width | 4 bits offset from minx each: bits 0..15 = widths, 16..31 = offsets.
 // 0xffffffff = no row code (more than 4 rows, wider than 15 tiles, or no ellipse): the walks enumerate the whole box.
-constexpr uint32_t ROW_CODE_BOX = 0xffffffffu;
 #ifndef PGR_ROW_CODES
 #define PGR_ROW_CODES 1          // 0: every splat enumerates its whole box (rounds 1-5; A/B builds)
 #endif

@@ -225,6 +225,8 @@ __global__ __launch_bounds__(THREADS) void bin_kernel(const BinView* __restrict_
             const int i = base + lane;
             const int ic = i < end ? i : end - 1;
             uint2 r = gload(bv.rects + ic);
+            // (behind the n rectangles: their row codes, defined where the rectangle is not empty)
+            const uint32_t rcode = gload(reinterpret_cast<const uint32_t*>(bv.rects + n) + ic);
             float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
             float depth = 0.0f;
             uint64_t my_ballot = 0;                  // scatter walk: lane l = the verdicts of window l
@@ -238,7 +240,12 @@ __global__ __launch_bounds__(THREADS) void bin_kernel(const BinView* __restrict_
             }
             if (i >= end) r = make_uint2(0u, 0u);
             const int w = (int)(r.y & 0xffff) - (int)(r.x & 0xffff), h = (int)(r.y >> 16) - (int)(r.x >> 16);
-            const uint32_t area = (w > 0 && h > 0) ? (uint32_t)(w * h) : 0u;
+            // candidates of this splat: the tiles of its box, or (row code) of its per-row intervals -- cumulative widths
+            // c1 <= c2 <= c3 <= rows_total; candidate k lies in the row whose cumulative range holds it
+            const bool rowm = rcode != ROW_CODE_BOX;
+            const uint32_t rc1 = rcode & 15u, rc2 = rc1 + ((rcode >> 4) & 15u), rc3 = rc2 + ((rcode >> 8) & 15u);
+            const uint32_t rows_total = rc3 + ((rcode >> 12) & 15u);
+            const uint32_t area = (w > 0 && h > 0) ? (rowm ? rows_total : (uint32_t)(w * h)) : 0u;
             const uint32_t incl = wave_inclusive_scan(area);
             const uint32_t excl = incl - area;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
@@ -262,7 +269,10 @@ __global__ __launch_bounds__(THREADS) void bin_kernel(const BinView* __restrict_
                         s1 = make_float4(cs.C, cs.rBC, cs.rBA, cs.tau);
                         flags = cs.flags;
                     }
-                    s2 = make_float4(__uint_as_float(flags | ((uint32_t)w << 2)), __uint_as_float(r.x), 1.0f / (float)w, depth);
+                    // box: (flags | w << 2, min corner, 1 / w); rows: (flags | bit 31, min corner, c1 | c2 << 4 | c3 << 9 | offsets << 15)
+                    s2 = rowm ? make_float4(__uint_as_float(flags | 0x80000000u), __uint_as_float(r.x),
+                                            __uint_as_float(rc1 | (rc2 << 4) | (rc3 << 9) | ((rcode >> 16) << 15)), depth)
+                              : make_float4(__uint_as_float(flags | ((uint32_t)w << 2)), __uint_as_float(r.x), 1.0f / (float)w, depth);
                 }
                 if (!FROM_BITS) { stage[lane * 3 + 0] = s0; stage[lane * 3 + 1] = s1; }
                 stage[lane * 3 + 2] = s2;
@@ -291,14 +301,27 @@ __global__ __launch_bounds__(THREADS) void bin_kernel(const BinView* __restrict_
                     const uint32_t k = c - ((key >> 6) - 1u);
                     const float4 o2 = stage[g * 3 + 2];
                     const uint32_t fw = __float_as_uint(o2.x), rlo = __float_as_uint(o2.y);
-                    const int ow = (int)(fw >> 2);
-                    // ty = k / w: reciprocal estimate, then an exact +-1 correction
-                    int ty = (int)(((float)k + 0.5f) * o2.z);
-                    int tx = (int)k - ty * ow;
-                    if (tx < 0) { --ty; tx += ow; } else if (tx >= ow) { ++ty; tx -= ow; }
+                    const bool o_rows = (int)fw < 0, live = c < total;
+                    int tx = 0, ty = 0;
+                    if (__ballot(live && !o_rows) != 0ull) {          // (scalar branch: most windows hold row-coded splats only)
+                        const int ow = (int)((fw & 0x7fffffffu) >> 2);
+                        // ty = k / w: reciprocal estimate, then an exact +-1 correction
+                        ty = (int)(((float)k + 0.5f) * o2.z);
+                        tx = (int)k - ty * ow;
+                        if (tx < 0) { --ty; tx += ow; } else if (tx >= ow) { ++ty; tx -= ow; }
+                    }
+                    if (__ballot(live && o_rows) != 0ull) {
+                        const uint32_t rc = __float_as_uint(o2.z);
+                        const uint32_t q1 = rc & 15u, q2 = (rc >> 4) & 31u, q3 = (rc >> 9) & 63u;
+                        const int row = (k >= q1 ? 1 : 0) + (k >= q2 ? 1 : 0) + (k >= q3 ? 1 : 0);
+                        const uint32_t first = k >= q3 ? q3 : (k >= q2 ? q2 : (k >= q1 ? q1 : 0u));
+                        const int col = (int)((rc >> (15 + 4 * row)) & 15u) + (int)(k - first);
+                        tx = o_rows ? col : tx;
+                        ty = o_rows ? row : ty;
+                    }
                     const int x = (int)(rlo & 0xffff) + tx, y = (int)(rlo >> 16) + ty;
                     const int t = y * grid_x + x - lo;
-                    bool pass = c < total && (unsigned)t < (unsigned)span;
+                    bool pass = live && (unsigned)t < (unsigned)span;
                     if (FROM_BITS) {
                         pass = pass && ((verdicts >> lane) & 1ull);
                     } else if (pass) {
@@ -1270,20 +1293,22 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES) void tile_sort_long_kernel(cons
 constexpr int PART_THREADS = 512;
 constexpr int SEG_HALF = 4096;                       // segments hold < 2 * SEG_HALF keys: the 512 x 16 tier's capacity
 
-__global__ __launch_bounds__(PART_THREADS) void tile_partition_kernel(const BinView* __restrict__ views, int tiles,
-                                                                       const uint4* __restrict__ queue,
-                                                                       const uint32_t* __restrict__ n_queue,
-                                                                       uint4* __restrict__ seg_queue, uint32_t* __restrict__ n_seg,
-                                                                       uint32_t seg_cap, uint4* __restrict__ open_queue,
-                                                                       uint32_t* __restrict__ n_open) {
+constexpr size_t PART_LDS_BYTES = (size_t)(PART_BUCKETS + 4 + PART_THREADS / WAVE + PART_MAX_SEGMENTS + 3) * 4;
+
+// the lists first, first + stride, ... of the queue; lds_words: PART_LDS_BYTES of LDS
+__device__ __forceinline__ void partition_lists(uint32_t* __restrict__ lds_words, const BinView* __restrict__ views, int tiles,
+                                                const uint4* __restrict__ queue, const uint32_t* __restrict__ n_queue,
+                                                uint4* __restrict__ seg_queue, uint32_t* __restrict__ n_seg, uint32_t seg_cap,
+                                                uint4* __restrict__ open_queue, uint32_t* __restrict__ n_open,
+                                                uint32_t first, uint32_t stride) {
     constexpr int THREADS = PART_THREADS, WAVES = THREADS / WAVE, CH = PART_BUCKETS / (WAVES * WAVE), HALF = SEG_HALF, PB = 8;
     static_assert(PART_BUCKETS % (WAVES * WAVE) == 0, "bucket count");
-    __shared__ uint32_t s_hist[PART_BUCKETS];             // counts -> starts -> cursors
-    __shared__ uint32_t s_misc[4 + WAVES];                // [0] min [1] max [2] largest bucket [3] queue slot [4..] wave totals
-    __shared__ uint32_t s_cut[PART_MAX_SEGMENTS + 3];     // segment g starts at s_cut[g]; n = not opened
+    uint32_t* const s_hist = lds_words;                               // [PART_BUCKETS] counts -> starts -> cursors
+    uint32_t* const s_misc = s_hist + PART_BUCKETS;                   // [0] min [1] max [2] largest bucket [3] queue slot [4..] wave totals
+    uint32_t* const s_cut = s_misc + 4 + WAVES;                       // [PART_MAX_SEGMENTS + 3] segment g starts at s_cut[g]; n = not opened
     const int t = threadIdx.x, lane = t & (WAVE - 1), wave = t / WAVE;
     const uint32_t cand = *n_queue;
-    for (uint32_t k = blockIdx.x; k < cand; k += gridDim.x) {
+    for (uint32_t k = first; k < cand; k += stride) {
         const uint4 q = queue[k];
         const uint2* bucket; uint32_t* out; int n; uint64_t* alt64; ObjOut oo;
         sort_item(views, tiles, q, bucket, out, n, oo, &alt64);
@@ -1375,18 +1400,36 @@ __global__ __launch_bounds__(PART_THREADS) void tile_partition_kernel(const BinV
     }
 }
 
-// 8193 .. SORT_WINDOW_MAX keys: the windowed sort; a rejected list joins the open-ended tier's queue (launched afterwards)
+// 8193 .. SORT_WINDOW_MAX keys: the windowed sort; a rejected list joins the open-ended tier's queue (launched afterwards).
+// part_blocks workgroups of the same launch run the split pre-pass of the longer lists instead (part_queue; 0 = none):
+// that pass is as long as its longest list -- a few hundred workgroups that each walk one list three times -- and left most
+// of the chip idle as a launch of its own (C5: 238 us per 32-view batch); here the windowed sort fills the chip beside it.
+static_assert(PART_THREADS == SORT_WINDOW_THREADS && PART_LDS_BYTES <= SORT_WINDOW_LDS, "the two share workgroups");
 __global__ __launch_bounds__(SORT_WINDOW_THREADS, 4) void tile_sort_window_kernel(const BinView* __restrict__ views, int tiles,
                                                                                    const uint4* __restrict__ queue,
                                                                                    const uint32_t* __restrict__ n_queue,
                                                                                    uint4* __restrict__ open_queue,
-                                                                                   uint32_t* __restrict__ n_open) {
+                                                                                   uint32_t* __restrict__ n_open,
+                                                                                   uint32_t part_blocks = 0,
+                                                                                   const uint4* __restrict__ part_queue = nullptr,
+                                                                                   const uint32_t* __restrict__ n_part = nullptr,
+                                                                                   uint4* __restrict__ seg_queue = nullptr,
+                                                                                   uint32_t* __restrict__ n_seg = nullptr,
+                                                                                   uint32_t seg_cap = 0) {
     constexpr size_t LDS_BYTES = SORT_WINDOW_LDS;
     static_assert(2 * (LDS_BYTES + 64) <= 160 * 1024, "two workgroups per CU");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     __shared__ uint32_t s_win[2 * (SORT_WINDOW_ROUNDS + 1) + 2];
+    // every third workgroup of the launch's front is a pre-pass workgroup: the two kinds are resident side by side from the
+    // start (all pre-pass workgroups first would fill the chip alone -- workgroups are dispatched in order)
+    const uint32_t part_before = min(part_blocks, (blockIdx.x + 2u) / 3u);        // pre-pass workgroups among [0, blockIdx.x)
+    if (blockIdx.x % 3u == 0u && blockIdx.x / 3u < part_blocks) {
+        partition_lists(reinterpret_cast<uint32_t*>(lds), views, tiles, part_queue, n_part, seg_queue, n_seg, seg_cap, open_queue,
+                        n_open, blockIdx.x / 3u, part_blocks);
+        return;
+    }
     const uint32_t cand = *n_queue;
-    for (uint32_t k = blockIdx.x; k < cand; k += gridDim.x) {
+    for (uint32_t k = blockIdx.x - part_before; k < cand; k += gridDim.x - part_blocks) {
         const uint4 q = queue[k];
         const uint2* bucket; uint32_t* out; int n; ObjOut oo;
         sort_item(views, tiles, q, bucket, out, n, oo);

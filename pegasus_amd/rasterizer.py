@@ -88,8 +88,11 @@ def reset_capacity(hint: Optional[int] = None, *, free_workspaces: bool = True) 
 
 
 def drop_async_workspaces() -> None:
-    """Releases the cached workspaces of the asynchronous slots (the next batch of each slot allocates afresh)."""
-    for key in [k for k in _WS.buf if isinstance(k, tuple) and len(k) == 2 and isinstance(k[1], tuple)]:
+    """Releases the cached DEVICE workspaces of the asynchronous slots -- keys (device, ("async", slot)) -- so that the next
+    batch of each slot allocates afresh.  The page-locked host scratch of a slot (("pinned", slot): a few KiB of tables and
+    status words, independent of the instance capacity) stays: re-pinning memory per reset costs more than it frees."""
+    for key in [k for k in _WS.buf if isinstance(k, tuple) and len(k) == 2 and isinstance(k[1], tuple) and len(k[1]) == 2
+                and k[1][0] == "async"]:
         _WS.buf.pop(key)
 
 

@@ -424,3 +424,44 @@ def test_render_follows_cameras_with_transposed_matrices_and_in_place_edits(gpu_
         assert torch.equal(c["visibility_filter"], c["radii"] > 0) and int(c["visibility_filter"].sum()) > 100
         assert float(c["viewspace_points"].abs().max()) == 0.0 and c["viewspace_points"].shape == pc.get_xyz.shape
         assert c["viewspace_points"] is a["viewspace_points"]                                   # the shared zero probe
+
+
+@pytest.mark.gpu
+def test_render_after_an_instance_overflow_redoes_the_queued_visibility_filter(gpu_device):
+    """render() queues its visibility filter (radii > 0) behind the compositor BEFORE it reads the batch's status; if that
+    status says "instance overflow" the view is rendered again and the filter must be taken from the NEW radii (the
+    `_was_redone` branch of diff_gaussian_rasterization.rasterize_gaussians): a capacity hint far below the view's need
+    forces the branch; image, radii and visibility_filter must equal the roomy first call's."""
+    import sys
+    from argparse import ArgumentParser
+    import torch
+    root = str(Path(__file__).resolve().parents[1])
+    for p in (root, root + "/compat"):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from gaussian_renderer import render, GaussianModel
+    from scene.cameras import Camera
+    from arguments import PipelineParams
+    from pegasus_amd import rasterizer, scenes
+    dev = torch.device(gpu_device)
+    cloud, views = scenes.scene_c3(scale=0.02, n_views=2, width=320, height=240)
+    v = views[0]
+    with torch.no_grad():
+        pc = GaussianModel.from_arrays(cloud.xyz, cloud.features_dc, cloud.features_rest, cloud.opacity, cloud.scaling,
+                                       cloud.rotation, device=dev)
+        cam = Camera(colmap_id=0, R=v.R_c2w, T=v.t_w2c, FoVx=v.fovx, FoVy=v.fovy, image=None, image_width=v.width,
+                     image_height=v.height, gt_alpha_mask=None, image_name="0", uid=0, data_device=str(dev))
+        pipe = PipelineParams(ArgumentParser())
+        bg = torch.zeros(3, device=dev)
+        first = {k: t.clone() for k, t in render(cam, pc, pipe, bg).items() if torch.is_tensor(t)}
+        need = int(rasterizer.last_forward_info()["num_instances"][0])
+        assert need > 4000
+        key = (dev, cloud.n, v.width, v.height)                      # (capacity_hints()' key of this scene shape)
+        rasterizer.set_capacity_hint(key, 1024)                    # far below the need: the next call overflows and is redone
+        rasterizer.drop_async_workspaces()
+        again = render(cam, pc, pipe, bg)
+        info = rasterizer.last_forward_info()
+        assert int(info["used_max_instances"]) >= need > 1024      # the capacity did grow: the branch ran
+        for k in ("render", "depth", "radii", "visibility_filter"):
+            assert torch.equal(again[k], first[k]), k
+        assert int(again["visibility_filter"].sum()) == int((first["radii"] > 0).sum()) > 0

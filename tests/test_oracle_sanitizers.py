@@ -37,6 +37,12 @@ z = lambda *s: np.zeros(s, np.float32)
 e = oracle.forward(z(0, 3), z(0), scales=z(0, 3), rotations=z(0, 4), shs=z(0, 16, 3), sh_degree=3, **views[0].raster_kwargs(), num_threads=2)
 assert e["num_instances"] == 0
 m = oracle.color_masks(o["color"], np.array([[0.1, 0.2, 0.3], [0.9, 0.9, 0.9]], np.float32), 0.1)
+# the backward oracle (pgr_oracle_backward.c) on the same small merged scene: every gradient finite
+rng = np.random.default_rng(3)
+H, W = views[0].height, views[0].width
+g = oracle.backward(**act, grad_color=rng.normal(size=(3, H, W)).astype(np.float32), grad_depth=rng.normal(size=(H, W)).astype(np.float32),
+                    sh_degree=3, **views[0].raster_kwargs(), num_threads=2)
+assert all(np.isfinite(v).all() for v in g.values()) and float(np.abs(g["means3d"]).max()) > 0
 print("SANITIZED RUN OK", int(o["num_instances"]), int(m.sum()))
 '''
 
