@@ -68,7 +68,7 @@ static Layout make_layout(int32_t n, int32_t width, int32_t height, int64_t max_
     L.splats = take(N * 48);
     L.radii = take(N * 4);
     L.rects = take(N * 8);
-    L.crects = take(N * 12);     // candidate rectangles (8 B) + behind them the row codes (4 B): preprocess.hip.h row_code
+    L.crects = take(N * 8);
     L.rel = take((size_t)L.n_chunks * L.tiles * 4);
     L.ranges = take((size_t)L.tiles * 8);
     L.bucket = take(I * 8);

@@ -91,8 +91,4 @@ __device__ __forceinline__ int length_class(uint32_t len) {
 
 constexpr int PRE_BLOCK = 256;               // Gaussians per preprocess workgroup
 
-// Row code of a candidate rectangle (preprocess.hip.h row_code): rows 0..3, 4 bits width | 4 bits offset each (bits 0..15 the
-// widths, 16..31 the offsets); ROW_CODE_BOX = none, the binning walks enumerate the whole box.
-constexpr uint32_t ROW_CODE_BOX = 0xffffffffu;
-
 }  // namespace pgr

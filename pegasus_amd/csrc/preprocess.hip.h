@@ -124,15 +124,11 @@ __device__ __forceinline__ float3 sh_to_rgb(const float* __restrict__ sh, float 
 // ellipse {q <= tau''} where tau'' bounds from above every threshold the tight-list predicate
 // (cull.hip.h) can apply to a tile of this splat; tiles outside it are rejected by the predicate anyway, so the
 // lists are unchanged -- there are just fewer candidates to test (anisotropic and faint splats shrink most).
-struct CandRect { uint2 rect; float tau2, exg, eyg; bool ellipse; };     // ellipse: tau2 / exg / eyg are valid
-
-__device__ __forceinline__ CandRect candidate_rect(const TileRect& r, float mx, float my, float c_xx, float c_yy,
-                                                   float con_x, float con_y, float con_z, float opacity, int radius) {
-    CandRect out{make_uint2(0u, 0u), 0.0f, 0.0f, 0.0f, false};
-    if (opacity < ALPHA_MIN) return out;                                 // never listed
+__device__ __forceinline__ uint2 candidate_rect(const TileRect& r, float mx, float my, float c_xx, float c_yy,
+                                                float con_x, float con_y, float con_z, float opacity, int radius) {
+    if (opacity < ALPHA_MIN) return make_uint2(0u, 0u);                 // never listed
     const uint2 full = make_uint2((uint32_t)r.minx | ((uint32_t)r.miny << 16), (uint32_t)r.maxx | ((uint32_t)r.maxy << 16));
-    out.rect = full;
-    if (!(con_x > 0.0f) || !(con_z > 0.0f)) return out;                  // degenerate conic: the predicate keeps all
+    if (!(con_x > 0.0f) || !(con_z > 0.0f)) return full;                // degenerate conic: the predicate keeps all
     const float t = 255.0f * opacity;
     const uint32_t bits = __float_as_uint(t);
     const float e = (float)((int)((bits >> 23) & 0xffu) - 127);
@@ -141,76 +137,19 @@ __device__ __forceinline__ CandRect candidate_rect(const TileRect& r, float mx, 
     const float D = (float)radius + 2.0f * (float)TILE;                  // no pixel of the rectangle is farther than this
     const float M = (con_x + 2.0f * fabsf(con_y) + con_z) * D * D;
     const float tau2 = 1.001f * (tau + 0.00001f * M + 0.01f) + 0.001f;
-    const float exg = sqrtf(tau2 * c_xx), eyg = sqrtf(tau2 * c_yy);
-    const float ex = exg * 1.001f + 1.0f, ey = eyg * 1.001f + 1.0f;
-    if (!(ex < 1.0e9f) || !(ey < 1.0e9f)) return out;
+    const float ex = sqrtf(tau2 * c_xx) * 1.001f + 1.0f, ey = sqrtf(tau2 * c_yy) * 1.001f + 1.0f;
+    if (!(ex < 1.0e9f) || !(ey < 1.0e9f)) return full;
     // tiles whose pixel-centre span [16t, 16t+15] meets [m - e, m + e]
     const int minx = max(r.minx, (int)floorf((mx - ex - (float)(TILE - 1)) / (float)TILE) + 0);
     const int miny = max(r.miny, (int)floorf((my - ey - (float)(TILE - 1)) / (float)TILE) + 0);
     const int maxx = min(r.maxx, (int)floorf((mx + ex) / (float)TILE) + 1);
     const int maxy = min(r.maxy, (int)floorf((my + ey) / (float)TILE) + 1);
-    out.rect = make_uint2(0u, 0u);
-    if (maxx <= minx || maxy <= miny) return out;
-    out.rect = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)maxx | ((uint32_t)maxy << 16));
-    out.tau2 = tau2; out.exg = exg; out.eyg = eyg; out.ellipse = true;
-    return out;
+    if (maxx <= minx || maxy <= miny) return make_uint2(0u, 0u);
+    return make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)maxx | ((uint32_t)maxy << 16));
 }
-
-// ---- row code (round 6): the candidate rectangle, one interval of tiles per tile ROW ------------------------------------
-// The rectangle above is the box of the ellipse E = {q <= tau2}; a sheared (diagonal) ellipse leaves the box's corners empty,
-// and the binning walks evaluate the tight-list predicate on every tile of the box (5.8 M candidates per C3 view for 3.8 M
-// listed instances).  In the sheared form  q = A (dx + (B/A) dy)^2 + k dy^2,  k = C - B^2 / A,  a horizontal line dy = const
-// meets E in |dx + (B/A) dy| <= sqrt((tau2 - k dy^2) / A) <= HW := sqrt(tau2 / A): over a tile row's band dy in [e0, e1]
-// (clipped to |dy| <= eyg, the ellipse's vertical extent) E lies inside the PARALLELOGRAM slice
-//     min(c(e0), c(e1)) - HW <= dx <= max(c(e0), c(e1)) + HW,    c(dy) = -(B/A) dy        (c is linear: ends suffice).
-// Tiles outside the slice cannot meet E, so the predicate would reject them: the lists are unchanged, there are 21 % fewer
-// candidates to test (C3; scripts/sim/row_codes.py checks every listed instance of full-size views against the slices, with
-// the exact per-row ellipse extents: 4.53 M candidates, the parallelogram: 4.59 M).  The margins are those of the box
-// (0.1 % + 1 px), plus the box's own clipping.
-// Code: rows 0..3 of the rectangle, 4 bits width | 4 bits offset from minx each: bits 0..15 = widths, 16..31 = offsets.
-// 0xffffffff = no row code (more than 4 rows, wider than 15 tiles, or no ellipse): the walks enumerate the whole box.
-#ifndef PGR_ROW_CODES
-#define PGR_ROW_CODES 1          // 0: every splat enumerates its whole box (rounds 1-5; A/B builds)
-#endif
-
-__device__ __forceinline__ uint32_t row_code(const CandRect& cr, float mx, float my, float A, float B, float C, float bA) {
-    const int minx = (int)(cr.rect.x & 0xffffu), miny = (int)(cr.rect.x >> 16);
-    const int maxx = (int)(cr.rect.y & 0xffffu), maxy = (int)(cr.rect.y >> 16);
-    const int w = maxx - minx, h = maxy - miny;
-    if (w > 15 || h > 4 || w <= 0 || h <= 0) return ROW_CODE_BOX;
-    if (h == 1 || w == 1 || !cr.ellipse) {                   // nothing to gain: every row takes the box's width
-        uint32_t code = 0;
-        for (int r = 0; r < h; ++r) code |= (uint32_t)w << (4 * r);
-        return code;
-    }
-    const float k = fmaf(-B, bA, C);
-    const float hw = __builtin_amdgcn_sqrtf(cr.tau2 * __builtin_amdgcn_rcpf(A));        // (approximate forms: the margin below is 1 px)
-    const float HWm = hw + 0.001f * cr.exg + 1.0f;
-    if (!(k > 0.0f) || !(HWm < 1.0e9f)) return ROW_CODE_BOX;
-    const float eyg = cr.eyg;
-    const float base = (float)(TILE * miny) - 0.5f - my;      // dy of the first row's upper band edge
-    // P_j = mx + c(dy_j) at the band edges j = 0 .. 4; edges beyond the last row collapse onto +eyg (their rows are empty)
-    float dy[5], P[5];
-    dy[0] = -eyg;
-#pragma unroll
-    for (int j = 1; j < 5; ++j) {
-        const float d = __builtin_amdgcn_fmed3f(base + (float)(TILE * j), -eyg, eyg);
-        dy[j] = j < h ? d : eyg;
-    }
-#pragma unroll
-    for (int j = 0; j < 5; ++j) P[j] = fmaf(-bA, dy[j], mx);
-    uint32_t code = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float hi = fmaxf(P[r], P[r + 1]) + HWm, lo = fminf(P[r], P[r + 1]) - (HWm + (float)(TILE - 1));
-        int t_hi = (int)floorf(hi * (1.0f / (float)TILE)) + 1, t_lo = (int)floorf(lo * (1.0f / (float)TILE));
-        t_hi = min(max(t_hi, minx), maxx);
-        t_lo = min(max(t_lo, minx), maxx);
-        const uint32_t wid = dy[r + 1] > dy[r] ? (uint32_t)max(t_hi - t_lo, 0) : 0u;     // (a band outside |dy| <= eyg is empty)
-        code |= (wid << (4 * r)) | ((wid ? (uint32_t)(t_lo - minx) : 0u) << (16 + 4 * r));
-    }
-    return code;
-}
+// (Round 6 built a per-tile-ROW refinement of this rectangle -- parallelogram slices of the ellipse, 21 % fewer candidates,
+// lists unchanged -- and measured it a net loss: computing the intervals costs the preprocess what the walks save.
+// profiles/r06_rows_ab.txt; code: git log -S row_code -- pegasus_amd/csrc/preprocess.hip.h)
 
 // Per-Gaussian, per-view record the later stages gather: ONE 48-byte row instead of four arrays, so a gather
 // touches 1-2 64-byte sectors instead of 3-4 (PMC: the compositor fetched 2.3x its algorithmic bytes with the
@@ -221,8 +160,7 @@ constexpr int SPLAT_F4 = 3;
 struct PreOut {
     float4* splats;          // [n, SPLAT_F4]
     uint2* rects;            // packed tile rectangle (4 x uint16: minx,miny,maxx,maxy), all zero when culled; NULL = not wanted
-    uint2* crects;           // candidate rectangle for binning: rects clipped to the alpha >= 1/255 ellipse's box; behind its n
-                             // entries: n row codes (uint32, row_code above), written for the non-empty rectangles only
+    uint2* crects;           // candidate rectangle for binning: rects clipped to the alpha >= 1/255 ellipse's box
     int32_t* radii;          // NULL = not wanted
 };
 
@@ -466,12 +404,7 @@ __global__ __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                     rect = make_uint2((uint32_t)r.minx | ((uint32_t)r.miny << 16),
                                       (uint32_t)r.maxx | ((uint32_t)r.maxy << 16));
                     const float op = sc.opacities[i];
-                    const CandRect cr = candidate_rect(r, pix_x, pix_y, c_xx, c_yy, con_x, con_y, con_z, op, rad);
-                    crect = cr.rect;
-                    const float rBA = con_y / con_x;
-                    if (crect.x | crect.y)
-                        reinterpret_cast<uint32_t*>(out_crects + sc.n)[i] = PGR_ROW_CODES ? row_code(cr, pix_x, pix_y, con_x, con_y, con_z, rBA)
-                                                                                       : ROW_CODE_BOX;
+                    crect = candidate_rect(r, pix_x, pix_y, c_xx, c_yy, con_x, con_y, con_z, op, rad);
                     if (LAYERED) {           // tile rows of layer k start at (k - 1) * grid_y
                         const uint32_t off = (uint32_t)((layer - 1) * cam_gy) << 16;
                         rect.x += off; rect.y += off;
@@ -479,7 +412,7 @@ __global__ __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                     }
                     float4* rec = out_splats + (size_t)i * SPLAT_F4;
                     rec[0] = make_float4(pix_x, pix_y, con_x, con_y);
-                    rec[1] = make_float4(con_z, op, con_y / con_z, rBA);               // + the cull record's B/C, B/A (cull.hip.h)
+                    rec[1] = make_float4(con_z, op, con_y / con_z, con_y / con_x);     // + the cull record's B/C, B/A (cull.hip.h)
                     rec[2] = make_float4(rgb.x, rgb.y, rgb.z, tz);
                 }
             }

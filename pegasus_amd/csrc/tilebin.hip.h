@@ -225,8 +225,6 @@ __global__ __launch_bounds__(THREADS) void bin_kernel(const BinView* __restrict_
             const int i = base + lane;
             const int ic = i < end ? i : end - 1;
             uint2 r = gload(bv.rects + ic);
-            // (behind the n rectangles: their row codes, defined where the rectangle is not empty)
-            const uint32_t rcode = gload(reinterpret_cast<const uint32_t*>(bv.rects + n) + ic);
             float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
             float depth = 0.0f;
             uint64_t my_ballot = 0;                  // scatter walk: lane l = the verdicts of window l
@@ -240,12 +238,7 @@ __global__ __launch_bounds__(THREADS) void bin_kernel(const BinView* __restrict_
             }
             if (i >= end) r = make_uint2(0u, 0u);
             const int w = (int)(r.y & 0xffff) - (int)(r.x & 0xffff), h = (int)(r.y >> 16) - (int)(r.x >> 16);
-            // candidates of this splat: the tiles of its box, or (row code) of its per-row intervals -- cumulative widths
-            // c1 <= c2 <= c3 <= rows_total; candidate k lies in the row whose cumulative range holds it
-            const bool rowm = rcode != ROW_CODE_BOX;
-            const uint32_t rc1 = rcode & 15u, rc2 = rc1 + ((rcode >> 4) & 15u), rc3 = rc2 + ((rcode >> 8) & 15u);
-            const uint32_t rows_total = rc3 + ((rcode >> 12) & 15u);
-            const uint32_t area = (w > 0 && h > 0) ? (rowm ? rows_total : (uint32_t)(w * h)) : 0u;
+            const uint32_t area = (w > 0 && h > 0) ? (uint32_t)(w * h) : 0u;
             const uint32_t incl = wave_inclusive_scan(area);
             const uint32_t excl = incl - area;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
@@ -269,10 +262,7 @@ __global__ __launch_bounds__(THREADS) void bin_kernel(const BinView* __restrict_
                         s1 = make_float4(cs.C, cs.rBC, cs.rBA, cs.tau);
                         flags = cs.flags;
                     }
-                    // box: (flags | w << 2, min corner, 1 / w); rows: (flags | bit 31, min corner, c1 | c2 << 4 | c3 << 9 | offsets << 15)
-                    s2 = rowm ? make_float4(__uint_as_float(flags | 0x80000000u), __uint_as_float(r.x),
-                                            __uint_as_float(rc1 | (rc2 << 4) | (rc3 << 9) | ((rcode >> 16) << 15)), depth)
-                              : make_float4(__uint_as_float(flags | ((uint32_t)w << 2)), __uint_as_float(r.x), 1.0f / (float)w, depth);
+                    s2 = make_float4(__uint_as_float(flags | ((uint32_t)w << 2)), __uint_as_float(r.x), 1.0f / (float)w, depth);
                 }
                 if (!FROM_BITS) { stage[lane * 3 + 0] = s0; stage[lane * 3 + 1] = s1; }
                 stage[lane * 3 + 2] = s2;
@@ -301,27 +291,14 @@ __global__ __launch_bounds__(THREADS) void bin_kernel(const BinView* __restrict_
                     const uint32_t k = c - ((key >> 6) - 1u);
                     const float4 o2 = stage[g * 3 + 2];
                     const uint32_t fw = __float_as_uint(o2.x), rlo = __float_as_uint(o2.y);
-                    const bool o_rows = (int)fw < 0, live = c < total;
-                    int tx = 0, ty = 0;
-                    if (__ballot(live && !o_rows) != 0ull) {          // (scalar branch: most windows hold row-coded splats only)
-                        const int ow = (int)((fw & 0x7fffffffu) >> 2);
-                        // ty = k / w: reciprocal estimate, then an exact +-1 correction
-                        ty = (int)(((float)k + 0.5f) * o2.z);
-                        tx = (int)k - ty * ow;
-                        if (tx < 0) { --ty; tx += ow; } else if (tx >= ow) { ++ty; tx -= ow; }
-                    }
-                    if (__ballot(live && o_rows) != 0ull) {
-                        const uint32_t rc = __float_as_uint(o2.z);
-                        const uint32_t q1 = rc & 15u, q2 = (rc >> 4) & 31u, q3 = (rc >> 9) & 63u;
-                        const int row = (k >= q1 ? 1 : 0) + (k >= q2 ? 1 : 0) + (k >= q3 ? 1 : 0);
-                        const uint32_t first = k >= q3 ? q3 : (k >= q2 ? q2 : (k >= q1 ? q1 : 0u));
-                        const int col = (int)((rc >> (15 + 4 * row)) & 15u) + (int)(k - first);
-                        tx = o_rows ? col : tx;
-                        ty = o_rows ? row : ty;
-                    }
+                    const int ow = (int)(fw >> 2);
+                    // ty = k / w: reciprocal estimate, then an exact +-1 correction
+                    int ty = (int)(((float)k + 0.5f) * o2.z);
+                    int tx = (int)k - ty * ow;
+                    if (tx < 0) { --ty; tx += ow; } else if (tx >= ow) { ++ty; tx -= ow; }
                     const int x = (int)(rlo & 0xffff) + tx, y = (int)(rlo >> 16) + ty;
                     const int t = y * grid_x + x - lo;
-                    bool pass = live && (unsigned)t < (unsigned)span;
+                    bool pass = c < total && (unsigned)t < (unsigned)span;
                     if (FROM_BITS) {
                         pass = pass && ((verdicts >> lane) & 1ull);
                     } else if (pass) {
