@@ -402,16 +402,17 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
             bin_table, L.tiles, sort_queue + 3 * qs, n_queue + 3, sort_queue + 5 * qs, n_open, (uint32_t)part_blocks,
             sort_queue + 4 * qs, n_queue + 4, sort_queue + SORT_TIERS * qs, order_state + ORDER_SEG_WORD, (uint32_t)B.seg_cap);
     }
-    tile_sort_long_kernel<1024, 16, true><<<std::min(items, 512), 1024, 0, stream>>>(
+    // the open-ended kernel: every long list of a one- / two-view call; in a batch only what the two kernels above rejected
+    // (piled-up depths: rare) -- a handful of workgroups then, 512 of them cost 20 us to find an empty queue
+    tile_sort_long_kernel<1024, 16, true><<<merge_long ? std::min(items, 512) : 32, 1024, 0, stream>>>(
         bin_table, L.tiles, sort_queue + 5 * qs, n_queue + 5);
-    if (!merge_long)
-        tile_sort_long_kernel<512, 16, false, SORT_T2_BUCKETS, 4, true><<<std::min(items, 2048), 512, 0, stream>>>(
-            bin_table, L.tiles, sort_queue + SORT_TIERS * qs, order_state + ORDER_SEG_WORD, (uint32_t)B.seg_cap);
     if (!merge_long) {
         // 4097..8192 keys: 512 threads x 16 keys over 3584 buckets = 80 KiB, TWO workgroups per CU (round 5: the position-owned
-        // ranking needs no index image, so the bucket count is free; 1024 x 8 over 8192 buckets = 96 KiB held a CU alone)
-        tile_sort_long_kernel<512, 16, false, SORT_T2_BUCKETS, 4><<<std::min(items, 2048), 512, 0, stream>>>(
-            bin_table, L.tiles, sort_queue + 2 * qs, n_queue + 2);
+        // ranking needs no index image, so the bucket count is free; 1024 x 8 over 8192 buckets = 96 KiB held a CU alone);
+        // the same launch sorts the split pre-pass's segments behind its own lists
+        tile_sort_long_kernel<512, 16, false, SORT_T2_BUCKETS, 4, true><<<std::min(items, 2048), 512, 0, stream>>>(
+            bin_table, L.tiles, sort_queue + 2 * qs, n_queue + 2, sort_queue + SORT_TIERS * qs, order_state + ORDER_SEG_WORD,
+            (uint32_t)B.seg_cap);
         tile_sort_long_kernel<512, 8, false><<<std::min(items, 2048), 512, 0, stream>>>(
             bin_table, L.tiles, sort_queue + qs, n_queue + 1);
     }

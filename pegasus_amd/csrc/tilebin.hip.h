@@ -1200,11 +1200,14 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* 
 //               and its alt buffer.
 // A kernel per tier keeps each one's register budget its own: with the open-ended tier's code in the same kernel the
 // 4097..8192 path (a quarter of C3's keys) ran out of the 128 VGPRs a 1024-thread workgroup gets and spilled.
-// SEG: the queue holds depth SEGMENTS of longer lists (tile_partition_kernel) instead of whole lists; seg_cap = its capacity
+// SEG: behind the tier's own lists the launch also sorts the depth SEGMENTS of longer lists (the split pre-pass's segment
+// queue, seg_cap = its capacity): one launch, the segments fill the tail of the tier's own lists
 template <int THREADS, int E, bool LAST, int NB = THREADS * E, int MIN_WAVES = (THREADS == 512 ? PGR_T1_WAVES : 4), bool SEG = false>
 __global__ __launch_bounds__(THREADS, MIN_WAVES) void tile_sort_long_kernel(const BinView* __restrict__ views, int tiles,
                                                                  const uint4* __restrict__ queue,
-                                                                 const uint32_t* __restrict__ n_queue, uint32_t seg_cap = 0) {
+                                                                 const uint32_t* __restrict__ n_queue,
+                                                                 const uint4* __restrict__ seg_queue = nullptr,
+                                                                 const uint32_t* __restrict__ n_seg = nullptr, uint32_t seg_cap = 0) {
     constexpr int CAP = THREADS * E;
     static_assert(!LAST || CAP == SORT_LARGE_MAX, "the open-ended tier");
     // bucket sort image: 8 B per key + 4 B per bucket, or (last tier) keys + 8192 counters = 157 KiB; the merge sort's padded keys fit
@@ -1213,19 +1216,23 @@ __global__ __launch_bounds__(THREADS, MIN_WAVES) void tile_sort_long_kernel(cons
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     __shared__ uint32_t s_cut[LAST ? PART_MAX_SEGMENTS + 3 : 1];
     uint64_t* skeys = reinterpret_cast<uint64_t*>(lds);
-    const uint32_t cand = SEG ? min(*n_queue, seg_cap) : *n_queue;
+    const uint32_t own = *n_queue;
+    uint32_t cand = own;
+    if constexpr (SEG) cand += min(*n_seg, seg_cap);
     for (uint32_t k = blockIdx.x; k < cand; k += gridDim.x) {
         const uint2* bucket; uint32_t* out; int n; uint64_t* alt; ObjOut oo;
         if constexpr (SEG) {
             static_assert(!SEG || !LAST, "segments fit the tier");
-            uint32_t pos;
-            sort_segment(views, tiles, queue[k], bucket, out, n, oo, pos);
-            if (n > 0) {                         // (n == 0: a reservation that did not fit the queue, see tile_partition_kernel)
-                if (!bucket_sort_tile<THREADS, E, NB>(lds, bucket, out, n, oo.n_env, oo.last, pos, oo.tie))
-                    merge_sort_tile<THREADS, E>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, pos, oo.tie, oo.inv);
+            if (k >= own) {
+                uint32_t pos;
+                sort_segment(views, tiles, seg_queue[k - own], bucket, out, n, oo, pos);
+                if (n > 0) {                     // (n == 0: a reservation that did not fit the queue, see partition_lists)
+                    if (!bucket_sort_tile<THREADS, E, NB>(lds, bucket, out, n, oo.n_env, oo.last, pos, oo.tie))
+                        merge_sort_tile<THREADS, E>(skeys, bucket, out, n, nullptr, oo.n_env, oo.last, pos, oo.tie, oo.inv);
+                }
+                __syncthreads();
+                continue;
             }
-            __syncthreads();
-            continue;
         }
         sort_item(views, tiles, queue[k], bucket, out, n, oo, &alt);
         {
