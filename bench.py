@@ -922,9 +922,8 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
                                                  "lds_busy": round(float(k.get("lds_busy") or 0.0), 4), "hbm": round(hbm_live, 4)}
                 # The issue model (profiles/issue_model.json, scripts/issue_model.py): cycles this kernel's vector instructions
                 # NEED at the measured per-kind issue costs, against the cycles it TOOK = live duration x the shader clock read
-                # during the stage-profile run.  Only with counters of THIS build of the library (sha of the loaded .so).
-                import hashlib
-                lib_sha = hashlib.sha256(Path(_lib.LIB_PATH).read_bytes()).hexdigest()[:16]
+                # during the stage-profile run.  Only with counters of THESE kernels (the source hash the loaded library was built from).
+                lib_sha = _lib.lib().pgr_version().decode().rsplit(" ", 1)[-1]      # hash of the sources the library was built from
                 im = json.loads((ROOT / "profiles" / "issue_model.json").read_text())
                 mk = im["kernels"].get(args.workload, {}).get(kern)
                 same_build = pmc.get("library_sha16") == lib_sha and im.get("library_sha16", {}).get(args.workload) == lib_sha

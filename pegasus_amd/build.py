@@ -24,6 +24,19 @@ def sources():
     return sorted(CSRC.glob("*.hip")), sorted(CSRC.glob("*.h")) + [CSRC.parents[1] / "include" / "pegasus_raster.h"]
 
 
+def source_hash() -> str:
+    """16 hex digits over the kernel sources, the C header and the compiler flags: WHICH kernels a library holds.  Compiled into
+    the library (pgr_version() ends with it) and stamped into the counter files of scripts/pmc_report.py, so that bench.py prices
+    a kernel's live duration only with counters of the same kernels.  (The .so itself is not byte-reproducible.)"""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    srcs, hdrs = sources()
+    for f in sorted(srcs + hdrs):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def needs_build() -> bool:
     if not LIB.exists():
         return True
@@ -38,7 +51,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     srcs, _ = sources()
     tmp = LIB.with_suffix(f".tmp{os.getpid()}.so")
-    cmd = [hipcc, *FLAGS, "-o", str(tmp), *map(str, srcs)]
+    cmd = [hipcc, *FLAGS, f'-DPGR_SOURCE_HASH="{source_hash()}"', "-o", str(tmp), *map(str, srcs)]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=str(CSRC))

@@ -471,7 +471,10 @@ using namespace pgr;
 extern "C" {
 
 int32_t pgr_abi_version(void) { return PGR_ABI_VERSION; }
-const char* pgr_version(void) { return "pegasus_raster 0.9 (gfx950)"; }
+#ifndef PGR_SOURCE_HASH
+#define PGR_SOURCE_HASH "unstamped"      // pegasus_amd/build.py passes the hash of the sources it compiled
+#endif
+const char* pgr_version(void) { return "pegasus_raster 0.9 (gfx950) src " PGR_SOURCE_HASH; }
 
 const char* pgr_status_string(int32_t status) {
     switch (status) {

@@ -87,15 +87,17 @@ def main(out_json, out_txt, command, *dbs):
             stage_kernel[st] = max(cands, key=lambda k: (kernels[k]["dispatches"], kernels[k].get("traffic_bytes_per_launch", 0)))
     m = re.search(r"--batch (\d+)", command)
     w = re.search(r"--workload (\w+)", command)
-    # which build of the library the counters describe (bench.py compares it with the library it loaded: a counter file of
-    # older kernels must not price today's durations)
-    import hashlib
+    # which kernels the counters describe: the source hash compiled into the profiled library (pgr_version() ends with it;
+    # bench.py compares it with the library it loaded -- a counter file of older kernels must not price today's durations)
+    import ctypes
     import os
     lib_path = os.environ.get("PGR_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pegasus_amd", "csrc",
                                                          "libpegasus_raster.so")
     try:
-        lib_sha = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()[:16]
-    except OSError:
+        h = ctypes.CDLL(lib_path)
+        h.pgr_version.restype = ctypes.c_char_p
+        lib_sha = h.pgr_version().decode().rsplit(" ", 1)[-1]
+    except (OSError, AttributeError):
         lib_sha = None
     out = {"workload": w.group(1) if w else "c3", "batch": int(m.group(1)) if m else 32, "library_sha16": lib_sha,
            "fused": "--raster-only" not in command and "--separate-semantic" not in command,

@@ -1,12 +1,16 @@
 #!/bin/bash
-# Round-5 evidence run (GPU box): tests, counter passes, bench lines, kernel traces -> gpurun_out/r05_*
+# Round-6 evidence run (GPU box): tests, counter passes + issue model, bench lines, kernel traces -> gpurun_out/r06_*
 cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set}"
 mkdir -p gpurun_out
-P=gpurun_out/r05
+P=gpurun_out/r06
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > ${P}_pytest_gpu.txt
-# counters first: bench.py reads profiles/pmc.json, so the lines below carry THIS code's traffic / issue numbers
-bash scripts/pmc_profile.sh r05_pmc > ${P}_pmc.log 2>&1
-cp gpurun_out/r05_pmc.json profiles/pmc.json
+# counters first: bench.py reads profiles/pmc*.json + profiles/issue_model.json, so the lines below carry THIS code's numbers
+bash scripts/pmc_profile.sh r06_pmc > ${P}_pmc.log 2>&1
+bash scripts/pmc_profile.sh r06_pmc_c5 --workload c5 --views 200 > ${P}_pmc_c5.log 2>&1
+cp gpurun_out/r06_pmc.json profiles/pmc.json; cp gpurun_out/r06_pmc_c5.json profiles/pmc_c5.json
+cp gpurun_out/r06_pmc.json profiles/r06_pmc.json; cp gpurun_out/r06_pmc_c5.json profiles/r06_pmc_c5.json
+python scripts/issue_model.py profiles/r06_pmc.json profiles/r06_pmc_c5.json > ${P}_issue_model.log 2>&1
+cp profiles/r06_issue_model.txt profiles/issue_model.json gpurun_out/
 python bench.py > ${P}_bench_default.json 2> ${P}_bench_default.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > ${P}_bench_steps20_warmup5.json 2>/dev/null
 python bench.py --data-points all --no-cpu-baseline --no-drop-in > ${P}_bench_all_data_points.json 2>/dev/null
@@ -20,11 +24,11 @@ python bench.py --facade > ${P}_bench_facade.json 2>/dev/null
 python bench.py --width 640 --height 480 --objects 6 --data-points all --no-cpu-baseline > ${P}_bench_ref_default_640x480.json 2>/dev/null
 python bench.py --gpus 2 --share-devices --backend gloo --steps 6 --warmup 2 --no-drop-in > ${P}_bench_rehearsal_2ranks_1gpu.json 2>/dev/null
 python bench.py --force-dist --backend nccl --no-drop-in --no-cpu-baseline > ${P}_bench_rccl_1rank_forced.json 2>/dev/null
-python bench.py --force-dist --backend nccl --records pack --no-drop-in --no-cpu-baseline > ${P}_bench_rccl_1rank_forced_pack.json 2>/dev/null
-bash scripts/trace_run.sh r05 --no-drop-in > /dev/null 2>&1
-bash scripts/trace_run.sh r05_sync --no-drop-in --sync-steps > /dev/null 2>&1
-bash scripts/trace_run.sh r05_c5_sync --no-drop-in --sync-steps --workload c5 --views 200 > /dev/null 2>&1
-bash scripts/single_view_trace.sh r05 40 c3 > /dev/null 2>&1
+python bench.py --force-dist --backend nccl --full-outputs --no-drop-in --no-cpu-baseline > ${P}_bench_rccl_1rank_forced_full_outputs.json 2>/dev/null
+bash scripts/trace_run.sh r06 --no-drop-in > /dev/null 2>&1
+bash scripts/trace_run.sh r06_sync --no-drop-in --sync-steps > /dev/null 2>&1
+bash scripts/trace_run.sh r06_c5_sync --no-drop-in --sync-steps --workload c5 --views 200 > /dev/null 2>&1
+bash scripts/single_view_trace.sh r06 40 c3 > /dev/null 2>&1
 python scripts/silhouette_time.py 2>&1 | grep -v amdgpu.ids > ${P}_silhouette_time.txt
 ( python scripts/fuzz_parity.py 90000 1500 2>&1 | tail -1; python scripts/fuzz_fused.py 5000 200 2>&1 | tail -1; python scripts/fuzz_layered.py 3000 100 2>&1 | tail -1
   python scripts/soak_determinism.py 4 c3 2>&1 | tail -1; python scripts/full_size_parity.py 2>&1 | tail -1 ) | grep -v amdgpu.ids > ${P}_verification.txt
@@ -33,7 +37,8 @@ import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     r = d.get("roofline") or {}
-    print(sys.argv[1], d.get("value"), d.get("value_min"), d.get("value_max"), r.get("stage_ms_per_view"), r.get("bound"), r.get("frac"), r.get("hbm_frac"))
+    print(sys.argv[1], d.get("value"), d.get("value_min"), d.get("value_max"), r.get("stage_ms_per_view"), r.get("bound"), r.get("frac"), r.get("hbm_frac"),
+          (r.get("issue_model") or {}).get("clock_mhz"))
 except Exception as e:
     print(sys.argv[1], "unreadable:", e)
 PY

@@ -1,6 +1,8 @@
-"""The per-tile-row candidate intervals the binning walks use for splats of 2..4 tile rows (pegasus_amd/csrc/tilebin.hip.h,
-row_code): restated in numpy fp32, checked for conservativeness against the oracle's LISTED instances (every listed
-(Gaussian, tile) must lie inside the intervals) and counted.   python scripts/sim/row_codes.py [c3|c5|fuzz] [n]"""
+"""Per-tile-row candidate intervals for splats of 2..4 tile rows (exact per-row extents of the ellipse {q <= tau2}) in numpy
+fp32, checked for conservativeness against the oracle's LISTED instances (every listed (Gaussian, tile) must lie inside the
+intervals) and counted: 5.78 M -> 4.53 M candidates per C3 view.  Round 6 built the cheaper parallelogram form of this into the
+preprocess and both binning walks (lists bit-exact, 4.59 M candidates) and measured a net loss -- profiles/r06_rows_ab.txt; the
+product enumerates the box.   python scripts/sim/row_codes.py [c3|c5|fuzz] [n]"""
 import sys
 
 import numpy as np
