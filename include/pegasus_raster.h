@@ -344,9 +344,10 @@ int32_t pgr_pose_objects(int32_t n_jobs, const PgrPoseJob *jobs, const double *s
                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* Measurement aid (bench.py's roofline.issue_model; replaces nothing of the reference): ONE wave that reads its two clocks
- * around a sleep loop of spin_us microseconds -- ticks[0] = shader cycles (s_memtime), ticks[1] = 100 MHz ticks
- * (s_memrealtime) -- so ticks[0] / ticks[1] x 100 MHz is the shader clock under whatever runs beside it on other streams.
- * `ticks`: device uint64[2]. */
+ * around a sleep loop of spin_us microseconds (0: no loop, a time stamp) -- ticks[0] = shader cycles (s_memtime), ticks[1] =
+ * 100 MHz ticks (s_memrealtime), ticks[2] / ticks[3] = the 100 MHz counter at its start / end -- so ticks[0] / ticks[1] x
+ * 100 MHz is the shader clock under whatever runs beside it on other streams, and stamps taken on the measured stream show
+ * whether the two really overlapped.  `ticks`: device uint64[4]. */
 int32_t pgr_clock_probe(uint64_t *ticks, uint32_t spin_us, void *stream);
 
 /* Mean squared distance to the 3 nearest neighbours of every point (replaces simple_knn._C.distCUDA2 of the reference's

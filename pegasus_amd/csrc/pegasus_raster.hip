@@ -694,7 +694,8 @@ int32_t pgr_compose_object(int32_t n, const float* xyz, const float* rot, const 
 
 // one wave that watches both of its clocks for spin_us microseconds: s_memtime ticks once per SHADER cycle, s_memrealtime
 // at a constant 100 MHz (MI355X_MICROARCH.md "Per-instruction cycle constants"), so ticks[0] / ticks[1] x 100 MHz is the
-// clock the chip ran at while whatever else was resident ran beside it
+// clock the chip ran at while whatever else was resident ran beside it; ticks[2], ticks[3] = the 100 MHz counter at the
+// start and at the end (two probes on two streams can be checked for having overlapped)
 __global__ void clock_probe_kernel(unsigned long long* __restrict__ ticks, uint32_t spin_us) {
     const unsigned long long r0 = wall_clock64();
     const unsigned long long c0 = __builtin_readcyclecounter();
@@ -704,11 +705,11 @@ __global__ void clock_probe_kernel(unsigned long long* __restrict__ ticks, uint3
         r1 = wall_clock64();
     }
     const unsigned long long c1 = __builtin_readcyclecounter();
-    if (threadIdx.x == 0) { ticks[0] = c1 - c0; ticks[1] = r1 - r0; }
+    if (threadIdx.x == 0) { ticks[0] = c1 - c0; ticks[1] = r1 - r0; ticks[2] = r0; ticks[3] = r1; }
 }
 
 int32_t pgr_clock_probe(uint64_t* ticks, uint32_t spin_us, void* stream_v) {
-    if (!ticks || spin_us == 0 || spin_us > 1000000u) return PGR_ERR_INVALID_ARGUMENT;
+    if (!ticks || spin_us > 1000000u) return PGR_ERR_INVALID_ARGUMENT;
     clock_probe_kernel<<<1, WAVE, 0, static_cast<hipStream_t>(stream_v)>>>(reinterpret_cast<unsigned long long*>(ticks), spin_us);
     return hip_ok(hipGetLastError(), "clock_probe launch") ? PGR_OK : PGR_ERR_LAUNCH_FAILURE;
 }
