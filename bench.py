@@ -334,8 +334,8 @@ class RealEngine:
         """N > 1 with direct records: a rank's only product is the frame record in the gather's send buffer, so its frame
         sets name no image (PgrOutputs color = depth = sem_* = NULL): the compositor writes 3.84 MB per 800x800 frame, not
         29.4 MB of fp32 / mask planes that nothing reads."""
+        self.frames = self.frame_sets[0]           # (one full set stays for the untimed side passes: stage profile, raster-only rate)
         self.frame_sets = [dict() for _ in range(self.n_slots)]
-        self.frames = None
         self.records_only = True
 
     def full_frame_set(self):
@@ -387,7 +387,7 @@ class ClockProbe:
 
     def start(self, spin_us):
         cur = self.torch.cuda.current_stream(self.dev)
-        self.stream = self.torch.cuda.Stream(self.dev, priority=-1)            # a new stream per attempt: another queue
+        self.stream = self.torch.cuda.Stream(self.dev)                         # a new stream per attempt: another queue
         self.ticks.zero_()
         self.stream.wait_stream(cur)
         self._launch(1, 0, cur)                                                # stamp: the measured stream gets here

@@ -122,19 +122,18 @@ def flush_all():
                 keep.append((src, R, t))
         if not jobs:
             break
-        dev = outs[0][2].device
-        if any(o[2].device != dev for o in outs):
-            raise RuntimeError("pose calls on models of different devices are pending; read one of them first")
-        need = int(L.pgr_pose_objects_workspace_bytes(len(jobs)))
-        ws = _workspace.get(dev)
-        if ws is None or ws.numel() < need:
-            ws = _workspace[dev] = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=dev)
-        dirs, pinv = _sh_tables(dev)
-        arr_t = (_lib.PgrPoseJob * len(jobs))(*jobs)
-        with torch.cuda.device(dev):
-            _lib.check(L.pgr_pose_objects(len(jobs), arr_t, C.c_void_p(dirs.data_ptr()), C.c_void_p(pinv.data_ptr()),
-                                          C.c_void_p(ws.data_ptr()), int(ws.numel()),
-                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "pgr_pose_objects")
+        for dev in sorted({o[2].device for o in outs}, key=str):             # one call per device that has jobs this round
+            sel = [i for i, o in enumerate(outs) if o[2].device == dev]
+            need = int(L.pgr_pose_objects_workspace_bytes(len(sel)))
+            ws = _workspace.get(dev)
+            if ws is None or ws.numel() < need:
+                ws = _workspace[dev] = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=dev)
+            dirs, pinv = _sh_tables(dev)
+            arr_t = (_lib.PgrPoseJob * len(sel))(*[jobs[i] for i in sel])
+            with torch.cuda.device(dev):
+                _lib.check(L.pgr_pose_objects(len(sel), arr_t, C.c_void_p(dirs.data_ptr()), C.c_void_p(pinv.data_ptr()),
+                                              C.c_void_p(ws.data_ptr()), int(ws.numel()),
+                                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "pgr_pose_objects")
         for m, arr, dst in outs:
             m.__dict__[arr] = dst
         # (`keep` dies here: the caching allocator hands the sources' blocks out again in stream order, behind the launches)
