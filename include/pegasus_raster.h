@@ -223,6 +223,19 @@ int32_t pgr_forward_posed_async(const PgrScene *scene, const PgrSemantic *semant
                                 size_t workspace_bytes, int64_t max_instances_per_view, void *host_scratch,
                                 size_t host_scratch_size, void *stream);
 int32_t pgr_batch_status(const void *host_scratch, int32_t n_views, int64_t *num_instances);
+/* pgr_forward_posed_async whose status words reach the host EARLY.  The instance counts and overflow flags are final once the
+ * tile scan has run -- a third into a single-view call -- and nothing later changes them: the scan stores them into
+ * `host_scratch` itself (which must therefore be device-accessible at its host address: hipHostMalloc memory, what torch's
+ * pin_memory() hands out) and `status_event` (a hipEvent_t) is recorded on `stream` right behind it.  After
+ * hipEventSynchronize(status_event), pgr_batch_status(host_scratch, ...) is valid while scatter, sort and compositor still
+ * run: the caller of a single view (PEGASUS's render(), /root/reference/src/gs/render.py:17-24 -- the upstream rasterizer
+ * blocks on its own instance count in the middle of every call the same way) returns to its host code without leaving the
+ * GPU idle; the outputs are complete in STREAM order, as for every asynchronous call.  On PGR_ERR_INSTANCE_OVERFLOW the rest
+ * of the call does nothing; re-run with a larger capacity. */
+int32_t pgr_forward_posed_early_status(const PgrScene *scene, const PgrSemantic *semantic, const PgrPosedObjects *posed,
+                                       int32_t n_views, const PgrCamera *cameras, const PgrOutputs *outs, void *workspace,
+                                       size_t workspace_bytes, int64_t max_instances_per_view, void *host_scratch,
+                                       size_t host_scratch_size, void *stream, void *status_event);
 
 /* Per-SCENE constants the batch calls would otherwise rebuild on every call (round 3: invert_tie_index_kernel and
  * pack_object_ids_kernel, 24 us + 76 MB of traffic per batch of the 2 M-Gaussian scene): the inverse of

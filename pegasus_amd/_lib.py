@@ -118,6 +118,9 @@ SYMBOLS = {
     "pgr_forward_posed_async": (C.c_int32, [C.POINTER(PgrScene), C.POINTER(PgrSemantic), C.POINTER(PgrPosedObjects),
                                             C.c_int32, C.POINTER(PgrCamera), C.POINTER(PgrOutputs), C.c_void_p,
                                             C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pgr_forward_posed_early_status": (C.c_int32, [C.POINTER(PgrScene), C.POINTER(PgrSemantic), C.POINTER(PgrPosedObjects),
+                                                   C.c_int32, C.POINTER(PgrCamera), C.POINTER(PgrOutputs), C.c_void_p,
+                                                   C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "pgr_batch_status": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "pgr_scene_cache_bytes": (C.c_size_t, [C.c_int32]),
     "pgr_scene_prepare": (C.c_int32, [C.POINTER(PgrScene), C.POINTER(PgrSemantic), C.c_void_p, C.c_size_t,

@@ -215,7 +215,8 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
                                   void* workspace, size_t workspace_bytes, int64_t max_instances,
                                   int64_t* num_instances, hipStream_t stream, hipEvent_t* ev,
                                   void* host_scratch = nullptr, const PgrSemantic* semantic = nullptr,
-                                  const PgrPosedObjects* posed = nullptr, const PgrLayers* layers = nullptr) {
+                                  const PgrPosedObjects* posed = nullptr, const PgrLayers* layers = nullptr,
+                                  hipEvent_t status_event = nullptr) {
     auto mark = [&](int k) { if (ev) (void)hipEventRecord(ev[k], stream); };
     // every argument check happens here, before the first enqueue: an early return below this block would leave work
     // on the stream that still reads the (pageable) table staging of the synchronous path
@@ -256,6 +257,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     if (N == 0) {
         for (int v = 0; v < n_views; ++v)
             if (int rc = zero_outputs(&outs[v], P, stream, layers ? n_layers : (semantic && semantic->mask_colors ? semantic->k_objects : 0))) return rc;
+        if (status_event && !hip_ok(hipEventRecord(status_event, stream), "record status event")) return PGR_ERR_LAUNCH_FAILURE;
         return PGR_OK;
     }
 
@@ -374,7 +376,10 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     // tile scan -> ranges; the same pass counts the compositor's work items per (XCD stream, length class) and its last
     // workgroup turns the counts into the streams' write cursors
     tile_scan_kernel<<<n_views, 1024, 0, stream>>>(bin_table, L.tiles, (uint32_t)max_instances, L.grid_x, order_state,
-                                                   layers ? 1 : 0);
+                                                   layers ? 1 : 0, status_event ? h_status : nullptr);
+    // early status: the scan wrote the status words into the pinned host scratch itself; whoever waits for this event reads
+    // them two thirds of a single-view call before its compositor ends
+    if (status_event && !hip_ok(hipEventRecord(status_event, stream), "record status event")) return fail(PGR_ERR_LAUNCH_FAILURE);
     mark(2);
     // ---- stage 2: scatter (depth bits, index) into the tiles' slices
     if (few_views)
@@ -397,8 +402,8 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         // 8193..15872 keys: the windowed sort (two workgroups per CU); longer: the split pre-pass, whose depth segments the
         // 512 x 16 tier's kernel sorts from the segment queue; what either rejects joins the open-ended kernel's queue
         // (one launch: its first workgroups run the split pre-pass, the windowed sort fills the chip beside them)
-        const int part_blocks = std::min(items, 1024);
-        tile_sort_window_kernel<<<part_blocks + std::min(items, 2048), SORT_WINDOW_THREADS, 0, stream>>>(
+        const int part_blocks = std::min(items, 1024);          // every third workgroup: 3 x part_blocks in all, two thirds sort
+        tile_sort_window_kernel<<<3 * part_blocks, SORT_WINDOW_THREADS, 0, stream>>>(
             bin_table, L.tiles, sort_queue + 3 * qs, n_queue + 3, sort_queue + 5 * qs, n_open, (uint32_t)part_blocks,
             sort_queue + 4 * qs, n_queue + 4, sort_queue + SORT_TIERS * qs, order_state + ORDER_SEG_WORD, (uint32_t)B.seg_cap);
     }
@@ -451,6 +456,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     mark(5);
     if (!hip_ok(hipGetLastError(), "kernel launch")) return fail(PGR_ERR_LAUNCH_FAILURE);
 
+    if (status_event) return PGR_OK;       // the status words reached the host behind the scan
     // the only host read of the batch: instance counts + overflow flags, after everything is enqueued
     if (!hip_ok(hipMemcpyAsync(h_status, status_dev, (size_t)n_views * 8, hipMemcpyDeviceToHost, stream), "memcpy status"))
         return fail(PGR_ERR_LAUNCH_FAILURE);
@@ -560,6 +566,18 @@ int32_t pgr_forward_posed_async(const PgrScene* scene, const PgrSemantic* semant
     if (scene && scene->n == 0) memset(static_cast<char*>(host_scratch), 0, host_scratch_bytes(n_views));
     return forward_batch_impl(scene, n_views, cameras, outs, workspace, workspace_bytes, max_instances_per_view, nullptr,
                               static_cast<hipStream_t>(stream_v), nullptr, host_scratch, semantic, posed);
+}
+
+int32_t pgr_forward_posed_early_status(const PgrScene* scene, const PgrSemantic* semantic, const PgrPosedObjects* posed,
+                                       int32_t n_views, const PgrCamera* cameras, const PgrOutputs* outs, void* workspace,
+                                       size_t workspace_bytes, int64_t max_instances_per_view, void* host_scratch,
+                                       size_t host_scratch_size, void* stream_v, void* status_event) {
+    if (!host_scratch || !status_event || n_views <= 0 || host_scratch_size < host_scratch_bytes(n_views))
+        return PGR_ERR_INVALID_ARGUMENT;
+    if (scene && scene->n == 0) memset(static_cast<char*>(host_scratch), 0, host_scratch_bytes(n_views));
+    return forward_batch_impl(scene, n_views, cameras, outs, workspace, workspace_bytes, max_instances_per_view, nullptr,
+                              static_cast<hipStream_t>(stream_v), nullptr, host_scratch, semantic, posed, nullptr,
+                              static_cast<hipEvent_t>(status_event));
 }
 
 size_t pgr_layers_workspace_bytes(int32_t n, int32_t width, int32_t height, int64_t max_instances, int32_t n_views,

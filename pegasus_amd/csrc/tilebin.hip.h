@@ -13,11 +13,14 @@
 //                overflow flag -- all on the device, no host round trip.
 //   bin_scatter  same chunks: LDS cursors = range start + rel; every instance takes its slot with an
 //                LDS atomic and stores (depth bits, index) = 8 B.
-//   tile_sort    one workgroup per tile: the list is sorted by the 64-bit key (depth bits << 32 | index)
-//                in LDS (register sorting network + merge-path rounds), which is exactly the order of a
-//                stable sort of Gaussian-major emission by (tile, depth) -- the order the compositor's
-//                blending depends on.  Tiers: <= 4096 keys (256 threads, 32 KiB), <= 16384 keys (1024
-//                threads, 128 KiB of the CU's 160 KiB); longer lists are sorted in place in global memory.
+//   tile_sort    one workgroup per tile list: sorted by the 64-bit key (depth bits << 32 | index) in LDS -- a bucket sort on
+//                the depth bits with position-owned ranking, a merge sort where depths pile up -- which is exactly the order
+//                of a stable sort of Gaussian-major emission by (tile, depth), the order the compositor's blending depends
+//                on.  One launch per length tier: <= 2048 keys (256 threads, 7 workgroups per CU), <= 4096 (512 x 8),
+//                <= 8192 (512 x 16; also the depth segments of the longest lists), 8193..15872 (windowed sort: depths in
+//                registers, the key image filled window by window; its launch carries the split pre-pass that cuts longer
+//                lists into segments), and the open-ended kernel (157 KiB: one- and two-view calls, and whatever the
+//                others reject).
 //
 // Everything is integer/bit work: bit-exact against the oracle's sorted lists.
 #pragma once
@@ -353,7 +356,8 @@ __global__ void invert_tie_index_kernel(int n, const int32_t* __restrict__ tie_i
 // workgroup to finish (agent-scope ticket behind a fence) turns the counts into the streams' write cursors.
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const BinView* __restrict__ views, int tiles,
                                                          uint32_t max_instances, int grid_x,
-                                                         uint32_t* __restrict__ order_state, int skip_empty) {
+                                                         uint32_t* __restrict__ order_state, int skip_empty,
+                                                         uint32_t* __restrict__ host_status) {
     __shared__ unsigned long long wave_tot[1024 / WAVE];
     __shared__ unsigned long long carry_s;
     __shared__ uint32_t hist[ORDER_BINS];
@@ -391,8 +395,18 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const BinView* __restri
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        bv.counters[0] = (uint32_t)min(carry_s, 0xffffffffull);
-        bv.counters[1] = carry_s > (unsigned long long)max_instances ? 1u : 0u;
+        const uint32_t total = (uint32_t)min(carry_s, 0xffffffffull);
+        const uint32_t over = carry_s > (unsigned long long)max_instances ? 1u : 0u;
+        bv.counters[0] = total;
+        bv.counters[1] = over;
+        // early status (pgr_forward_posed_early_status): the two words are FINAL here -- nothing after the scan changes them --
+        // so they go straight to the caller's pinned host memory, and the event recorded behind this kernel lets the host
+        // decide about an overflow while scatter, sort and compositor still run
+        if (host_status) {
+            host_status[2 * blockIdx.x] = total;
+            host_status[2 * blockIdx.x + 1] = over;
+            __threadfence_system();
+        }
     }
     if (!order_state) return;
     if (gridDim.x == 1) {
@@ -1195,9 +1209,11 @@ __global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const BinView* 
 //   (512, 16)   4097..8192 keys over SORT_T2_BUCKETS = 3584 buckets, 80 KiB: two per CU (round 5; rounds 2-4 used 1024 x 8
 //               with one bucket per key, 96 KiB, one per CU: C3 sort stage 0.0237 -> 0.0229 ms per view, C5 0.0744 ->
 //               0.0708, profiles/r05_sort_tier_shapes_ab.txt; the same treatment of the 2049..4096 tier returned nothing);
-//   (1024, 16)  LAST, open-ended: 8193..16000 keys over 8192 buckets (157 KiB), anything longer depth-partitioned into
+//   (1024, 16)  LAST, open-ended: up to 16000 keys over 8192 buckets (157 KiB), anything longer depth-partitioned into
 //               LDS-sized segments or, failing that, merge-sorted 16384-key chunks merged through L2 between the list
-//               and its alt buffer.
+//               and its alt buffer.  Since round 6 only one- and two-view calls send their long lists here; a batch sorts
+//               8193..15872 keys with the windowed sort and longer lists through the split pre-pass (below), and this
+//               kernel takes what those reject.
 // A kernel per tier keeps each one's register budget its own: with the open-ended tier's code in the same kernel the
 // 4097..8192 path (a quarter of C3's keys) ran out of the 128 VGPRs a 1024-thread workgroup gets and spilled.
 // SEG: behind the tier's own lists the launch also sorts the depth SEGMENTS of longer lists (the split pre-pass's segment
@@ -1406,14 +1422,18 @@ __global__ __launch_bounds__(SORT_WINDOW_THREADS, 4) void tile_sort_window_kerne
     __shared__ uint32_t s_win[2 * (SORT_WINDOW_ROUNDS + 1) + 2];
     // every third workgroup of the launch's front is a pre-pass workgroup: the two kinds are resident side by side from the
     // start (all pre-pass workgroups first would fill the chip alone -- workgroups are dispatched in order)
-    const uint32_t part_before = min(part_blocks, (blockIdx.x + 2u) / 3u);        // pre-pass workgroups among [0, blockIdx.x)
-    if (blockIdx.x % 3u == 0u && blockIdx.x / 3u < part_blocks) {
+    // (part_eff: the pre-pass workgroups that exist in THIS grid -- every one of them must be there, they stride over their
+    // queue by their own number)
+    const uint32_t part_eff = min(part_blocks, (gridDim.x + 2u) / 3u);
+    const uint32_t part_before = min(part_eff, (blockIdx.x + 2u) / 3u);           // pre-pass workgroups among [0, blockIdx.x)
+    if (blockIdx.x % 3u == 0u && blockIdx.x / 3u < part_eff) {
         partition_lists(reinterpret_cast<uint32_t*>(lds), views, tiles, part_queue, n_part, seg_queue, n_seg, seg_cap, open_queue,
-                        n_open, blockIdx.x / 3u, part_blocks);
+                        n_open, blockIdx.x / 3u, part_eff);
         return;
     }
+    if (gridDim.x == part_eff) return;                                            // (no workgroup left for the windowed sort: not launched so)
     const uint32_t cand = *n_queue;
-    for (uint32_t k = blockIdx.x - part_before; k < cand; k += gridDim.x - part_blocks) {
+    for (uint32_t k = blockIdx.x - part_before; k < cand; k += gridDim.x - part_eff) {
         const uint4 q = queue[k];
         const uint2* bucket; uint32_t* out; int n; ObjOut oo;
         sort_item(views, tiles, q, bucket, out, n, oo);

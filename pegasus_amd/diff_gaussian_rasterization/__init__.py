@@ -53,19 +53,21 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     """Forward rasterization of one view.  Returns (color, radii, depth) -- plus (final_T, n_contrib)
     when ``want_aux``.
 
-    The call is ENQUEUED without a host round trip (pgr_forward_posed_async: tables through pinned memory), then
+    The call is ENQUEUED without a host round trip (pgr_forward_posed_early_status: tables through pinned memory), then
     ``after_enqueue(result_dict)`` runs -- work that only needs the outputs in stream order, e.g. render()'s visibility
-    filter, is queued behind the compositor while the GPU is still busy -- and only then the host waits for the batch's
-    status words.  A single view leaves the GPU idle between its kernels, so host microseconds after the wait are
-    wall-clock microseconds (round 5: 0.54 -> see profiles/r05_single_view_timeline.txt).  ``after_enqueue`` runs again
-    if an instance overflow re-rendered the view."""
+    filter, is queued behind the compositor -- and then the host waits for the call's STATUS WORDS only, which are final
+    behind the tile scan (a third into the call: the one thing the host has to decide is whether the instance capacity
+    held).  The function returns while scatter, sort and compositor still run; the tensors it returns are complete in
+    stream order, like the result of any torch operation.  Until round 6 it waited for the end of the call, and the GPU
+    idled for the host code between two render() calls (78 us of a 0.50 ms call, profiles/r06_single_view_timeline.txt).
+    ``after_enqueue`` runs again if an instance overflow re-rendered the view."""
     rs = raster_settings
     view = rasterizer.ViewSpec(rs.image_height, rs.image_width, rs.tanfovx, rs.tanfovy, rs.bg, rs.viewmatrix,
                                rs.projmatrix, rs.campos)
     pb = rasterizer.forward_views(means3D, opacities, [view], shs=sh, colors_precomp=colors_precomp, scales=scales,
                                   rotations=rotations, cov3D_precomp=cov3Ds_precomp, sh_degree=rs.sh_degree,
                                   scale_modifier=rs.scale_modifier, want_radii=True, want_aux=want_aux,
-                                  async_slot=("single-view", 0))
+                                  async_slot=("single-view", 0), early_status=True)
     if isinstance(pb, list):            # (an empty view list cannot happen here; an empty SCENE still returns a handle)
         r = pb[0]
     else:

@@ -55,6 +55,17 @@ class _Workspace:
             self.buf[key] = t
         return t
 
+    def status_event(self, device, slot) -> torch.cuda.Event:
+        """One event per asynchronous slot for pgr_forward_posed_early_status.  torch creates the HIP event at the first
+        record(); after that ``cuda_event`` is the handle the library records again on every call."""
+        key = ("status-event", device, slot)
+        ev = self.buf.get(key)
+        if ev is None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+            self.buf[key] = ev
+        return ev
+
 
 _WS = _Workspace()
 _LAST_INFO: dict = {}
@@ -170,7 +181,7 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
                   rotations=None, cov3D_precomp=None, sh_degree=0, scale_modifier=1.0, want_radii=True,
                   want_aux=False, stage_ms: Optional[list] = None, outputs: Optional[list] = None,
                   async_slot=None, semantic: Optional[dict] = None, posed: Optional[dict] = None, tie_index=None,
-                  tie_inv=None, layers: Optional[dict] = None):
+                  tie_inv=None, layers: Optional[dict] = None, early_status: bool = False):
     """Renders ``len(views)`` views of one scene.  Returns a list of dicts with keys
     color[3,H,W], depth[1,H,W], radii[N] (or None), and final_T / n_contrib when ``want_aux``.
 
@@ -179,6 +190,9 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
     ``outputs``: optional pre-allocated list of dicts (same keys) to render into.
     ``async_slot``: not None -> enqueue on torch's CURRENT stream without synchronising and return a
     PendingBatch; the slot names the workspace / pinned scratch to use (one batch in flight per slot).
+    ``early_status`` (with ``async_slot``, not layered): PendingBatch.wait() returns as soon as the call's status words are
+    final -- behind the tile scan, pgr_forward_posed_early_status -- instead of at the end of the call; the outputs are
+    complete in stream order (whatever the caller queues on the current stream, or fetches with .cpu(), comes after them).
     ``semantic``: dict(object_id int32[N], colors float32[K,3], n_env, k) -> the fused objects-only semantic
     render is written to r["sem_color"] (and r["sem_depth"]) of every view (pgr_forward_frames_async).
     ``semantic`` may also carry ``mask_colors`` float32[K,3] (+ ``mask_threshold``): every output dict with a ``sem_masks``
@@ -315,14 +329,23 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
                                                       cams, outs, C.c_void_p(ws.data_ptr()), ws.numel(), max_inst,
                                                       C.c_void_p(scratch.data_ptr()), scratch.numel(), stream),
                            "pgr_forward_layers_async")
+            elif early_status:
+                ev = _WS.status_event(device, async_slot)
+                _lib.check(L.pgr_forward_posed_early_status(C.byref(scene), C.byref(sem_struct) if sem_struct else None,
+                                                            C.byref(posed_struct) if posed_struct else None, nv,
+                                                            cams, outs, C.c_void_p(ws.data_ptr()), ws.numel(), max_inst,
+                                                            C.c_void_p(scratch.data_ptr()), scratch.numel(), stream,
+                                                            C.c_void_p(ev.cuda_event)),
+                           "pgr_forward_posed_early_status")
             else:
                 _lib.check(L.pgr_forward_posed_async(C.byref(scene), C.byref(sem_struct) if sem_struct else None,
                                                      C.byref(posed_struct) if posed_struct else None, nv,
                                                      cams, outs, C.c_void_p(ws.data_ptr()), ws.numel(), max_inst,
                                                      C.c_void_p(scratch.data_ptr()), scratch.numel(), stream),
                            "pgr_forward_posed_async")
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(device))
+            if not (early_status and layers_struct is None):
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(device))
         kw = dict(shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
                   cov3D_precomp=cov3D_precomp, sh_degree=sh_degree, scale_modifier=scale_modifier,
                   want_radii=want_radii, want_aux=want_aux, outputs=results, semantic=semantic, posed=posed,

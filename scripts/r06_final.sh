@@ -29,6 +29,21 @@ bash scripts/trace_run.sh r06 --no-drop-in > /dev/null 2>&1
 bash scripts/trace_run.sh r06_sync --no-drop-in --sync-steps > /dev/null 2>&1
 bash scripts/trace_run.sh r06_c5_sync --no-drop-in --sync-steps --workload c5 --views 200 > /dev/null 2>&1
 bash scripts/single_view_trace.sh r06 40 c3 > /dev/null 2>&1
+# records-only frame sets against full ones: frames/s interleaved, then the compositor's WRITE_SIZE per launch of each form
+( python scripts/records_only_ab.py both 3 2>&1 | grep -v amdgpu.ids
+  for kind in full records; do
+    rm -rf /tmp/ro_$kind
+    ( cd /tmp && TMPDIR=/tmp timeout 600 rocprofv3 --pmc WRITE_SIZE -d /tmp/ro_$kind -- python3 $GRAFT_REPO_ROOT/scripts/records_only_ab.py $kind 1 > /tmp/ro_$kind.log 2>&1 )
+    python - $kind "$(find /tmp/ro_$kind -name '*.db' | head -1)" <<'PY'
+import sys
+sys.path.insert(0, "scripts")
+import pmc_report
+acc, disp = pmc_report.read(sys.argv[2])
+for k in sorted(acc):
+    if "WRITE_SIZE" in acc[k]:
+        print(f"  {sys.argv[1]:8s} {k:44s} WRITE_SIZE {acc[k]['WRITE_SIZE'] / len(disp[k]) * 1024 / 1e6:9.3f} MB per launch ({len(disp[k])} launches of 32 views)")
+PY
+  done ) > ${P}_records_only.txt 2>&1
 python scripts/silhouette_time.py 2>&1 | grep -v amdgpu.ids > ${P}_silhouette_time.txt
 ( python scripts/fuzz_parity.py 90000 1500 2>&1 | tail -1; python scripts/fuzz_fused.py 5000 200 2>&1 | tail -1; python scripts/fuzz_layered.py 3000 100 2>&1 | tail -1
   python scripts/soak_determinism.py 4 c3 2>&1 | tail -1; python scripts/full_size_parity.py 2>&1 | tail -1 ) | grep -v amdgpu.ids > ${P}_verification.txt
@@ -43,4 +58,4 @@ except Exception as e:
     print(sys.argv[1], "unreadable:", e)
 PY
 done
-cat ${P}_pytest_gpu.txt ${P}_silhouette_time.txt ${P}_verification.txt
+cat ${P}_pytest_gpu.txt ${P}_records_only.txt ${P}_silhouette_time.txt ${P}_verification.txt

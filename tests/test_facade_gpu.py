@@ -465,3 +465,59 @@ def test_render_after_an_instance_overflow_redoes_the_queued_visibility_filter(g
         for k in ("render", "depth", "radii", "visibility_filter"):
             assert torch.equal(again[k], first[k]), k
         assert int(again["visibility_filter"].sum()) == int((first["radii"] > 0).sum()) > 0
+
+
+@pytest.mark.gpu
+def test_render_returns_behind_the_tile_scan_with_stream_ordered_outputs(gpu_device):
+    """render() waits for the call's STATUS WORDS only (pgr_forward_posed_early_status: final behind the tile scan) and returns
+    while scatter, sort and compositor still run.  What the caller does next is ordered behind them by the stream: a clone
+    queued straight after the return, a second render() into the SAME workspace, and an in-place edit of the model between two
+    calls must all see complete images -- equal to the synchronous batch call's."""
+    import sys
+    from argparse import ArgumentParser
+    import torch
+    root = str(Path(__file__).resolve().parents[1])
+    for p in (root, root + "/compat"):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from gaussian_renderer import render, GaussianModel
+    from scene.cameras import Camera
+    from arguments import PipelineParams
+    from pegasus_amd import rasterizer as R, scenes
+    dev = torch.device(gpu_device)
+    cloud, views = scenes.scene_c3(scale=0.05, n_views=3, width=400, height=304)
+    with torch.no_grad():
+        pc = GaussianModel.from_arrays(cloud.xyz, cloud.features_dc, cloud.features_rest, cloud.opacity, cloud.scaling,
+                                       cloud.rotation, device=dev)
+        cams = [Camera(colmap_id=i, R=v.R_c2w, T=v.t_w2c, FoVx=v.fovx, FoVy=v.fovy, image=None, image_width=v.width,
+                       image_height=v.height, gt_alpha_mask=None, image_name=str(i), uid=i, data_device=str(dev))
+                for i, v in enumerate(views)]
+        pipe = PipelineParams(ArgumentParser())
+        bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+
+        def sync_reference(cam):
+            spec = R.ViewSpec(int(cam.image_height), int(cam.image_width), math.tan(0.5 * cam.FoVx), math.tan(0.5 * cam.FoVy),
+                              bg, cam.world_view_transform, cam.full_proj_transform, cam.camera_center)
+            r = R.forward_views(pc.get_xyz, pc.get_opacity, [spec], shs=pc.get_features, scales=pc.get_scaling,
+                                rotations=pc.get_rotation, sh_degree=pc.active_sh_degree, want_radii=True)[0]
+            torch.cuda.synchronize()
+            return {k: r[k].clone() for k in ("color", "depth", "radii")}
+
+        want = [sync_reference(c) for c in cams]
+        for rep in range(3):                       # back to back, nothing synchronises in between
+            got = []
+            for c in cams:
+                out = render(c, pc, pipe, bg)
+                got.append((out["render"].clone(), out["depth"].clone(), out["radii"].clone(), out["visibility_filter"].clone()))
+            for g, w in zip(got, want):
+                assert torch.equal(g[0], w["color"]) and torch.equal(g[1], w["depth"]) and torch.equal(g[2], w["radii"])
+                assert torch.equal(g[3], w["radii"] > 0)
+        info = R.last_forward_info()
+        assert int(info["num_instances"][0]) > 0 and info["n_views"] == 1
+        # an in-place edit of the model right behind a call lands AFTER that call's preprocess in stream order
+        before = render(cams[0], pc, pipe, bg)["render"]
+        pc._xyz[:, 2] += 0.05
+        moved = render(cams[0], pc, pipe, bg)["render"].clone()
+        pc._xyz[:, 2] -= 0.05
+        assert torch.equal(before, want[0]["color"])
+        assert not torch.equal(moved, want[0]["color"])

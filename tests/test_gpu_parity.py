@@ -502,6 +502,40 @@ def test_windowed_sort_with_scattered_depth_ties(oracle, gpu_device, n, pairs):
             np.testing.assert_array_equal(w["gauss_sorted"], want["gauss_sorted"], err_msg=f"view {k}")
 
 
+def test_every_tile_of_a_small_image_holds_a_long_list(oracle, gpu_device):
+    """A 64x64 image (16 tiles) whose every tile lists 14-35 k pinpoint splats, three views per call: 36 of the batch's 48
+    lists go through the split pre-pass (the launch that carries its workgroups is sized by the number of tiles -- here a
+    small one -- not by a constant) and their segments through the 512 x 16 kernel, the 12 corner lists through the
+    windowed sort -- lists bit-exact against the oracle."""
+    import torch
+    from helpers import fetch_workspace
+    from pegasus_amd import graphics as G, rasterizer as R
+    rng = np.random.default_rng(77)
+    n = 320_000
+    cloud, _ = scenes.scene_c1(seed=9, n=n)
+    cloud.xyz[:, 0] = rng.uniform(-0.9, 0.9, n).astype(np.float32)
+    cloud.xyz[:, 1] = rng.uniform(-0.9, 0.9, n).astype(np.float32)
+    cloud.xyz[:, 2] = rng.normal(0, 0.3, n).astype(np.float32)
+    cloud.scaling[:] = np.log(0.0005).astype(np.float32)
+    cloud.opacity[:] = rng.normal(-3.0, 0.5, size=(n, 1)).astype(np.float32)
+    Rm, t = G.look_at_opencv((0.0, 0.0, -3.0), (0, 0, 0), up=(0, -1, 0))
+    v = scenes.make_view(Rm, t, 64, 64, fovx=math.radians(40), fovy=math.radians(40))
+    act = cloud.activated()
+    o = oracle.forward(**act, sh_degree=3, **v.raster_kwargs(), num_threads=8, cull_mode=1)
+    lens = o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]
+    assert lens.size == 16 and lens.min() > 8192 and (lens > 15872).sum() == 12, lens
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(gpu_device)
+    spec = R.ViewSpec(v.height, v.width, v.tanfovx, v.tanfovy, tt(np.zeros(3)), tt(v.world_view_transform),
+                      tt(v.full_proj_transform), tt(v.camera_center))
+    T = {k: tt(a) for k, a in act.items()}
+    R.forward_views(T["means3d"], T["opacities"], [spec] * 3, shs=T["shs"], scales=T["scales"], rotations=T["rotations"],
+                    sh_degree=3, want_radii=True, want_aux=True)
+    torch.cuda.synchronize()
+    for k in range(3):
+        w = fetch_workspace(k, n, v.width, v.height)
+        np.testing.assert_array_equal(w["gauss_sorted"], o["gauss_sorted"], err_msg=f"view {k}")
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_hostile_inputs_do_not_fault_and_match_oracle(oracle, gpu_device, seed):
     """NaN / Inf positions, huge and vanishing scales, opacity exactly 0 and 1, zero and unnormalised quaternions,
