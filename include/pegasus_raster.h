@@ -74,6 +74,13 @@ typedef struct PgrScene {
     const uint32_t *tie_inv;     /* [n] inverse permutation of tie_index (tie_inv[tie_index[i]] = i), or NULL = the library
                                     rebuilds it in its workspace on every call.  A per-SCENE constant: pgr_scene_prepare
                                     computes it once into caller-owned memory. */
+    const float *shs_rest;       /* optional: [n,sh_stride-1,3] -- the SH coefficients as PEGASUS's model STORES them, in two
+                                    tensors: `shs` is then _features_dc [n,1,3] (coefficient 0 only) and this is
+                                    _features_rest (coefficients 1 .. sh_stride-1).  Saves the caller the torch.cat of
+                                    get_features (/root/reference/src/gs/gaussian_model.py:118-121: 768 MB moved per
+                                    render() of a freshly merged 2 M-Gaussian scene).  Same coefficients, same arithmetic:
+                                    results are bit-identical.  Forward entry points only (pgr_backward returns
+                                    PGR_ERR_INVALID_ARGUMENT: its SH gradient is one [n,sh_stride,3] array). */
 } PgrScene;
 
 /* The depth image's blend rule.  The reference's rasterizer is the absent fork `depth-diff-gaussian-rasterization`

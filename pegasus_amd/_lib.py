@@ -30,7 +30,7 @@ class PgrScene(C.Structure):
         ("means3d", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
         ("cov3d_precomp", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
         ("sh_degree", C.c_int32), ("sh_stride", C.c_int32), ("scale_modifier", C.c_float),
-        ("tie_index", C.c_void_p), ("tie_inv", C.c_void_p),
+        ("tie_index", C.c_void_p), ("tie_inv", C.c_void_p), ("shs_rest", C.c_void_p),
     ]
 
 

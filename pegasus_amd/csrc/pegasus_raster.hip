@@ -88,6 +88,7 @@ static int check_scene(const PgrScene* s) {
     if (have_sr == (s->cov3d_precomp != nullptr)) return PGR_ERR_INVALID_ARGUMENT;
     if (s->shs && (s->sh_degree < 0 || s->sh_degree > 3 || s->sh_stride < (s->sh_degree + 1) * (s->sh_degree + 1)))
         return PGR_ERR_INVALID_ARGUMENT;
+    if (s->shs_rest && (!s->shs || s->sh_stride < 2)) return PGR_ERR_INVALID_ARGUMENT;   // split layout: dc + at least one more
     return PGR_OK;
 }
 
@@ -666,6 +667,7 @@ int32_t pgr_backward(const PgrScene* scene, const PgrCamera* cam, const float* g
                      void* stream_v) {
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     if (int rc = check_scene(scene)) return rc;
+    if (scene->shs_rest) return PGR_ERR_INVALID_ARGUMENT;      // the SH gradient is one [n,sh_stride,3] array
     if (!cam || !grads || !grad_color || !final_T || !n_contrib || cam->image_width <= 0 || cam->image_height <= 0)
         return PGR_ERR_INVALID_ARGUMENT;
     const int N = scene->n, W = cam->image_width, H = cam->image_height;

@@ -200,6 +200,21 @@ __device__ __forceinline__ void load_sh(ShRegs& sh, const float* __restrict__ p,
     }
 }
 
+// The split layout (PgrScene::shs_rest): coefficient 0 from the [n,1,3] array, the others from the [n,stride-1,3] one.
+// Rows of 3 and 3 (stride - 1) floats are only 4-B aligned: 12-B loads (global_load_dwordx3), one per coefficient.
+typedef float f32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+template <int DEG>
+__device__ __forceinline__ void load_sh_split(ShRegs& sh, const float* __restrict__ dc, const float* __restrict__ rest) {
+    constexpr int NC = (DEG + 1) * (DEG + 1);
+    const f32x3_a4 c0 = *reinterpret_cast<const f32x3_a4*>(dc);
+    sh.v[0] = c0.x; sh.v[1] = c0.y; sh.v[2] = c0.z;
+#pragma unroll
+    for (int k = 1; k < NC; ++k) {
+        const f32x3_a4 c = *reinterpret_cast<const f32x3_a4*>(rest + 3 * (k - 1));
+        sh.v[3 * k + 0] = c.x; sh.v[3 * k + 1] = c.y; sh.v[3 * k + 2] = c.z;
+    }
+}
+
 // One thread per Gaussian, ALL views of the batch: the 236 B of scene data are read from HBM once per
 // batch instead of once per view (the view-independent 3D covariance is also built once), which turns the
 // kernel from read-bound (~356 MB/view) into write-bound (12 N + 44 V per view).  Per-view arithmetic is
@@ -254,7 +269,7 @@ __global__ __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
     float cov[6];
     bool have_cov = false, have_sh = false;
     ShRegs sh;
-    const bool vec4 = (sc.sh_stride * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(sc.shs) & 15u) == 0;
+    const bool vec4 = !sc.shs_rest && (sc.sh_stride * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(sc.shs) & 15u) == 0;
 
     for (int v = 0; v < n_views; ++v) {
         const CameraDev& cam = cams[v];
@@ -386,7 +401,10 @@ __global__ __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                                           sc.colors_precomp[3 * (size_t)i + 2]);
                     } else {
                         if (!have_sh) {
-                            load_sh<DEG>(sh, sc.shs + (size_t)i * sc.sh_stride * 3, vec4);
+                            if (sc.shs_rest)
+                                load_sh_split<DEG>(sh, sc.shs + (size_t)i * 3, sc.shs_rest + (size_t)i * (sc.sh_stride - 1) * 3);
+                            else
+                                load_sh<DEG>(sh, sc.shs + (size_t)i * sc.sh_stride * 3, vec4);
                             have_sh = true;
                         }
                         float dx = px - cam_cx, dy = py - cam_cy, dz = pz - cam_cz;

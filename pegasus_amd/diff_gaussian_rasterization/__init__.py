@@ -49,7 +49,8 @@ def last_forward_info() -> dict:
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings: GaussianRasterizationSettings, want_aux: bool = False, after_enqueue=None):
+                        raster_settings: GaussianRasterizationSettings, want_aux: bool = False, after_enqueue=None,
+                        sh_rest=None):
     """Forward rasterization of one view.  Returns (color, radii, depth) -- plus (final_T, n_contrib)
     when ``want_aux``.
 
@@ -60,14 +61,16 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     held).  The function returns while scatter, sort and compositor still run; the tensors it returns are complete in
     stream order, like the result of any torch operation.  Until round 6 it waited for the end of the call, and the GPU
     idled for the host code between two render() calls (78 us of a 0.50 ms call, profiles/r06_single_view_timeline.txt).
-    ``after_enqueue`` runs again if an instance overflow re-rendered the view."""
+    ``after_enqueue`` runs again if an instance overflow re-rendered the view.
+    ``sh_rest``: with it, ``sh`` is the model's _features_dc [N,1,3] and ``sh_rest`` its _features_rest [N,K-1,3]
+    (PgrScene::shs_rest) -- the coefficients where they are stored, instead of get_features' concatenation."""
     rs = raster_settings
     view = rasterizer.ViewSpec(rs.image_height, rs.image_width, rs.tanfovx, rs.tanfovy, rs.bg, rs.viewmatrix,
                                rs.projmatrix, rs.campos)
     pb = rasterizer.forward_views(means3D, opacities, [view], shs=sh, colors_precomp=colors_precomp, scales=scales,
                                   rotations=rotations, cov3D_precomp=cov3Ds_precomp, sh_degree=rs.sh_degree,
                                   scale_modifier=rs.scale_modifier, want_radii=True, want_aux=want_aux,
-                                  async_slot=("single-view", 0), early_status=True)
+                                  async_slot=("single-view", 0), early_status=True, shs_rest=sh_rest)
     if isinstance(pb, list):            # (an empty view list cannot happen here; an empty SCENE still returns a handle)
         r = pb[0]
     else:

@@ -104,6 +104,16 @@ def _colour(pc, pipe, cam, override_color) -> dict:
     if override_color is not None:
         return dict(colors_precomp=override_color)
     if not getattr(pipe, "convert_SHs_python", False):
+        # inference: the coefficients where the model stores them (PgrScene::shs_rest) -- get_features is a torch.cat of
+        # _features_dc and _features_rest (/root/reference/src/gs/gaussian_model.py:118-121), 768 MB moved per render() of a
+        # freshly merged 2 M-Gaussian scene, which PEGASUS's loop builds anew for every frame (pegasus.py:255-264)
+        if not torch.is_grad_enabled():
+            dc, rest = getattr(pc, "_features_dc", None), getattr(pc, "_features_rest", None)
+            if (isinstance(dc, torch.Tensor) and isinstance(rest, torch.Tensor) and dc.dim() == 3 and rest.dim() == 3 and
+                    dc.shape[1] == 1 and dc.shape[2] == 3 and rest.shape[2] == 3 and rest.shape[0] == dc.shape[0] and
+                    dc.dtype == torch.float32 and rest.dtype == torch.float32 and dc.is_cuda and rest.device == dc.device and
+                    dc.is_contiguous() and rest.is_contiguous()):
+                return dict(shs=dc, shs_rest=rest)
         return dict(shs=kept_activation(pc, "get_features"))
     coeff = pc.get_features                                        # [N, (max_deg+1)^2, 3]
     towards = torch.nn.functional.normalize(pc.get_xyz - cam.camera_center.reshape(1, 3), dim=1)
@@ -142,6 +152,6 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         image, radii, depth = rasterize_gaussians(
             inputs["means3D"], inputs["means2D"], inputs.get("shs"), inputs.get("colors_precomp"), inputs["opacities"],
             inputs.get("scales"), inputs.get("rotations"), inputs.get("cov3D_precomp"), settings,
-            after_enqueue=lambda r: extra.__setitem__("vis", r["radii"] > 0))
+            after_enqueue=lambda r: extra.__setitem__("vis", r["radii"] > 0), sh_rest=inputs.get("shs_rest"))
         return {"render": image, "depth": depth, "viewspace_points": probe, "visibility_filter": extra["vis"], "radii": radii}
     return {"render": image, "depth": depth, "viewspace_points": probe, "visibility_filter": radii > 0, "radii": radii}

@@ -181,7 +181,7 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
                   rotations=None, cov3D_precomp=None, sh_degree=0, scale_modifier=1.0, want_radii=True,
                   want_aux=False, stage_ms: Optional[list] = None, outputs: Optional[list] = None,
                   async_slot=None, semantic: Optional[dict] = None, posed: Optional[dict] = None, tie_index=None,
-                  tie_inv=None, layers: Optional[dict] = None, early_status: bool = False):
+                  tie_inv=None, layers: Optional[dict] = None, early_status: bool = False, shs_rest=None):
     """Renders ``len(views)`` views of one scene.  Returns a list of dicts with keys
     color[3,H,W], depth[1,H,W], radii[N] (or None), and final_T / n_contrib when ``want_aux``.
 
@@ -190,6 +190,8 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
     ``outputs``: optional pre-allocated list of dicts (same keys) to render into.
     ``async_slot``: not None -> enqueue on torch's CURRENT stream without synchronising and return a
     PendingBatch; the slot names the workspace / pinned scratch to use (one batch in flight per slot).
+    ``shs_rest``: the SH coefficients as the model stores them -- ``shs`` = _features_dc [N,1,3], ``shs_rest`` = _features_rest
+    [N,K-1,3] (PgrScene::shs_rest) -- instead of their concatenation; results are bit-identical.
     ``early_status`` (with ``async_slot``, not layered): PendingBatch.wait() returns as soon as the call's status words are
     final -- behind the tile scan, pgr_forward_posed_early_status -- instead of at the end of the call; the outputs are
     complete in stream order (whatever the caller queues on the current stream, or fetches with .cpu(), comes after them).
@@ -222,6 +224,12 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
     means3D = dev_f32(means3D, device)
     opacities = dev_f32(opacities, device)
     shs = dev_f32(shs, device)
+    shs_rest = dev_f32(shs_rest, device)
+    if shs_rest is not None:
+        if shs is None or shs.dim() != 3 or shs.shape[1] != 1 or shs_rest.dim() != 3 or shs_rest.shape[0] != shs.shape[0]:
+            raise ValueError("shs_rest goes with shs = [N,1,3] (the first coefficient) and is [N,K-1,3]")
+        if shs_rest.shape[1] == 0:
+            shs_rest = None                        # nothing but the first coefficient: the plain layout with stride 1
     colors_precomp = dev_f32(colors_precomp, device)
     scales = dev_f32(scales, device)
     rotations = dev_f32(rotations, device)
@@ -230,8 +238,10 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
     scene = _lib.PgrScene(
         n=n, means3d=_ptr(means3D), opacities=_ptr(opacities), scales=_ptr(scales), rotations=_ptr(rotations),
         cov3d_precomp=_ptr(cov3D_precomp), shs=_ptr(shs), colors_precomp=_ptr(colors_precomp),
-        sh_degree=int(sh_degree), sh_stride=int(shs.shape[1]) if shs is not None else 0,
-        scale_modifier=float(scale_modifier), tie_index=_ptr(tie_index), tie_inv=_ptr(tie_inv) if tie_index is not None else None)
+        sh_degree=int(sh_degree),
+        sh_stride=(int(shs.shape[1]) + (int(shs_rest.shape[1]) if shs_rest is not None else 0)) if shs is not None else 0,
+        scale_modifier=float(scale_modifier), tie_index=_ptr(tie_index), tie_inv=_ptr(tie_inv) if tie_index is not None else None,
+        shs_rest=_ptr(shs_rest))
 
     cams = (_lib.PgrCamera * nv)()
     outs = (_lib.PgrOutputs * nv)()
@@ -295,7 +305,7 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
         max_inst = _WS.capacity_hint.get(key, max(1 << 20, 6 * n))
     if semantic is not None or posed is not None:
         if async_slot is None and stage_ms is None:      # synchronous fused call: enqueue asynchronously, wait, retry on overflow
-            kw = dict(shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
+            kw = dict(shs=shs, shs_rest=shs_rest, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
                       cov3D_precomp=cov3D_precomp, sh_degree=sh_degree, scale_modifier=scale_modifier,
                       want_radii=want_radii, want_aux=want_aux, outputs=results, semantic=semantic, posed=posed,
                       tie_index=tie_index, tie_inv=tie_inv)
@@ -346,7 +356,7 @@ def forward_views(means3D, opacities, views: Sequence[ViewSpec], *, shs=None, co
             if not (early_status and layers_struct is None):
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(device))
-        kw = dict(shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
+        kw = dict(shs=shs, shs_rest=shs_rest, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
                   cov3D_precomp=cov3D_precomp, sh_degree=sh_degree, scale_modifier=scale_modifier,
                   want_radii=want_radii, want_aux=want_aux, outputs=results, semantic=semantic, posed=posed,
                   tie_index=tie_index, tie_inv=tie_inv)

@@ -126,6 +126,18 @@ def test_new_entry_points_validate_before_any_launch():
     out_m = _lib.PgrOutputs(color=fake, depth=fake, sem_color=fake, sem_masks=fake)
     assert lib.pgr_forward_frames_async(C.byref(scene), C.byref(sem), 1, C.byref(cam), C.byref(out_m), None, 0, 100, scratch,
                                         len(scratch), None) == _lib.PGR_ERR_INVALID_ARGUMENT
+    # the split SH layout (PgrScene::shs_rest): needs the first coefficient in `shs` and room for more than one; the
+    # backward takes the concatenated layout only (its SH gradient is one array)
+    for bad_scene in (_lib.PgrScene(n=10, means3d=fake, opacities=fake, scales=fake, rotations=fake, colors_precomp=fake,
+                                    shs_rest=fake, scale_modifier=1.0),
+                      _lib.PgrScene(n=10, means3d=fake, opacities=fake, scales=fake, rotations=fake, shs=fake, shs_rest=fake,
+                                    sh_degree=0, sh_stride=1, scale_modifier=1.0)):
+        assert lib.pgr_forward(C.byref(bad_scene), C.byref(cam), C.byref(out), None, 0, 100, C.byref(need), None) == _lib.PGR_ERR_INVALID_ARGUMENT
+    split = _lib.PgrScene(n=10, means3d=fake, opacities=fake, scales=fake, rotations=fake, shs=fake, shs_rest=fake, sh_degree=3,
+                          sh_stride=16, scale_modifier=1.0)
+    grads = _lib.PgrGradOutputs()
+    assert lib.pgr_backward(C.byref(split), C.byref(cam), fake, None, fake, fake, fake, fake, 1 << 30, 100, C.byref(grads), fake,
+                            None) == _lib.PGR_ERR_INVALID_ARGUMENT
     # records: stride below the layout's size, unaligned stride, NULL destination
     lay = _lib.PgrRecordLayout()
     assert lib.pgr_frame_record_layout(16, 16, 8, C.byref(lay)) == 0

@@ -502,6 +502,46 @@ def test_windowed_sort_with_scattered_depth_ties(oracle, gpu_device, n, pairs):
             np.testing.assert_array_equal(w["gauss_sorted"], want["gauss_sorted"], err_msg=f"view {k}")
 
 
+@pytest.mark.parametrize("degree,stride", [(0, 16), (1, 16), (2, 16), (3, 16), (1, 4), (2, 9), (3, 17), (0, 1)])
+def test_split_sh_layout_equals_the_concatenated_one(oracle, gpu_device, degree, stride):
+    """PgrScene::shs_rest: the SH coefficients as the model stores them (_features_dc [N,1,3] + _features_rest [N,K-1,3],
+    /root/reference/src/gs/gaussian_model.py:118-121) instead of get_features' torch.cat -- per-Gaussian colours bit-equal to
+    the concatenated layout's and to the oracle's, for every active degree and for strides that are not 16 (12-byte loads at
+    4-byte alignment); one view through the early-status call and a batch of three through the synchronous one."""
+    import torch
+    from helpers import fetch_workspace
+    from pegasus_amd import rasterizer as R
+    cloud, (view,) = scenes.scene_c1(seed=21, n=6000)
+    act = cloud.activated()
+    rng = np.random.default_rng(5)
+    shs = rng.normal(0, 0.4, size=(cloud.n, stride, 3)).astype(np.float32)
+    shs[:, 0] += 0.8
+    o = oracle.forward(**{**act, "shs": shs}, sh_degree=degree, **view.raster_kwargs(), num_threads=4, cull_mode=1)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(gpu_device)
+    T = {k: tt(a) for k, a in act.items() if k != "shs"}
+    full, dc, rest = tt(shs), tt(shs[:, :1]), tt(shs[:, 1:])
+    spec = R.ViewSpec(view.height, view.width, view.tanfovx, view.tanfovy, tt(np.zeros(3)), tt(view.world_view_transform),
+                      tt(view.full_proj_transform), tt(view.camera_center))
+    common = dict(scales=T["scales"], rotations=T["rotations"], sh_degree=degree, want_radii=True)
+    a = R.forward_views(T["means3d"], T["opacities"], [spec] * 3, shs=full, **common)
+    torch.cuda.synchronize()
+    a = [{k: r[k].clone() for k in ("color", "depth", "radii")} for r in a]
+    b = R.forward_views(T["means3d"], T["opacities"], [spec] * 3, shs=dc, shs_rest=rest, **common)
+    torch.cuda.synchronize()
+    w = fetch_workspace(1, cloud.n, view.width, view.height)
+    m = o["radii"] > 0
+    rec = w["rgb4"][m][:, :3]
+    np.testing.assert_array_equal(rec.view(np.uint32), o["rgb"][m].view(np.uint32))
+    for ra, rb in zip(a, b):
+        for k in ("color", "depth", "radii"):
+            assert torch.equal(ra[k], rb[k]), k
+    pb = R.forward_views(T["means3d"], T["opacities"], [spec], shs=dc, shs_rest=rest, async_slot=("split-sh", 0),
+                         early_status=True, **common)
+    one = pb.wait()[0]
+    for k in ("color", "depth", "radii"):
+        assert torch.equal(one[k], a[0][k]), k
+
+
 def test_every_tile_of_a_small_image_holds_a_long_list(oracle, gpu_device):
     """A 64x64 image (16 tiles) whose every tile lists 14-35 k pinpoint splats, three views per call: 36 of the batch's 48
     lists go through the split pre-pass (the launch that carries its workgroups is sized by the number of tiles -- here a
