@@ -79,8 +79,9 @@ typedef struct PgrScene {
                                     _features_rest (coefficients 1 .. sh_stride-1).  Saves the caller the torch.cat of
                                     get_features (/root/reference/src/gs/gaussian_model.py:118-121: 768 MB moved per
                                     render() of a freshly merged 2 M-Gaussian scene).  Same coefficients, same arithmetic:
-                                    results are bit-identical.  Forward entry points only (pgr_backward returns
-                                    PGR_ERR_INVALID_ARGUMENT: its SH gradient is one [n,sh_stride,3] array). */
+                                    results are bit-identical.  Forward entry points without PgrPosedObjects only
+                                    (with poses, and in pgr_backward -- whose SH gradient is one [n,sh_stride,3] array --
+                                    PGR_ERR_INVALID_ARGUMENT). */
 } PgrScene;
 
 /* The depth image's blend rule.  The reference's rasterizer is the absent fork `depth-diff-gaussian-rasterization`

@@ -223,7 +223,8 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     // on the stream that still reads the (pageable) table staging of the synchronous path
     // (per-Gaussian arrays of an EMPTY scene may be NULL: torch hands out a null pointer for an empty tensor)
     const bool empty = scene && scene->n == 0;
-    if (posed && ((!posed->object_id && !empty) || !posed->poses || posed->k_objects <= 0 || (scene && scene->cov3d_precomp)))
+    if (posed && ((!posed->object_id && !empty) || !posed->poses || posed->k_objects <= 0 ||
+                  (scene && (scene->cov3d_precomp || scene->shs_rest))))
         return PGR_ERR_INVALID_ARGUMENT;
     if (semantic && ((!semantic->object_id && !empty) || !semantic->colors || semantic->n_env < 0 || semantic->k_objects <= 0))
         return PGR_ERR_INVALID_ARGUMENT;
@@ -352,13 +353,15 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     const PosedDev pd{posed ? posed->object_id : nullptr, posed ? posed->poses : nullptr, posed ? posed->k_objects : 0};
     const int deg = scene->shs ? scene->sh_degree : 0;
     const LayerDev ld{layers ? layers->layer_id : nullptr, n_layers};
-#define PGR_PRE(D, Pz, Ly) preprocess_batch_kernel<D, Pz, Ly><<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, cams_dev, pre_table, n_views, pd, vis, B.vis_words, ld)
-#define PGR_PRE_DEG(Pz, Ly) switch (deg) { case 0: PGR_PRE(0, Pz, Ly); break; case 1: PGR_PRE(1, Pz, Ly); break; \
-                                           case 2: PGR_PRE(2, Pz, Ly); break; default: PGR_PRE(3, Pz, Ly); break; }
+#define PGR_PRE(D, Pz, Ly, Sp) preprocess_batch_kernel<D, Pz, Ly, Sp><<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, cams_dev, pre_table, n_views, pd, vis, B.vis_words, ld)
+#define PGR_PRE_DEG(Pz, Ly, Sp) switch (deg) { case 0: PGR_PRE(0, Pz, Ly, Sp); break; case 1: PGR_PRE(1, Pz, Ly, Sp); break; \
+                                               case 2: PGR_PRE(2, Pz, Ly, Sp); break; default: PGR_PRE(3, Pz, Ly, Sp); break; }
+    // (the split SH layout -- PgrScene::shs_rest, the single-view render() of a model as stored -- has its own kernels for the
+    //  plain and the layered call; a posed call takes the concatenated layout: check above)
     if (layers) {
-        if (posed) { PGR_PRE_DEG(true, true) } else { PGR_PRE_DEG(false, true) }
+        if (posed) { PGR_PRE_DEG(true, true, false) } else if (scene->shs_rest) { PGR_PRE_DEG(false, true, true) } else { PGR_PRE_DEG(false, true, false) }
     } else {
-        if (posed) { PGR_PRE_DEG(true, false) } else { PGR_PRE_DEG(false, false) }
+        if (posed) { PGR_PRE_DEG(true, false, false) } else if (scene->shs_rest) { PGR_PRE_DEG(false, false, true) } else { PGR_PRE_DEG(false, false, false) }
     }
 #undef PGR_PRE_DEG
 #undef PGR_PRE

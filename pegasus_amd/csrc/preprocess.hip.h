@@ -245,7 +245,9 @@ struct LayerDev {
 // for view 64 c + l whether the whole block is certainly culled there (one ballot = 64 views): such views are skipped by
 // the whole wave (radii / rectangles, where the caller wants them, are zero; the candidate rectangle is not written:
 // the binning walk consults the same bits, stored as vis_out[group * vis_words + view / 32]).
-template <int DEG, bool POSED, bool LAYERED = false>
+// SPLIT_SH: the coefficients come from two arrays (PgrScene::shs_rest) -- its own instantiation, so that the combined layout's
+// kernels are the ones they were (a run-time branch in front of the SH loads cost the batch preprocess 11 %).
+template <int DEG, bool POSED, bool LAYERED = false, bool SPLIT_SH = false>
 __global__ __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void preprocess_batch_kernel(PgrScene sc, const CameraDev* __restrict__ cams,
                                                                      const PreOut* __restrict__ outs, int n_views,
                                                                      PosedDev posed, uint32_t* __restrict__ vis_out,
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
     float cov[6];
     bool have_cov = false, have_sh = false;
     ShRegs sh;
-    const bool vec4 = !sc.shs_rest && (sc.sh_stride * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(sc.shs) & 15u) == 0;
+    const bool vec4 = (sc.sh_stride * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(sc.shs) & 15u) == 0;
 
     for (int v = 0; v < n_views; ++v) {
         const CameraDev& cam = cams[v];
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
                                           sc.colors_precomp[3 * (size_t)i + 2]);
                     } else {
                         if (!have_sh) {
-                            if (sc.shs_rest)
+                            if constexpr (SPLIT_SH)
                                 load_sh_split<DEG>(sh, sc.shs + (size_t)i * 3, sc.shs_rest + (size_t)i * (sc.sh_stride - 1) * 3);
                             else
                                 load_sh<DEG>(sh, sc.shs + (size_t)i * sc.sh_stride * 3, vec4);

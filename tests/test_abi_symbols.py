@@ -135,6 +135,9 @@ def test_new_entry_points_validate_before_any_launch():
         assert lib.pgr_forward(C.byref(bad_scene), C.byref(cam), C.byref(out), None, 0, 100, C.byref(need), None) == _lib.PGR_ERR_INVALID_ARGUMENT
     split = _lib.PgrScene(n=10, means3d=fake, opacities=fake, scales=fake, rotations=fake, shs=fake, shs_rest=fake, sh_degree=3,
                           sh_stride=16, scale_modifier=1.0)
+    posed = _lib.PgrPosedObjects(object_id=fake, poses=fake, k_objects=2)
+    assert lib.pgr_forward_posed_async(C.byref(split), None, C.byref(posed), 1, C.byref(cam), C.byref(out), fake, 1 << 30, 100,
+                                       scratch, len(scratch), None) == _lib.PGR_ERR_INVALID_ARGUMENT
     grads = _lib.PgrGradOutputs()
     assert lib.pgr_backward(C.byref(split), C.byref(cam), fake, None, fake, fake, fake, fake, 1 << 30, 100, C.byref(grads), fake,
                             None) == _lib.PGR_ERR_INVALID_ARGUMENT
