@@ -971,7 +971,11 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
                         "path_under_profiler": {name: kk["frac"] for name, kk in im["kernels"].get(args.workload, {}).items()
                                                 if not name.startswith("composite_quarter_kernel") or name == kern},
                         "source": "scripts/issue_model.py: profiles/r06_valu_classes.txt (costs), r06_valu_classes_pmc.txt (classes), "
-                                  + pmc_file.name + " (class counters), hipcc --save-temps ISA (split inside a class)"}
+                                  + pmc_file.name + " (class counters), hipcc --save-temps ISA (split inside a class)",
+                        # what the model is NOT: a promise that 1 - frac is there to be had by trimming vector instructions
+                        "model_check": "a build with 9 % fewer priced cycles per valid entry (blend under an exec mask) ran no faster, "
+                                       "one with 3 fewer waves per SIMD (LDS quads a pair ahead) 31 % slower: the kernel lives on "
+                                       "seven waves covering each other's per-entry chains (profiles/r06_blend_exec_ab.txt)"}
                 elif not same_build:
                     roofline["bound_note"] = (f"counter files on record describe another build of the library (pmc {pmc.get('library_sha16')}, "
                                               f"issue model {im.get('library_sha16', {}).get(args.workload)}, loaded {lib_sha}): `bound` stays the "
