@@ -38,6 +38,11 @@ static size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 // Calls of one or two views (the drop-in GaussianRasterizer: one camera per call) cannot fill the chip; their launches are
 // latency-bound and get a few arrangements of their own (fewer, fuller launches).  Results never depend on it.
 constexpr int SMALL_BATCH_VIEWS = 2;
+#ifndef PGR_PRE_SMALL_SCENE
+#define PGR_PRE_SMALL_SCENE 400000
+#endif
+constexpr int PRE_SMALL_SCENE = PGR_PRE_SMALL_SCENE;   // Gaussians: below this the preprocess spreads a batch's views over gridDim.y ...
+constexpr int PRE_VIEW_GROUP = 8;         // ... in groups of this many
 
 // A/B switch for tests and measurements (read per call; results never depend on it)
 static bool block_cull_enabled() {
@@ -348,12 +353,18 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     // PGR_BLOCK_CULL=0 switches the test off), left in `vis` for the binning walks
     // (one- and two-view calls skip it: bounding the blocks costs their latency-bound preprocess more than the skipped
     // work returns -- 98 -> 88 us for a single view of the 2 M-Gaussian scene)
-    uint32_t* vis = block_cull_enabled() && n_views > SMALL_BATCH_VIEWS ? reinterpret_cast<uint32_t*>(ws + B.vis) : nullptr;
+    // small scene, many views (an objects-only pass, a single object): the batch's views are spread over gridDim.y in groups of
+    // PRE_VIEW_GROUP instead of walked by one wave -- 200 k Gaussians are 3 000 waves, a quarter of what the chip holds, and 32
+    // views in a row per wave cost 0.31 ms where the arithmetic is 0.1.  Block culling is off there (its words hold 32 views).
+    const bool split_views = N <= PRE_SMALL_SCENE && n_views >= 2 * PRE_VIEW_GROUP;
+    const int view_groups = split_views ? (n_views + PRE_VIEW_GROUP - 1) / PRE_VIEW_GROUP : 1;
+    const int views_per_block = split_views ? PRE_VIEW_GROUP : n_views;
+    uint32_t* vis = block_cull_enabled() && n_views > SMALL_BATCH_VIEWS && !split_views ? reinterpret_cast<uint32_t*>(ws + B.vis) : nullptr;
     // one pass over the Gaussians for the whole batch (scene data read once, per-view outputs written)
     const PosedDev pd{posed ? posed->object_id : nullptr, posed ? posed->poses : nullptr, posed ? posed->k_objects : 0};
     const int deg = scene->shs ? scene->sh_degree : 0;
     const LayerDev ld{layers ? layers->layer_id : nullptr, n_layers};
-#define PGR_PRE(D, Pz, Ly, Sp) preprocess_batch_kernel<D, Pz, Ly, Sp><<<L.n_blocks, PRE_BLOCK, 0, stream>>>(*scene, cams_dev, pre_table, n_views, pd, vis, B.vis_words, ld)
+#define PGR_PRE(D, Pz, Ly, Sp) preprocess_batch_kernel<D, Pz, Ly, Sp><<<dim3(L.n_blocks, view_groups), PRE_BLOCK, 0, stream>>>(*scene, cams_dev, pre_table, n_views, pd, vis, B.vis_words, ld, views_per_block)
 #define PGR_PRE_DEG(Pz, Ly, Sp) switch (deg) { case 0: PGR_PRE(0, Pz, Ly, Sp); break; case 1: PGR_PRE(1, Pz, Ly, Sp); break; \
                                                case 2: PGR_PRE(2, Pz, Ly, Sp); break; default: PGR_PRE(3, Pz, Ly, Sp); break; }
     // (the split SH layout -- PgrScene::shs_rest, the single-view render() of a model as stored -- has its own kernels for the
@@ -446,7 +457,7 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
     if (layers) {
         sd.mask_colors = layers->mask_colors; sd.mask_thr = layers->mask_threshold; sd.k = n_layers;
         // empty (layer, tile) lists have no work item: their pixels hold the background's verdict
-        layer_mask_fill_kernel<<<dim3((unsigned)((P + 1023) / 1024), n_layers, n_views), 256, 0, stream>>>(
+        layer_mask_fill_kernel<<<dim3(LAYER_FILL_BLOCKS, n_layers, n_views), 256, 0, stream>>>(
             view_table, layers->mask_colors, layers->mask_threshold, P, layers->layer_id, N);
         launch_composite<false, false, true>(slots, stream, view_table, items_per_view, work_order, sd);
     } else if (want_aux && want_sem)

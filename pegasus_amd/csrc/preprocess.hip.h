@@ -251,7 +251,8 @@ template <int DEG, bool POSED, bool LAYERED = false, bool SPLIT_SH = false>
 __global__ __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void preprocess_batch_kernel(PgrScene sc, const CameraDev* __restrict__ cams,
                                                                      const PreOut* __restrict__ outs, int n_views,
                                                                      PosedDev posed, uint32_t* __restrict__ vis_out,
-                                                                     int vis_words, LayerDev layers = LayerDev{nullptr, 0}) {
+                                                                     int vis_words, LayerDev layers = LayerDev{nullptr, 0},
+                                                                     int views_per_block = 0x7fffffff) {
     const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & (WAVE - 1);
     if (i - lane >= sc.n) return;            // the whole wave is past the end
@@ -273,7 +274,12 @@ __global__ __launch_bounds__(PRE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
     ShRegs sh;
     const bool vec4 = (sc.sh_stride * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(sc.shs) & 15u) == 0;
 
-    for (int v = 0; v < n_views; ++v) {
+    // gridDim.y > 1 (small scenes: fewer waves than the chip holds): the views are dealt to blockIdx.y in groups of
+    // views_per_block -- a wave walks its views one after the other, and 3 000 waves doing 32 views each leave the SIMDs idle
+    // behind their dependency chains (vis_out is NULL then: its words hold 32 views)
+    const int v_begin = (int)blockIdx.y * views_per_block;
+    const int v_end = (int)min((long long)n_views, (long long)v_begin + views_per_block);
+    for (int v = v_begin; v < v_end; ++v) {
         const CameraDev& cam = cams[v];
         const PreOut& o = outs[v];
         if (vis_out) {
