@@ -177,6 +177,11 @@ def lib():
             raise RasterizerLibraryError(
                 f"{LIB_PATH} is missing: build it with `python -m pegasus_amd.build` "
                 "(there is no CPU fallback for the rasterizer)")
+        # torch FIRST: its wheel bundles its own libamdhip64 / libhsa-runtime64, and the library's DT_NEEDED entries name the
+        # same sonames -- loaded behind torch it binds to torch's runtime (one HIP runtime in the process, the one that owns
+        # the tensors it is handed); loaded in front of it the system's runtime comes in as a SECOND one and every HIP call
+        # of the library fails with "no ROCm-capable device is detected" (build() followed by smoke() in one process did)
+        import torch  # noqa: F401
         try:
             handle = C.CDLL(str(LIB_PATH))
         except OSError as e:

@@ -227,3 +227,24 @@ int main(void) {
     sizes = [int(x) for x in got["sizes"].split()]
     assert sizes == [C.sizeof(t) for t in (_lib.PgrScene, _lib.PgrCamera, _lib.PgrOutputs, _lib.PgrSemantic, _lib.PgrLayers,
                                            _lib.PgrPosedObjects)]
+
+
+def test_loading_the_library_leaves_one_hip_runtime_in_the_process():
+    """torch's wheel bundles its own libamdhip64 / libhsa-runtime64; the library must bind to THAT runtime whichever of the two
+    is asked for first (pegasus_amd._lib.lib() imports torch before dlopen).  With the system runtime loaded beside torch's,
+    every HIP call of the library failed with "no ROCm-capable device is detected" (build() then smoke() in one process)."""
+    import subprocess
+    import sys
+    root = str(Path(__file__).resolve().parents[1])
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from pegasus_amd import _lib\n"
+            "_lib.lib()\n"
+            "import torch\n"
+            "maps = open('/proc/self/maps').read()\n"
+            "hip = sorted({l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l})\n"
+            "hsa = sorted({l.split()[-1] for l in maps.splitlines() if 'libhsa-runtime64' in l})\n"
+            "print(hip, hsa)\n"
+            "assert len(hip) == 1 and len(hsa) <= 1, (hip, hsa)\n") % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+
