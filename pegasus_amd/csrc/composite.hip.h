@@ -572,14 +572,6 @@ __global__ __launch_bounds__(256) void layer_mask_fill_kernel(const ViewEntry* _
     }
 }
 
-// One launch prepares a batch's header: [zero, zero + n_zero) words cleared (tile counters | obj_last, work-order state),
-// [ff, ff + n_ff) words set to INVALID_ITEM (the work order).  Was three memsets.
-__global__ void batch_init_kernel(uint32_t* __restrict__ zero, size_t n_zero, uint32_t* __restrict__ ff, size_t n_ff) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += stride) gstore(zero + i, 0u);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ff; i += stride) gstore(ff + i, INVALID_ITEM);
-}
-
 // object ids of the object Gaussians as one byte each (see SemanticDev::object_u8)
 __global__ void pack_object_ids_kernel(const int32_t* __restrict__ object_id, int n_env, int n, uint8_t* __restrict__ out) {
     const int i = n_env + blockIdx.x * blockDim.x + threadIdx.x;

@@ -212,6 +212,24 @@ static int zero_outputs(const PgrOutputs* out, size_t P, hipStream_t stream, int
     return PGR_OK;
 }
 
+// The batch header in ONE launch: tile counters | obj_last and the work-order state cleared, the work order invalid, the first
+// CAM_PACK_MAX cameras packed, and -- one- and two-view calls -- the pointer tables written from the launch arguments.  A
+// single-view call lasts 0.45 ms on the GPU: the H2D copy of its 300 bytes of tables and the camera launch were 10 us of it.
+constexpr int HEADER_TABLE_WORDS = 256;
+struct HeaderTables { uint32_t w[HEADER_TABLE_WORDS]; };
+__global__ __launch_bounds__(256) void batch_header_kernel(uint32_t* __restrict__ zero, size_t n_zero, uint32_t* __restrict__ ff,
+                                                           size_t n_ff, CamPack cams, int cam_count, int width, int height,
+                                                           CameraDev* __restrict__ cams_out, HeaderTables tables,
+                                                           uint32_t* __restrict__ tables_out, int table_words) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += stride) gstore(zero + i, 0u);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ff; i += stride) gstore(ff + i, INVALID_ITEM);
+    if ((int)blockIdx.x < cam_count && threadIdx.x < 64)
+        pack_camera(cams, (int)blockIdx.x, (int)threadIdx.x, width, height, cams_out + blockIdx.x);
+    if (blockIdx.x == gridDim.x - 1)
+        for (int i = threadIdx.x; i < table_words; i += blockDim.x) gstore(tables_out + i, tables.w[i]);
+}
+
 // The whole hot path for a batch of views of ONE scene.  All views share the image size.
 // ev: optional PGR_NUM_STAGES+1 events recorded at the stage boundaries (profiling entry point only).
 // host_scratch: NULL = synchronous call (tables staged from pageable memory, stream synchronised at the end,
@@ -327,27 +345,40 @@ static int32_t forward_batch_impl(const PgrScene* scene, int n_views, const PgrC
         // radii (12 N bytes per view the frame path never reads; pgr_workspace_view's `rects` is valid only then)
         pres[v] = PreOut{vw[v].splats, outs[v].radii ? vw[v].rects : nullptr, vw[v].crects, outs[v].radii};
     }
-    if (!hip_ok(hipMemcpyAsync(ws + B.tables, hs, B.tables_bytes, hipMemcpyHostToDevice, stream), "memcpy tables"))
+    // the pointer tables: in the header launch's arguments when they are small (one / two views), else one H2D copy
+    HeaderTables header_tables;
+    int table_words = 0;
+    if (n_views <= SMALL_BATCH_VIEWS && B.tables_bytes <= sizeof(header_tables)) {
+        memcpy(header_tables.w, hs, B.tables_bytes);
+        table_words = (int)(B.tables_bytes / 4);
+    } else if (!hip_ok(hipMemcpyAsync(ws + B.tables, hs, B.tables_bytes, hipMemcpyHostToDevice, stream), "memcpy tables"))
         return fail(PGR_ERR_LAUNCH_FAILURE);
 
-    // ---- stage 0: camera pack + per-Gaussian preprocess
+    // ---- stage 0: batch header (+ cameras) + per-Gaussian preprocess
     mark(0);
-    // the batch header in one launch: tile counters | obj_last and the work-order state cleared, the work order invalid
     static_assert(ORDER_STATE_WORDS * 4 <= 256, "order state fits its slot");
-    batch_init_kernel<<<256, 256, 0, stream>>>(reinterpret_cast<uint32_t*>(ws + B.tile_counts), (B.work_order - B.tile_counts) / 4,
-                                              reinterpret_cast<uint32_t*>(ws + B.work_order), B.order_slots);
-    if (scene->tie_index && !scene->tie_inv)     // (a per-scene constant: pgr_scene_prepare computes it once)
-        invert_tie_index_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, scene->tie_index,
-                                                                      reinterpret_cast<uint32_t*>(ws + B.tie_inv));
-    for (int v0 = 0; v0 < n_views; v0 += CAM_PACK_MAX) {
+    auto camera_pack = [&](int v0, int cnt) {
         CamPack cp;
-        const int cnt = std::min(CAM_PACK_MAX, n_views - v0);
         for (int k = 0; k < cnt; ++k) {
             const PgrCamera& c = cams[v0 + k];
             cp.view[k] = c.viewmatrix; cp.proj[k] = c.projmatrix; cp.campos[k] = c.campos; cp.bg[k] = c.bg;
             cp.tanfovx[k] = c.tanfovx; cp.tanfovy[k] = c.tanfovy; cp.depth_mode[k] = c.depth_mode;
         }
-        pack_camera_kernel<<<cnt, 64, 0, stream>>>(cp, W, H, cams_dev + v0);
+        return cp;
+    };
+    {
+        const int cnt = std::min(CAM_PACK_MAX, n_views);
+        batch_header_kernel<<<256, 256, 0, stream>>>(
+            reinterpret_cast<uint32_t*>(ws + B.tile_counts), (B.work_order - B.tile_counts) / 4,
+            reinterpret_cast<uint32_t*>(ws + B.work_order), B.order_slots, camera_pack(0, cnt), cnt, W, H, cams_dev, header_tables,
+            reinterpret_cast<uint32_t*>(ws + B.tables), table_words);
+    }
+    if (scene->tie_index && !scene->tie_inv)     // (a per-scene constant: pgr_scene_prepare computes it once)
+        invert_tie_index_kernel<<<(N + 255) / 256, 256, 0, stream>>>(N, scene->tie_index,
+                                                                      reinterpret_cast<uint32_t*>(ws + B.tie_inv));
+    for (int v0 = CAM_PACK_MAX; v0 < n_views; v0 += CAM_PACK_MAX) {
+        const int cnt = std::min(CAM_PACK_MAX, n_views - v0);
+        pack_camera_kernel<<<cnt, 64, 0, stream>>>(camera_pack(v0, cnt), W, H, cams_dev + v0);
     }
     // which 64-Gaussian blocks can show up in which view: decided by the preprocess waves themselves (conservative;
     // PGR_BLOCK_CULL=0 switches the test off), left in `vis` for the binning walks

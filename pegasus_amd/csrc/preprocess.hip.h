@@ -461,9 +461,7 @@ struct CamPack {
     int32_t depth_mode[CAM_PACK_MAX];
 };
 
-__global__ void pack_camera_kernel(CamPack p, int width, int height, CameraDev* __restrict__ outs) {
-    const int v = blockIdx.x, t = threadIdx.x;
-    CameraDev* out = outs + v;
+__device__ __forceinline__ void pack_camera(const CamPack& p, int v, int t, int width, int height, CameraDev* __restrict__ out) {
     if (t < 16) {
         out->view[t] = p.view[v][t];
         out->proj[t] = p.proj[v][t];
@@ -484,6 +482,10 @@ __global__ void pack_camera_kernel(CamPack p, int width, int height, CameraDev* 
         out->grid_y = (height + TILE - 1) / TILE;
         out->depth_mode = p.depth_mode[v];
     }
+}
+
+__global__ void pack_camera_kernel(CamPack p, int width, int height, CameraDev* __restrict__ outs) {
+    pack_camera(p, (int)blockIdx.x, (int)threadIdx.x, width, height, outs + blockIdx.x);
 }
 
 __global__ void mark_visible_kernel(int n, const float* __restrict__ means3d, const float* __restrict__ vm,

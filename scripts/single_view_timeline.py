@@ -22,11 +22,12 @@ def short(name):
     return (m.group(1) + (m.group(2) or "")) if m else name[:200]
 
 
-# a call = the kernels from one preprocess_batch_kernel to the next
+# a call = the kernels from one preprocess_batch_kernel to the next, cut at the kernel that packs its camera
+cutter = "batch_header" if any("batch_header_kernel" in n for _, _, n in rows) else "pack_camera"
 calls, cur = [], None
 for s, e, n in rows:
     k = short(n)
-    if k.startswith("pack_camera"):
+    if k.startswith(cutter):
         if cur:
             calls.append(cur)
         cur = []
