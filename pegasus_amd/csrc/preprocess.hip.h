@@ -201,18 +201,23 @@ __device__ __forceinline__ void load_sh(ShRegs& sh, const float* __restrict__ p,
 }
 
 // The split layout (PgrScene::shs_rest): coefficient 0 from the [n,1,3] array, the others from the [n,stride-1,3] one.
-// Rows of 3 and 3 (stride - 1) floats are only 4-B aligned: 12-B loads (global_load_dwordx3), one per coefficient.
+// Rows of 3 and 3 (stride - 1) floats are only 4-B aligned -- which is all a global load asks for: the first coefficient is
+// one 12-B load, the others arrive as 16-B quads (eleven + one word at degree 3: as many loads as the concatenated layout's
+// twelve; one 12-B load per coefficient cost a single-view call 6 us of its preprocess).
 typedef float f32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 template <int DEG>
 __device__ __forceinline__ void load_sh_split(ShRegs& sh, const float* __restrict__ dc, const float* __restrict__ rest) {
-    constexpr int NC = (DEG + 1) * (DEG + 1);
+    constexpr int NR = 3 * ((DEG + 1) * (DEG + 1) - 1);      // floats of the higher coefficients
     const f32x3_a4 c0 = *reinterpret_cast<const f32x3_a4*>(dc);
     sh.v[0] = c0.x; sh.v[1] = c0.y; sh.v[2] = c0.z;
 #pragma unroll
-    for (int k = 1; k < NC; ++k) {
-        const f32x3_a4 c = *reinterpret_cast<const f32x3_a4*>(rest + 3 * (k - 1));
-        sh.v[3 * k + 0] = c.x; sh.v[3 * k + 1] = c.y; sh.v[3 * k + 2] = c.z;
+    for (int k = 0; k < NR / 4; ++k) {
+        const f32x4_a4 q = *reinterpret_cast<const f32x4_a4*>(rest + 4 * k);
+        sh.v[3 + 4 * k + 0] = q.x; sh.v[3 + 4 * k + 1] = q.y; sh.v[3 + 4 * k + 2] = q.z; sh.v[3 + 4 * k + 3] = q.w;
     }
+#pragma unroll
+    for (int k = NR / 4 * 4; k < NR; ++k) sh.v[3 + k] = rest[k];
 }
 
 // One thread per Gaussian, ALL views of the batch: the 236 B of scene data are read from HBM once per
