@@ -1,6 +1,6 @@
 """N gaussian_renderer.render() calls on the C3 scene, one camera each -- the drop-in path of an unchanged PEGASUS loop
 (/root/reference/pegasus.py:254-271).  Run under `rocprofv3 --kernel-trace` by scripts/single_view_trace.sh; prints the
-un-profiled per-call time when run on its own."""
+un-profiled per-call time when run on its own.  python scripts/single_view_calls.py [calls] [workload] [concatenated]"""
 import sys
 import time
 from argparse import ArgumentParser
@@ -23,6 +23,8 @@ cloud, views, label = bench.build_workload(workload, 1.0, max(n_calls, 8))
 pc = GaussianModel.from_arrays(cloud.xyz, cloud.features_dc, cloud.features_rest, cloud.opacity, cloud.scaling, cloud.rotation, device=dev)
 cams = [Camera(colmap_id=i, R=v.R_c2w, T=v.t_w2c, FoVx=v.fovx, FoVy=v.fovy, image=None, image_width=v.width, image_height=v.height,
                gt_alpha_mask=None, image_name=str(i), uid=i, data_device=dev) for i, v in enumerate(views[:n_calls])]
+if len(sys.argv) > 3 and sys.argv[3] == "concatenated":      # A/B: get_features' torch.cat (kept between calls) instead of the stored layout
+    GR._colour = lambda pc_, pipe_, cam_, override: dict(shs=GR.kept_activation(pc_, "get_features"))
 pipe = PipelineParams(ArgumentParser())
 bg = torch.zeros(3, device=dev)
 with torch.no_grad():

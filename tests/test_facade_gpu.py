@@ -514,6 +514,10 @@ def test_render_returns_behind_the_tile_scan_with_stream_ordered_outputs(gpu_dev
                 assert torch.equal(g[3], w["radii"] > 0)
         info = R.last_forward_info()
         assert int(info["num_instances"][0]) > 0 and info["n_views"] == 1
+        # (nine renders of the unchanged model: the first three read the SH coefficients as stored -- _features_dc +
+        #  _features_rest, PgrScene::shs_rest --, from the fourth on the kept concatenation: all equal the reference above)
+        from pegasus_amd import gaussian_renderer as GR
+        assert "get_features" in GR._SLOTS[pc] and GR._SLOTS[pc]["split_renders"][1] == GR.SPLIT_RENDERS
         # an in-place edit of the model right behind a call lands AFTER that call's preprocess in stream order
         before = render(cams[0], pc, pipe, bg)["render"]
         pc._xyz[:, 2] += 0.05
