@@ -973,9 +973,11 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
                         "source": "scripts/issue_model.py: profiles/r06_valu_classes.txt (costs), r06_valu_classes_pmc.txt (classes), "
                                   + pmc_file.name + " (class counters), hipcc --save-temps ISA (split inside a class)",
                         # what the model is NOT: a promise that 1 - frac is there to be had by trimming vector instructions
-                        "model_check": "a build with 9 % fewer priced cycles per valid entry (blend under an exec mask) ran no faster, "
-                                       "one with 3 fewer waves per SIMD (LDS quads a pair ahead) 31 % slower: the kernel lives on "
-                                       "seven waves covering each other's per-entry chains (profiles/r06_blend_exec_ab.txt)"}
+                        "model_check": "a build with 9 % fewer priced vector cycles per valid entry but two scalar instructions and a "
+                                       "branch more (blend under an exec mask) ran no faster; capped at 6 / 5 / 4 waves per SIMD the kernel "
+                                       "takes +3 / +8 / +18 % (the flat part of its occupancy curve: an issue limit, not latency).  The limit "
+                                       "is the SIMD's issue as a whole -- this vector figure AND salu_per_cu_cycle -- not the vector port "
+                                       "alone (profiles/r06_blend_exec_ab.txt)"}
                 elif not same_build:
                     roofline["bound_note"] = (f"counter files on record describe another build of the library (pmc {pmc.get('library_sha16')}, "
                                               f"issue model {im.get('library_sha16', {}).get(args.workload)}, loaded {lib_sha}): `bound` stays the "
