@@ -557,7 +557,8 @@ def run_worker(args):
             raise SystemExit("--facade measures the single-process drop-in path: run it with --gpus 1")
         d = drop_in_numbers(eng, n_frames=16, n_render_calls=128)
         d_dyn = drop_in_numbers(eng, n_frames=16, n_render_calls=8, dynamic=True)
-        d["dynamic"] = {k: d_dyn[k] for k in ("mode", "frames_per_s", "ms_per_frame", "frames_per_s_all_data_points", "ms_per_part")}
+        d["dynamic"] = {k: d_dyn[k] for k in ("mode", "frames_per_s", "ms_per_frame", "frames_per_s_all_data_points", "ms_per_part",
+                                                "passes_ms_per_frame")}
         mode = "DYNAMIC scene: every object re-posed between frames through the reference's three pose calls, the objects-only " \
                "semantic scene rebuilt every frame" if args.dynamic else \
                "static scene: the objects-only semantic scene and its render are shared by the two semantic wrappers and kept " \
@@ -1005,7 +1006,7 @@ def _finish_real_line(args, eng, line, value, world, dist_info, gather_info, reh
         dyn = side_leg(drop_in_numbers, eng, n_frames=6, n_render_calls=4, dynamic=True)
         if isinstance(drop_in, dict) and "error" not in drop_in:
             drop_in["dynamic"] = ({k: dyn[k] for k in ("mode", "frames_per_s", "ms_per_frame", "frames_per_s_all_data_points",
-                                                       "ms_per_part")} if "error" not in dyn else dyn)
+                                                       "ms_per_part", "passes_ms_per_frame")} if "error" not in dyn else dyn)
 
     N_label = f"{N / 1e6:.2g}M"
     line.update(
@@ -1181,29 +1182,34 @@ def drop_in_numbers(eng, n_frames=4, n_render_calls=48, dynamic=False):
     with torch.no_grad():
         for _ in range(3):                                           # warm-up: allocator blocks of every size, pinned host
             scene = frame(cams[0])                                   # buffers, first-use costs of the pose path
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for c in cams[1:n_frames + 1]:
-            scene = frame(c)
-        torch.cuda.synchronize()
-        t_frame = (time.perf_counter() - t0) / n_frames
+        # a host-bound loop on a shared box: the median of three passes (one pass alone has come out a third low -- a
+        # neighbour on the host's cores -- where the passes before and after it agreed to 3 %)
+        def timed_pass(**kw):
+            nonlocal scene
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for c in cams[1:n_frames + 1]:
+                scene = frame(c, **kw)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n_frames
+        passes = sorted(timed_pass() for _ in range(3))
+        t_frame = passes[1]
         frame(cams[0], silhouettes=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for c in cams[1:n_frames + 1]:                               # all five default data points: + the K silhouettes
-            frame(c, silhouettes=True)
-        torch.cuda.synchronize()
-        t_frame_all = (time.perf_counter() - t0) / n_frames
+        passes_all = sorted(timed_pass(silhouettes=True) for _ in range(3))      # all five default data points: + the K silhouettes
+        t_frame_all = passes_all[1]
         for c in cams[1:n_frames + 1]:                               # once more with a synchronisation after every part
             frame(c, clock=True)
         for c in cams[:4]:
             GR.render(c, scene, pipe, bg)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for c in cams[:n_render_calls]:
-            GR.render(c, scene, pipe, bg)
-        torch.cuda.synchronize()
-        t_call = (time.perf_counter() - t0) / min(n_render_calls, len(cams))
+        calls = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for c in cams[:n_render_calls]:
+                GR.render(c, scene, pipe, bg)
+            torch.cuda.synchronize()
+            calls.append((time.perf_counter() - t0) / min(n_render_calls, len(cams)))
+        t_call = sorted(calls)[1]
     return {"mode": "dynamic" if dynamic else "static",
             "frames_per_s": round(1.0 / t_frame, 2), "ms_per_frame": round(t_frame * 1e3, 3),
             "frames_per_s_all_data_points": round(1.0 / t_frame_all, 2),
@@ -1217,7 +1223,9 @@ def drop_in_numbers(eng, n_frames=4, n_render_calls=48, dynamic=False):
                      "(mode = dynamic): after every frame each object is moved by the delta of its recorded trajectory through the "
                      "reference's three pose calls (pegasus.py:387-390, pegasus_setup.py:178-208), so the objects-only scene is "
                      "rebuilt every frame",
-            "sample": f"{n_frames} frames, {min(n_render_calls, len(cams))} render() calls; same scene and cameras as the batch path"}
+            "sample": f"median of three passes of {n_frames} frames / of {min(n_render_calls, len(cams))} render() calls; same scene and "
+                      "cameras as the batch path",
+            "passes_ms_per_frame": [round(t * 1e3, 3) for t in passes]}
 
 
 def run_cpu_only(args):
