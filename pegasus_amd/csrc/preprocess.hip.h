@@ -203,7 +203,9 @@ __device__ __forceinline__ void load_sh(ShRegs& sh, const float* __restrict__ p,
 // The split layout (PgrScene::shs_rest): coefficient 0 from the [n,1,3] array, the others from the [n,stride-1,3] one.
 // Rows of 3 and 3 (stride - 1) floats are only 4-B aligned -- which is all a global load asks for: the first coefficient is
 // one 12-B load, the others arrive as 16-B quads (eleven + one word at degree 3: as many loads as the concatenated layout's
-// twelve; one 12-B load per coefficient cost a single-view call 6 us of its preprocess).
+// twelve).  What the split layout costs is not the load count (one 12-B load per coefficient measured the same on one box)
+// but the rows themselves: 180 + 12 B straddle the cache lines that rows of 192 B sit in -- a single view's preprocess takes
+// 92 us against 83 (gaussian_renderer.py keeps the concatenation for a model that is rendered again and again).
 typedef float f32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
 typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 template <int DEG>
