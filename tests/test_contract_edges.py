@@ -132,3 +132,39 @@ def test_batch_in_which_only_some_views_overflow(gpu_device):
     torch.cuda.synchronize()
     for k in ("color", "depth", "seg", "masks"):
         assert torch.equal(out[k], ref[k]), k
+
+
+@pytest.mark.gpu
+def test_early_status_reports_every_view_of_a_batch(gpu_device):
+    """pgr_forward_posed_early_status with FOUR views: the tile scan of every view stores that view's instance count and
+    overflow flag into the pinned host scratch, the event behind the scan releases the host, and the status it reads is the
+    batch's -- the counts of every view, and PGR_ERR_INSTANCE_OVERFLOW (re-render at the grown capacity) when only some views
+    do not fit.  Images equal the synchronous call's."""
+    import torch
+    from pegasus_amd import frames as F, rasterizer as R, scenes
+    cloud, views = scenes.scene_c3(scale=0.04, n_views=4, width=320, height=240)
+    act = cloud.activated()
+    fr = F.FrameRenderer(act["means3d"], act["opacities"], act["scales"], act["rotations"], act["shs"],
+                         cloud.object_id, sh_degree=3, device=gpu_device)
+    specs = [fr.view_spec(v) for v in views]
+    kw = dict(shs=fr.shs, scales=fr.scales, rotations=fr.rotations, sh_degree=fr.sh_degree, tie_index=fr.tie_index, want_radii=False)
+    ref = R.forward_views(fr.means3d, fr.opacities, specs, **kw)
+    torch.cuda.synchronize()
+    need = [int(x) for x in R.last_forward_info()["num_instances"]]
+    ref = [{k: r[k].clone() for k in ("color", "depth")} for r in ref]
+    assert min(need) < max(need)
+    pb = R.forward_views(fr.means3d, fr.opacities, specs, async_slot=("early-batch", 0), early_status=True, **kw)
+    got = pb.wait()
+    assert pb.num_instances == need and not getattr(pb, "_was_redone", False)
+    for g, r in zip(got, ref):
+        assert torch.equal(g["color"], r["color"]) and torch.equal(g["depth"], r["depth"])
+    # room for the lightest view only: the flags of the others arrive with the early status, the batch is rendered again
+    key = (torch.device(gpu_device), int(fr.means3d.shape[0]), 320, 240)
+    R.set_capacity_hint(key, (min(need) + max(need)) // 2)
+    R.drop_async_workspaces()
+    pb = R.forward_views(fr.means3d, fr.opacities, specs, async_slot=("early-batch", 0), early_status=True, **kw)
+    got = pb.wait()
+    torch.cuda.synchronize()
+    assert getattr(pb, "_was_redone", False) and pb.num_instances == need
+    for g, r in zip(got, ref):
+        assert torch.equal(g["color"], r["color"]) and torch.equal(g["depth"], r["depth"])
